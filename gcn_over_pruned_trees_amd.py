@@ -1,0 +1,15 @@
+"""
+Import alias.  The package directory is named `gcn-over-pruned-trees_amd/` (hyphens, so it cannot be
+written in an `import` statement); importing `gcn_over_pruned_trees_amd` loads that directory as a
+regular package under this name.
+"""
+import importlib.util as _ilu
+import os as _os
+import sys as _sys
+
+_dir = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "gcn-over-pruned-trees_amd")
+_spec = _ilu.spec_from_file_location(__name__, _os.path.join(_dir, "__init__.py"),
+                                     submodule_search_locations=[_dir])
+_mod = _ilu.module_from_spec(_spec)
+_sys.modules[__name__] = _mod
+_spec.loader.exec_module(_mod)

@@ -1,0 +1,142 @@
+"""
+oracle/gcn_ref.py  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+NumPy CPU restatement of the reference's GCN layer loop (`adj_type == 'regular'`) and of
+its autograd, used only as the checker by tests/, __graft_entry__.smoke() and the
+`cpu_baseline` leg of bench.py.  Nothing under gcn-over-pruned-trees_amd/ imports it.
+
+Parity pin: tests/golden/layers_*.npz, generated from the live reference
+(/root/reference, torch CPU) by tests/golden/make_golden.py; checked in
+tests/test_oracle_golden.py.
+
+Reference lines followed (all model/gcn.py):
+  260   adj_matrix = where(adj != 0, 1, 0)
+  261   denom = adj_matrix.sum(2) + 1
+  262   mask  = (adj_matrix.sum(2) + adj_matrix.sum(1)).eq(0)
+  264-265 no_adj ablation zeroes adj_matrix AFTER denom/mask were taken
+  269   Ax  = adj_matrix.bmm(gcn_inputs)
+  270   AxW = W[l](Ax)
+  271   AxW = AxW + W[l](gcn_inputs)          (bias therefore enters twice)
+  390   AxW = AxW / denom
+  392   gAxW = relu(AxW)
+  393   dropout on every layer but the last
+  473-483 pool()
+"""
+import numpy as np
+
+INFINITY_NUMBER = 1e12  # utils/constant.py:35
+
+
+def adjacency_prep(adj):
+    """gcn.py:260-262.  adj: float32 [B,T,T] with deprel labels -> (A, denom, mask)."""
+    A = (adj != 0).astype(np.float32)
+    row = A.sum(2)
+    denom = (row + 1.0)[..., None].astype(np.float32)
+    mask = ((row + A.sum(1)) == 0)[..., None]
+    return A, denom, mask
+
+
+def gcn_forward(adj, x, weights, biases, drop_masks=None, drop_p=0.0, no_adj=False, return_saved=False):
+    """
+    Layer loop of GCN.forward (gcn.py:258-395) in float32.
+
+    adj      float32 [B,T,T]   labelled adjacency from tree_to_adj
+    x        float32 [B,T,Din] gcn_inputs (embeddings / BiLSTM output)
+    weights  list of [H,Din_l] (nn.Linear layout, gcn.py:176), biases list of [H]
+    drop_masks  optional list (len L-1) of {0,1} arrays [B,T,H]; the kept values are scaled by
+                1/(1-drop_p) exactly as nn.Dropout does (gcn.py:393).  None = eval mode / p = 0.
+    returns (h_L [B,T,H], mask bool [B,T,1])
+    """
+    A, denom, mask = adjacency_prep(adj)
+    if no_adj:
+        A = np.zeros_like(A)
+    h = np.asarray(x, dtype=np.float32)
+    saved = []
+    L = len(weights)
+    for l in range(L):
+        W = np.asarray(weights[l], dtype=np.float32)
+        b = np.asarray(biases[l], dtype=np.float32)
+        Ax = np.matmul(A, h)                       # gcn.py:269
+        AxW = np.matmul(Ax, W.T) + b               # gcn.py:270
+        AxW = AxW + (np.matmul(h, W.T) + b)        # gcn.py:271
+        AxW = AxW / denom                          # gcn.py:390
+        g = np.maximum(AxW, 0.0)                   # gcn.py:392
+        if l < L - 1 and drop_masks is not None and drop_p > 0.0:
+            scale = np.float32(1.0 / (1.0 - drop_p))
+            out = g * drop_masks[l].astype(np.float32) * scale   # gcn.py:393
+        else:
+            out = g
+        saved.append((h, Ax, out))
+        h = out.astype(np.float32)
+    if return_saved:
+        return h, mask, (A, denom, saved)
+    return h, mask
+
+
+def gcn_backward(adj, x, weights, biases, gy, drop_masks=None, drop_p=0.0, no_adj=False):
+    """
+    What torch autograd produces for gcn_forward:
+      dZ = dY * 1[out != 0] * dropscale / denom ;  dS = dZ W ;  dh = A^T dS + dS
+      dW = dZ^T (A h + h) ;  db = 2 * sum dZ
+    returns (dx, [dW_l], [db_l])
+    """
+    h_L, _, (A, denom, saved) = gcn_forward(adj, x, weights, biases, drop_masks, drop_p, no_adj, True)
+    L = len(weights)
+    g = np.asarray(gy, dtype=np.float32)
+    dWs, dbs = [None] * L, [None] * L
+    At = np.transpose(A, (0, 2, 1))
+    for l in reversed(range(L)):
+        h_in, Ax, out = saved[l]
+        W = np.asarray(weights[l], dtype=np.float32)
+        scale = np.float32(1.0)
+        if l < L - 1 and drop_masks is not None and drop_p > 0.0:
+            scale = np.float32(1.0 / (1.0 - drop_p))
+        dZ = g * (out > 0) * scale / denom          # relu', dropout and /denom in one factor
+        S = Ax + h_in
+        H, Din = W.shape
+        dWs[l] = np.matmul(dZ.reshape(-1, H).T, S.reshape(-1, Din)).astype(np.float32)
+        dbs[l] = (2.0 * dZ.reshape(-1, H).sum(0)).astype(np.float32)
+        dS = np.matmul(dZ, W)
+        g = (np.matmul(At, dS) + dS).astype(np.float32)
+    return g, dWs, dbs
+
+
+def pool(h, mask, type="max"):
+    """gcn.py:473-483."""
+    if type == "max":
+        return np.where(mask, np.float32(-INFINITY_NUMBER), h).max(1)
+    hz = np.where(mask, np.float32(0), h)
+    if type == "avg":
+        return hz.sum(1) / (mask.shape[1] - mask.astype(np.float32).sum(1))
+    return hz.sum(1)
+
+
+# ----------------------------------------------------------------------------------------------
+# bf16-storage variant: what the HIP path computes when `dtype = bf16` (bf16 operands and stored
+# activations, fp32 accumulation).  Used for the tight comparison; the fp32 functions above are
+# the loose one.  Not part of the reference -- the reference is fp32 only.
+# ----------------------------------------------------------------------------------------------
+def round_bf16(a):
+    """round-to-nearest-even float32 -> bfloat16 -> float32 (finite inputs)."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    u = a.view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).reshape(a.shape)
+
+
+def gcn_forward_bf16(adj, x, weights, biases, drop_masks=None, drop_p=0.0):
+    A, denom, mask = adjacency_prep(adj)
+    h = round_bf16(x)
+    L = len(weights)
+    acts = [h]
+    for l in range(L):
+        W = round_bf16(weights[l])
+        b = np.asarray(biases[l], dtype=np.float32)
+        S = round_bf16(np.matmul(A, h) + h)                      # gather sum in fp32, staged as bf16
+        Z = np.matmul(S.astype(np.float64), W.T.astype(np.float64)).astype(np.float32) + 2.0 * b
+        g = np.maximum(Z / denom, 0.0).astype(np.float32)
+        if l < L - 1 and drop_masks is not None and drop_p > 0.0:
+            g = g * drop_masks[l].astype(np.float32) * np.float32(1.0 / (1.0 - drop_p))
+        h = round_bf16(g)
+        acts.append(h)
+    return h, mask, acts

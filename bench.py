@@ -1,0 +1,349 @@
+#!/usr/bin/env python3
+"""
+bench.py -- BASELINE.json metric: GCN-layer fwd+bwd sentences/sec at batch=50 seq=100 h=200 on N MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]            (N > 1: launched by torch.distributed.run)
+
+One "step" = the hot path over one synthetic TACRED-shaped batch of 50 sentences x 100 tokens
+(BASELINE.json configs[1]: 2-layer GCN, no LSTM, Din 360 -> 200 -> 200, prune_k 1, bf16 storage,
+fp32 accumulation, dropout 0.5 between the layers), entirely through the C-ABI of include/gcnpt.h:
+    pack W0,W1 -> layer0 fwd -> layer1 fwd -> layer1 bwd (weight, data) -> layer0 bwd (weight, data)
+Inputs (x, gy, weights, the loader's integer tensors) are resident in HBM before the timed region.
+`value` is the layer stack alone, as the metric says; `with_prune` repeats the measurement with the
+pruned-tree adjacency build (gcnpt_prune_to_csr) inside every step.
+For N > 1 every rank runs its own 50-sentence shard (weak scaling, no data-path collective) and the
+flat gradient bucket [dW0,db0,dW1,db1] is all-reduced over RCCL once per step, overlapped with the
+next step's compute (BASELINE.json configs[3]).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant kernel and
+`cpu_baseline` (the CPU oracle -- a numpy port of the reference's dense-bmm layer loop -- on this box's cores).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--batch", type=int, default=50)
+    ap.add_argument("--seq", type=int, default=100)
+    ap.add_argument("--din", type=int, default=360)
+    ap.add_argument("--hidden", type=int, default=200)
+    ap.add_argument("--prune-k", type=int, default=1)
+    ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--lengths", choices=["full", "tacred"], default="full")
+    ap.add_argument("--drop", type=float, default=0.5)
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-kernel-breakdown", action="store_true")
+    return ap.parse_args()
+
+
+class Stack(object):
+    """Device buffers of one rank's shard and the C-ABI calls of one step."""
+
+    def __init__(self, args, dev, seed):
+        from gcn_over_pruned_trees_amd import _lib
+        from gcn_over_pruned_trees_amd.model import tree
+        from gcn_over_pruned_trees_amd.utils import synthetic
+        self.L, self._lib, self.tree = _lib.lib(), _lib, tree
+        self.args, self.dev = args, dev
+        B, T, Din, H = args.batch, args.seq, args.din, args.hidden
+        self.B, self.T, self.Din, self.H = B, T, Din, H
+        act = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+        self.compute = _lib.BF16 if args.dtype == "bf16" else _lib.F32
+        self.act = _lib.dtype_code(act)
+        tb = synthetic.random_tree_batch(seed, B, T, args.lengths)
+        self.tb = tb
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+        self.head, self.subj, self.obj, self.deprel, self.masks = (t(tb[k]) for k in ("head", "subj_pos", "obj_pos", "deprel", "masks"))
+        Ws, bs = synthetic.layer_params(seed + 1, [Din, H, H])
+        self.W = [t(w) for w in Ws]
+        self.b = [t(b) for b in bs]
+        self.x = t(synthetic.normal(seed + 2, (B, T, Din))).to(act)
+        self.gy = t(synthetic.normal(seed + 3, (B, T, H))).to(act)
+        self.h1 = torch.empty((B, T, H), dtype=act, device=dev)
+        self.h2 = torch.empty((B, T, H), dtype=act, device=dev)
+        self.dh1 = torch.empty((B, T, H), dtype=act, device=dev)
+        self.dx = torch.empty((B, T, Din), dtype=act, device=dev)
+        dims = [(H, Din), (H, H)]
+        self.wf = [torch.empty((self.L.gcnpt_packed_bytes(h, d, self.compute),), dtype=torch.uint8, device=dev) for h, d in dims]
+        self.wb = [torch.empty((self.L.gcnpt_packed_bytes(d, h, self.compute),), dtype=torch.uint8, device=dev) for h, d in dims]
+        # two flat gradient buckets [dW0, db0, dW1, db1] so that the all-reduce of step i overlaps step i+1
+        self.n_grad = H * Din + H + H * H + H
+        self.buckets = [torch.zeros((self.n_grad,), dtype=torch.float32, device=dev) for _ in range(2)]
+        self.trees = tree.prune_to_csr(self.head, self.subj, self.obj, self.deprel, args.prune_k, masks=self.masks, want_label=False)
+        self.trees.check(expect_maxlen=T)
+        self.nnz = int(self.trees.nnz().sum())
+        self.scale = 1.0 / (1.0 - args.drop) if args.drop > 0 else 1.0
+
+    def grads(self, k):
+        H, Din = self.H, self.Din
+        f = self.buckets[k]
+        o = [0, H * Din, H * Din + H, H * Din + H + H * H]
+        return f[o[0]:o[1]], f[o[1]:o[2]], f[o[2]:o[3]], f[o[3]:]
+
+    # ---- individual C-ABI calls (each only enqueues on the current stream) ----
+    def prune(self):
+        tr, P, st = self.trees, self._lib.ptr, self._lib.stream()
+        self._lib.check(self.L.gcnpt_prune_to_csr(st, P(self.head), P(self.subj), P(self.obj), P(self.deprel), P(self.masks), None,
+                                                  self.B, self.T, self.args.prune_k, tr.cap, P(tr.row_ptr), P(tr.col_idx), None,
+                                                  P(tr.rowT_ptr), P(tr.colT_idx), P(tr.pool_mask), P(tr.status)))
+
+    def pack(self, l):
+        P = self._lib.ptr
+        H, Din = self.W[l].shape
+        self._lib.check(self.L.gcnpt_pack_weights(self._lib.stream(), P(self.W[l]), H, Din, self.compute, P(self.wf[l]), P(self.wb[l])))
+
+    def fwd(self, l):
+        P, tr = self._lib.ptr, self.trees
+        src, dst = (self.x, self.h1) if l == 0 else (self.h1, self.h2)
+        H, Din = self.W[l].shape
+        p = self.args.drop if l == 0 else 0.0
+        self._lib.check(self.L.gcnpt_layer_fwd(self._lib.stream(), P(src), self.act, P(self.wf[l]), P(self.b[l]), P(tr.row_ptr), P(tr.col_idx),
+                                               None, self.B, self.T, Din, H, P(dst), self.act, self.compute, p, 0x5eed))
+
+    def bwd_data(self, l):
+        P, tr = self._lib.ptr, self.trees
+        dy, y, dst = (self.gy, self.h2, self.dh1) if l == 1 else (self.dh1, self.h1, self.dx)
+        H, Din = self.W[l].shape
+        sc = self.scale if l == 0 else 1.0
+        self._lib.check(self.L.gcnpt_layer_bwd_data(self._lib.stream(), P(dy), P(y), self.act, P(self.wb[l]), P(tr.row_ptr), P(tr.rowT_ptr),
+                                                    P(tr.colT_idx), self.B, self.T, Din, H, P(dst), self.act, self.compute, sc))
+
+    def bwd_weight(self, l, k=0):
+        P, tr = self._lib.ptr, self.trees
+        dy, y, h = (self.gy, self.h2, self.h1) if l == 1 else (self.dh1, self.h1, self.x)
+        H, Din = self.W[l].shape
+        g = self.grads(k)
+        dW, db = (g[0], g[1]) if l == 0 else (g[2], g[3])
+        sc = self.scale if l == 0 else 1.0
+        self._lib.check(self.L.gcnpt_layer_bwd_weight(self._lib.stream(), P(dy), P(y), self.act, P(h), self.act, P(tr.row_ptr), P(tr.col_idx),
+                                                      None, self.B, self.T, Din, H, P(dW), P(db), self.compute, sc, 1))
+
+    def step(self, k=0, with_prune=False):
+        if with_prune:
+            self.prune()
+        self.pack(0); self.pack(1)
+        self.fwd(0); self.fwd(1)
+        self.bwd_weight(1, k); self.bwd_data(1)
+        self.bwd_weight(0, k); self.bwd_data(0)
+
+    # ---- algorithmic bytes per launch (DESIGN.md "Measurement") ----
+    def algorithmic_bytes(self):
+        e = 2 if self.args.dtype == "bf16" else 4
+        N, B, T = self.B * self.T, self.B, self.T
+        csr = 4 * B * (T + 1) + 4 * self.nnz
+        out = {}
+        for l, (H, Din) in enumerate([tuple(w.shape) for w in self.W]):
+            wp = self.wf[l].numel()
+            out["fwd%d" % l] = e * N * (Din + H) + wp + 4 * H + csr
+            out["bwd_data%d" % l] = e * N * (2 * H + Din) + self.wb[l].numel() + 2 * csr
+            out["bwd_weight%d" % l] = e * N * (2 * H + Din) + 4 * (H * Din + H) + csr
+            out["pack%d" % l] = 4 * H * Din + self.wf[l].numel() + self.wb[l].numel()
+        out["prune"] = 4 * 8 * N + N + 2 * csr + N + 4 * (B + 1)
+        return out
+
+
+def capture(fn, use_graph):
+    """Returns a callable that replays `fn` (a hipGraph when possible)."""
+    if not use_graph:
+        return fn, False
+    try:
+        fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        torch.cuda.synchronize()
+        return g.replay, True
+    except Exception as exc:  # pragma: no cover - depends on the runtime
+        print("[bench] hipGraph capture failed (%s); launching eagerly" % exc, file=sys.stderr)
+        torch.cuda.synchronize()
+        return fn, False
+
+
+def timed(run, steps, warmup, barrier):
+    """Contract: W untimed steps, then exactly K steps bracketed by barrier + synchronize; also HIP events on the stream."""
+    for i in range(warmup):
+        run(i)
+    barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for i in range(steps):
+        run(i)
+    e1.record()
+    torch.cuda.synchronize()
+    barrier()
+    wall = time.perf_counter() - t0
+    return wall, e0.elapsed_time(e1) * 1e-3
+
+
+def kernel_breakdown(stack, use_graph, reps=50, rounds=20):
+    """Average duration of each kernel of the step: `reps` back-to-back launches replayed as one hipGraph, HIP events around it."""
+    calls = [("pack0", lambda: stack.pack(0)), ("pack1", lambda: stack.pack(1)), ("fwd0", lambda: stack.fwd(0)),
+             ("fwd1", lambda: stack.fwd(1)), ("bwd_weight1", lambda: stack.bwd_weight(1)), ("bwd_data1", lambda: stack.bwd_data(1)),
+             ("bwd_weight0", lambda: stack.bwd_weight(0)), ("bwd_data0", lambda: stack.bwd_data(0)), ("prune", stack.prune)]
+    stack.step()
+    torch.cuda.synchronize()
+    out = {}
+    for name, call in calls:
+        def many(call=call):
+            for _ in range(reps):
+                call()
+        run, _ = capture(many, use_graph)
+        run(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(rounds):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        out[name] = e0.elapsed_time(e1) * 1e-3 / (reps * rounds)
+    stack.step()          # leave consistent buffers behind
+    torch.cuda.synchronize()
+    return out
+
+
+def cpu_baseline(args, seconds):
+    """The CPU oracle (numpy port of the reference's dense-bmm layer loop, fp32) on this box's host cores, same workload."""
+    from gcn_over_pruned_trees_amd.utils import synthetic
+    from oracle import gcn_ref, prune_ref
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    B, T, Din, H = args.batch, args.seq, args.din, args.hidden
+    tb = synthetic.random_tree_batch(1234, B, T, args.lengths)
+    Ws, bs = synthetic.layer_params(1235, [Din, H, H])
+    x, gy = synthetic.normal(1236, (B, T, Din)), synthetic.normal(1237, (B, T, H))
+    t0 = time.perf_counter()
+    adj = prune_ref.batch_adj(tb["head"], tb["subj_pos"], tb["obj_pos"], tb["deprel"], tb["lens"], args.prune_k)["adj"]
+    t_prune = time.perf_counter() - t0
+    gcn_ref.gcn_backward(adj, x, Ws, bs, gy)          # warm-up (its forward is inside)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        gcn_ref.gcn_backward(adj, x, Ws, bs, gy)      # forward + backward of the 2-layer stack
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds and n >= 3:
+            break
+    return dict(value=B * n / el, unit="sentences/s", cores=int(cores), kind="port",
+                sample="%d fwd+bwd steps of the same %dx%d workload in %.1f s (numpy/BLAS fp32 port of the reference's dense-bmm layer loop, "
+                       "oracle/gcn_ref.py; tree build excluded, it took %.1f ms per batch in the C oracle on 1 core)" % (n, B, T, el, t_prune * 1e3))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        barrier = lambda: dist.barrier(device_ids=[local])  # noqa: E731
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+        barrier = lambda: None  # noqa: E731
+    if args.gpus != world and rank == 0 and world > 1:
+        print("[bench] --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    dev = torch.device("cuda", local if world > 1 else 0)
+    use_graph = not args.no_graph
+
+    stack = Stack(args, dev, seed=1234 + 17 * rank)
+    from gcn_over_pruned_trees_amd.shard import OverlappedAllReduce
+
+    # ---- the timed step: layer stack fwd+bwd (+ overlapped gradient all-reduce when N > 1)
+    replays = [capture(lambda k=k: stack.step(k), use_graph) for k in range(2 if world > 1 else 1)]
+    graphed = replays[0][1]
+    reducer = OverlappedAllReduce(stack.buckets, dist, average=True) if world > 1 else None
+
+    def run(i):
+        k = i & 1 if world > 1 else 0
+        if reducer:
+            reducer.before_write(k)
+        replays[k][0]()
+        if reducer:
+            reducer.after_write(k)
+
+    wall, ev = timed(run, args.steps, args.warmup, barrier)
+    if reducer:
+        reducer.finish()
+        torch.cuda.synchronize()
+    if world > 1:
+        tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        wall = float(tmax.item())
+    assert torch.isfinite(stack.buckets[0]).all() and torch.isfinite(stack.dx.float()).all()
+
+    result = None
+    if rank == 0:
+        sent = args.batch * world * args.steps
+        # second measurement on rank 0 only: tree build inside the step
+        run_p, _ = capture(lambda: stack.step(0, with_prune=True), use_graph)
+        wall_p, _ = timed(lambda i: run_p(), args.steps, min(args.warmup, 50), lambda: None)
+        result = {
+            "metric": "GCN-layer fwd+bwd sentences/sec at batch=50 seq=100 h=200",
+            "value": sent / wall, "unit": "sentences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": "2-layer GCN stack fwd+bwd (no LSTM), batch=%d seq_len=%d Din=%d hidden=%d prune_k=%d, %s storage / fp32 accumulate, "
+                                   "synthetic TACRED-shaped random trees (lengths=%s), dropout %.1f between layers"
+                                   % (args.batch, args.seq, args.din, args.hidden, args.prune_k, args.dtype, args.lengths, args.drop),
+                       "global_batch": args.batch * world, "per_gpu_batch": args.batch, "parallelism": "dp%d" % world,
+                       "launch": "hipGraph replay" if graphed else "eager", "nnz_per_batch": stack.nnz,
+                       "grad_allreduce": "flat fp32 bucket %d B per step over RCCL, overlapped with the next step" % (4 * stack.n_grad) if world > 1 else "none (1 GPU)"},
+            "event_ms_per_step": ev / args.steps * 1e3,
+            "with_prune": {"value": args.batch * args.steps / wall_p, "unit": "sentences/s", "ms_per_step": wall_p / args.steps * 1e3,
+                           "note": "rank 0, pruned-tree adjacency build (gcnpt_prune_to_csr) inside every step"},
+        }
+        alg = stack.algorithmic_bytes()
+        if not args.no_kernel_breakdown:
+            kt = kernel_breakdown(stack, use_graph)
+            step_keys = [k for k in kt if k != "prune"]
+            dom = max(step_keys, key=lambda k: kt[k])
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # per-launch HBM bytes from rocprofv3 --pmc passes, if recorded
+            if os.path.exists(tf):
+                with open(tf) as f:
+                    traffic = json.load(f).get(dom)
+            gbs = alg[dom] / kt[dom] / 1e9
+            result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                  "traffic": traffic, "algorithmic_bytes": alg[dom], "avg_launch_us": kt[dom] * 1e6,
+                                  "note": "avg duration from HIP events around 50 back-to-back launches replayed as one hipGraph (includes dispatch gaps)"}
+            result["kernels"] = {k: {"avg_us": kt[k] * 1e6, "algorithmic_bytes": alg[k], "GBps": alg[k] / kt[k] / 1e9} for k in kt}
+            tot_b = sum(alg[k] for k in step_keys)
+            result["step_roofline"] = {"algorithmic_bytes": tot_b, "sum_kernel_us": sum(kt[k] for k in step_keys) * 1e6,
+                                       "frac_of_hbm_peak": tot_b / sum(kt[k] for k in step_keys) / 1e9 / HBM_PEAK_GBS}
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier(device_ids=[local])
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()

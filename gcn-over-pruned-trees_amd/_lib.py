@@ -1,0 +1,90 @@
+"""
+ctypes binding of libgcnpt.so (include/gcnpt.h).  There is no CPU fallback: if the HIP library has
+not been built this module raises, and every op that needs it fails loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgcnpt.so")
+
+F32, BF16 = 0, 1
+OK, E_INVALID, E_PRUNE_NEGATIVE, E_NO_SUBJECT, E_NO_LCA, E_CYCLE, E_BAD_HEAD, E_ASSERT, E_CAPACITY, E_HIP, E_UNSUPPORTED = \
+    0, -1, -2, -3, -4, -5, -6, -7, -8, -9, -10
+
+# every symbol include/gcnpt.h declares: (restype, argtypes)
+_p, _i, _f, _u64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_uint64, ctypes.c_size_t
+SIGNATURES = {
+    "gcnpt_abi_version": (_i, []),
+    "gcnpt_last_error": (ctypes.c_char_p, []),
+    "gcnpt_prune_to_csr": (_i, [_p] * 7 + [_i] * 4 + [_p] * 7),
+    "gcnpt_adj_to_csr": (_i, [_p, _p, _i, _i, _i] + [_p] * 7),
+    "gcnpt_csr_to_adj": (_i, [_p, _p, _p, _p, _i, _i, _p]),
+    "gcnpt_packed_bytes": (_sz, [_i, _i, _i]),
+    "gcnpt_pack_weights": (_i, [_p, _p, _i, _i, _i, _p, _p]),
+    "gcnpt_layer_fwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _f, _u64]),
+    "gcnpt_layer_bwd_data": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _f]),
+    "gcnpt_layer_bwd_weight": (_i, [_p, _p, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p, _i, _f, _i]),
+}
+
+
+class GcnptError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("libgcnpt error %d: %s" % (code, message))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library.  Raises ImportError (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s is missing: build it with `make -C %s` (or python -c 'import __graft_entry__ as g; g.build()'). "
+                "This package has no CPU fallback." % (LIB_PATH, os.path.dirname(LIB_PATH)))
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError here = header and library disagree
+            fn.restype, fn.argtypes = res, args
+        if handle.gcnpt_abi_version() != 1:
+            raise ImportError("libgcnpt.so has ABI version %d, this binding needs 1" % handle.gcnpt_abi_version())
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise GcnptError(rc, lib().gcnpt_last_error().decode("utf-8", "replace"))
+
+
+def dtype_code(torch_dtype):
+    import torch
+    if torch_dtype == torch.float32:
+        return F32
+    if torch_dtype == torch.bfloat16:
+        return BF16
+    raise TypeError("gcnpt supports float32 and bfloat16 tensors, got %s" % torch_dtype)
+
+
+def require_gpu(t):
+    if not t.is_cuda:
+        raise RuntimeError("gcnpt ops run on the GPU only (tensor is on %s); there is no CPU path" % t.device)
+    return t
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  The tensor must be contiguous and live on a GPU."""
+    if t is None:
+        return None
+    require_gpu(t)
+    if not t.is_contiguous():
+        raise RuntimeError("gcnpt ops need contiguous tensors")
+    return t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

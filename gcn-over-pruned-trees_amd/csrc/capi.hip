@@ -1,0 +1,25 @@
+// Error state and version of the C-ABI (include/gcnpt.h).  The entry points themselves live next to
+// their kernels in tree_kernels.hip and layer_kernels.hip.
+#include <stdarg.h>
+
+#include "gcnpt_common.h"
+
+namespace gcnpt {
+
+char* err_buf() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+}  // namespace gcnpt
+
+extern "C" int gcnpt_abi_version(void) { return GCNPT_ABI_VERSION; }
+extern "C" const char* gcnpt_last_error(void) { return gcnpt::err_buf(); }

@@ -1,0 +1,49 @@
+// Shared host/device helpers for libgcnpt.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/gcnpt.h"
+
+namespace gcnpt {
+
+// ---- error reporting across the C boundary (no exceptions leave the library) -------------------
+char* err_buf();   // thread-local, defined in capi.hip
+int fail(int code, const char* fmt, ...);
+
+#define GCNPT_HIP_CHECK(expr)                                                                  \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return gcnpt::fail(GCNPT_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));    \
+    } while (0)
+
+#define GCNPT_REQUIRE(cond, ...)                                      \
+    do {                                                              \
+        if (!(cond)) return gcnpt::fail(GCNPT_E_INVALID, __VA_ARGS__); \
+    } while (0)
+
+constexpr int WAVE = 64;
+constexpr int FWD_BOUND = 42;      // utils/constant.py:14  DEPREL_FORWARD_BOUND
+constexpr int SELF_LOOP_ID = 84;   // utils/constant.py:12,29  DEPREL_TO_ID['self_loop']
+
+__host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+__host__ __device__ inline int ceil_div(int x, int m) { return (x + m - 1) / m; }
+
+// ---- bf16 <-> f32 (storage type is a raw 16-bit pattern) -------------------------------------------
+typedef unsigned short bf16_t;
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+
+// round-to-nearest-even; a plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps NaNs NaN
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+}  // namespace gcnpt

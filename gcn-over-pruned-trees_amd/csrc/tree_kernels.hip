@@ -1,0 +1,340 @@
+// Pruned-dependency-tree adjacency on the device (gfx950).
+//
+// Replaces the host round trip of reference model/gcn.py:96-110 (6 device->host copies, a Python loop
+// over model/tree.py:58 head_to_tree and model/tree.py:167 tree_to_adj, one host->device copy of a
+// dense [B,T,T] float tensor) with one launch: a workgroup per sentence stages the head array in LDS,
+// prunes the tree there and writes the CSR pattern (3n-2 entries for an n-node tree) the layer kernels
+// consume.  Integer work only; results are exact.
+//
+// The pruning uses the closed form of SURVEY.md 3c (fuzz-verified against the reference):
+//   chain(t) = t and its ancestors;  CA = intersection of chain(t) over entity tokens;
+//   lca = the member of CA with no child in CA;  P = (union of chains - CA) + {lca};
+//   dist[i] = edges from i up to its first ancestor-or-self in P (infinite if none);  keep = dist <= K;
+//   edges = {(head[i]-1 -> i) : keep[i], i != lca, head[i] > 0}.
+#include "gcnpt_common.h"
+
+namespace gcnpt {
+
+constexpr int PRUNE_THREADS = 128;
+constexpr int ADJ_THREADS = 256;
+
+enum : int {
+    F_SUBJ = 1, F_OBJ = 2, F_FWD_NZ = 4, F_REV_NZ = 8, F_CA = 16, F_CA_HASCHILD = 32, F_PATH = 64, F_HASEDGE = 128
+};
+enum : int { K_KEEP = 1, K_CHILD = 2 };
+enum : int { ERR_CHAIN_BADHEAD = 1, ERR_CHAIN_CYCLE = 2, ERR_BADHEAD = 4, ERR_CYCLE = 8, ERR_ASSERT = 16 };
+
+// exclusive scan of a[0..n) in place, a[n] = total; `scratch` holds blockDim.x ints
+__device__ void block_exclusive_scan(int* a, int n, int* scratch) {
+    const int t = threadIdx.x, nt = blockDim.x;
+    const int seg = (n + nt - 1) / nt;
+    const int lo = min(n, t * seg), hi = min(n, lo + seg);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += a[i];
+    scratch[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        int run = 0;
+        for (int k = 0; k < nt; ++k) { int v = scratch[k]; scratch[k] = run; run += v; }
+        a[n] = run;
+    }
+    __syncthreads();
+    int run = scratch[t];
+    for (int i = lo; i < hi; ++i) { int v = a[i]; a[i] = run; run += v; }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(PRUNE_THREADS) void prune_to_csr_kernel(
+    const int64_t* __restrict__ head, const int64_t* __restrict__ subj_pos, const int64_t* __restrict__ obj_pos,
+    const int64_t* __restrict__ deprel, const uint8_t* __restrict__ pad_mask, const int32_t* __restrict__ len_in,
+    int B, int T, int prune_k, int cap, int32_t* __restrict__ row_ptr, int32_t* __restrict__ col_idx,
+    int32_t* __restrict__ label, int32_t* __restrict__ rowT_ptr, int32_t* __restrict__ colT_idx,
+    uint8_t* __restrict__ pool_mask, int32_t* __restrict__ status) {
+    extern __shared__ int smem[];
+    int* par = smem;               // [T]   parent token (-1 root / none, -2 head points past the sentence)
+    int* cnt = par + T;            // [T]   #entity chains through the token; later K_KEEP/K_CHILD bits
+    int* flg = cnt + T;            // [T]   F_* bits
+    int* deg = flg + T;            // [T+1] row degree -> row offsets
+    int* degT = deg + T + 1;       // [T+1] column degree -> transposed row offsets
+    int* scratch = degT + T + 1;   // [PRUNE_THREADS]
+    __shared__ int s_len, s_nent, s_nsubj, s_err, s_lca;
+
+    const int b = blockIdx.x, t = threadIdx.x, NT = PRUNE_THREADS;
+    const size_t base = (size_t)b * T;
+    if (t == 0) { s_len = 0; s_nent = 0; s_nsubj = 0; s_err = 0; s_lca = 0x7fffffff; }
+    __syncthreads();
+
+    // ---- sentence length = number of non-pad slots (gcn.py:96)
+    if (pad_mask) {
+        int c = 0;
+        for (int i = t; i < T; i += NT) c += pad_mask[base + i] == 0;
+        if (c) atomicAdd(&s_len, c);
+    } else if (t == 0) {
+        s_len = min(max(len_in[b], 0), T);
+    }
+    __syncthreads();
+    const int len = s_len;
+    if (t == 0) atomicMax(&status[B], len);
+
+    // ---- stage the parse in LDS (tree.py:60-63, 82-83)
+    for (int i = t; i < T; i += NT) {
+        int f = 0, p = -1;
+        if (i < len) {
+            const int64_t h = head[base + i];
+            if (h > 0) p = (h - 1 < len) ? (int)(h - 1) : -2;
+            if (subj_pos[base + i] == 0) { f |= F_SUBJ; atomicAdd(&s_nsubj, 1); atomicAdd(&s_nent, 1); }
+            if (obj_pos[base + i] == 0) { f |= F_OBJ; atomicAdd(&s_nent, 1); }
+            const int64_t d = deprel[base + i];
+            if (d != 0) f |= F_FWD_NZ;                 // adj[p,c] = deprel[c]        survives `adj != 0`
+            if (d + FWD_BOUND != 0) f |= F_REV_NZ;     // adj[c,p] = deprel[c] + 42
+        }
+        par[i] = p; cnt[i] = 0; flg[i] = f; deg[i] = 0; degT[i] = 0;
+    }
+    __syncthreads();
+    const int nent = s_nent;
+
+    // ---- every entity token walks to the root, counting visits (tree.py:86-109)
+    for (int i = t; i < len; i += NT) {
+        const int f = flg[i];
+        const int w = ((f & F_SUBJ) ? 1 : 0) + ((f & F_OBJ) ? 1 : 0);
+        if (!w) continue;
+        int a = i, steps = 0;
+        while (a >= 0) {
+            atomicAdd(&cnt[a], w);
+            a = par[a];
+            if (++steps > len) { atomicOr(&s_err, ERR_CHAIN_CYCLE); a = -1; }
+        }
+        if (a == -2) atomicOr(&s_err, ERR_CHAIN_BADHEAD);
+    }
+    __syncthreads();
+    int err = 0;
+    if (s_err & ERR_CHAIN_BADHEAD) err = GCNPT_E_BAD_HEAD;
+    else if (s_err & ERR_CHAIN_CYCLE) err = GCNPT_E_CYCLE;
+    else if (s_nsubj == 0) err = GCNPT_E_NO_SUBJECT;
+
+    // ---- common ancestors and the lowest of them (tree.py:112-124)
+    if (!err) {
+        for (int i = t; i < len; i += NT)
+            if (cnt[i] == nent) flg[i] |= F_CA;
+        __syncthreads();
+        for (int i = t; i < len; i += NT) {
+            const int p = par[i];
+            if ((flg[i] & F_CA) && p >= 0 && (flg[p] & F_CA)) atomicOr(&flg[p], F_CA_HASCHILD);
+        }
+        __syncthreads();
+        for (int i = t; i < len; i += NT)
+            if ((flg[i] & (F_CA | F_CA_HASCHILD)) == F_CA) atomicMin(&s_lca, i);
+        __syncthreads();
+        if (s_lca == 0x7fffffff) err = GCNPT_E_NO_LCA;
+    }
+    const int lca = s_lca;
+
+    // ---- path nodes, distance to the path, kept tokens (tree.py:126-147)
+    if (!err) {
+        for (int i = t; i < len; i += NT)
+            if ((cnt[i] > 0 && !(flg[i] & F_CA)) || i == lca) flg[i] |= F_PATH;
+        __syncthreads();
+        for (int i = t; i < len; i += NT) {
+            int a = i, d = 0;
+            while (a >= 0 && !(flg[a] & F_PATH)) {
+                a = par[a];
+                if (++d > len) { atomicOr(&s_err, ERR_CYCLE); a = -1; }
+            }
+            if (a == -2) atomicOr(&s_err, ERR_BADHEAD);
+            const bool keep = a >= 0 && d <= prune_k;
+            const bool child = keep && i != lca && par[i] >= 0;
+            cnt[i] = (keep ? K_KEEP : 0) | (child ? K_CHILD : 0);   // cnt is free from here on
+        }
+        __syncthreads();
+        if (s_err & ERR_BADHEAD) err = GCNPT_E_BAD_HEAD;
+        else if (s_err & ERR_CYCLE) err = GCNPT_E_CYCLE;
+    }
+
+    // ---- degrees of the labelled adjacency tree_to_adj would write (tree.py:182-192)
+    if (!err) {
+        for (int i = t; i < len; i += NT) {
+            if (!(cnt[i] & K_CHILD)) continue;
+            const int p = par[i], f = flg[i];
+            if (!(cnt[p] & K_KEEP)) atomicOr(&s_err, ERR_ASSERT);   // tree.py:159
+            if (f & F_FWD_NZ) { atomicAdd(&deg[p], 1); atomicAdd(&degT[i], 1); }
+            if (f & F_REV_NZ) { atomicAdd(&deg[i], 1); atomicAdd(&degT[p], 1); }
+            atomicOr(&flg[p], F_HASEDGE);
+            atomicOr(&flg[i], F_HASEDGE);
+        }
+        __syncthreads();
+        if (s_err & ERR_ASSERT) err = GCNPT_E_ASSERT;
+    }
+    if (!err) {
+        for (int i = t; i < T; i += NT) {
+            if (i < len && (flg[i] & F_HASEDGE)) { deg[i] += 1; degT[i] += 1; }   // the 84 on the diagonal
+        }
+        __syncthreads();
+        if (pool_mask)
+            for (int i = t; i < T; i += NT) pool_mask[base + i] = (deg[i] + degT[i]) == 0;   // gcn.py:262
+        __syncthreads();
+        block_exclusive_scan(deg, T, scratch);
+        block_exclusive_scan(degT, T, scratch);
+        if (deg[T] > cap || degT[T] > cap) err = GCNPT_E_CAPACITY;
+    }
+
+    if (err) {   // the sentence contributes no edges; every row is empty and masked
+        for (int i = t; i <= T; i += NT) {
+            row_ptr[(size_t)b * (T + 1) + i] = b * cap;
+            if (rowT_ptr) rowT_ptr[(size_t)b * (T + 1) + i] = b * cap;
+        }
+        if (pool_mask)
+            for (int i = t; i < T; i += NT) pool_mask[base + i] = 1;
+        if (t == 0) status[b] = err;
+        return;
+    }
+
+    // ---- emit both patterns, columns ascending (same order a dense -> CSR conversion gives)
+    for (int i = t; i <= T; i += NT) {
+        row_ptr[(size_t)b * (T + 1) + i] = b * cap + deg[i];
+        if (rowT_ptr) rowT_ptr[(size_t)b * (T + 1) + i] = b * cap + degT[i];
+    }
+    for (int r = t; r < len; r += NT) {
+        const int rf = flg[r];
+        if (!(rf & F_HASEDGE)) continue;
+        const bool rchild = cnt[r] & K_CHILD;
+        const int rp = par[r];
+        int o = b * cap + deg[r], oT = b * cap + degT[r];
+        for (int j = 0; j < len; ++j) {
+            const bool child = (cnt[j] & K_CHILD) && par[j] == r;
+            const int fj = flg[j];
+            if (child) {
+                if (fj & F_FWD_NZ) { col_idx[o] = j; if (label) label[o] = (int)deprel[base + j]; ++o; }
+                if ((fj & F_REV_NZ) && colT_idx) colT_idx[oT++] = j;
+            } else if (j == r) {
+                col_idx[o] = r; if (label) label[o] = SELF_LOOP_ID; ++o;
+                if (colT_idx) colT_idx[oT++] = r;
+            } else if (rchild && j == rp) {
+                if (rf & F_REV_NZ) { col_idx[o] = j; if (label) label[o] = (int)deprel[base + r] + FWD_BOUND; ++o; }
+                if ((rf & F_FWD_NZ) && colT_idx) colT_idx[oT++] = j;
+            }
+        }
+    }
+    if (t == 0) status[b] = 0;
+}
+
+// ---- dense float adjacency -> CSR of (adj != 0) and of its transpose (gcn.py:260-262) -----------------
+__global__ __launch_bounds__(ADJ_THREADS) void adj_to_csr_kernel(
+    const float* __restrict__ adj, int B, int T, int cap, int32_t* __restrict__ row_ptr, int32_t* __restrict__ col_idx,
+    int32_t* __restrict__ label, int32_t* __restrict__ rowT_ptr, int32_t* __restrict__ colT_idx,
+    uint8_t* __restrict__ pool_mask, int32_t* __restrict__ status) {
+    extern __shared__ int smem[];
+    int* deg = smem;              // [T+1]
+    int* degT = deg + T + 1;      // [T+1]
+    int* scratch = degT + T + 1;  // [ADJ_THREADS]
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6, NW = ADJ_THREADS / WAVE;
+    const float* A = adj + (size_t)b * T * T;
+
+    for (int r = wave; r < T; r += NW) {
+        int n = 0, nT = 0;
+        for (int c0 = 0; c0 < T; c0 += WAVE) {
+            const int c = c0 + lane;
+            const bool nz = c < T && A[(size_t)r * T + c] != 0.0f;
+            const bool nzT = c < T && A[(size_t)c * T + r] != 0.0f;
+            n += __popcll(__ballot(nz));
+            nT += __popcll(__ballot(nzT));
+        }
+        if (lane == 0) { deg[r] = n; degT[r] = nT; }
+    }
+    __syncthreads();
+    if (pool_mask)
+        for (int i = t; i < T; i += ADJ_THREADS) pool_mask[(size_t)b * T + i] = (deg[i] + degT[i]) == 0;
+    __syncthreads();
+    block_exclusive_scan(deg, T, scratch);
+    block_exclusive_scan(degT, T, scratch);
+    const bool over = deg[T] > cap;
+    for (int i = t; i <= T; i += ADJ_THREADS) {
+        row_ptr[(size_t)b * (T + 1) + i] = b * cap + (over ? 0 : deg[i]);
+        if (rowT_ptr) rowT_ptr[(size_t)b * (T + 1) + i] = b * cap + (over ? 0 : degT[i]);
+    }
+    if (t == 0) {
+        status[b] = over ? GCNPT_E_CAPACITY : 0;
+        atomicMax(&status[B], T);
+    }
+    if (over) return;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int r = wave; r < T; r += NW) {
+        int o = b * cap + deg[r], oT = b * cap + degT[r];
+        for (int c0 = 0; c0 < T; c0 += WAVE) {
+            const int c = c0 + lane;
+            const float v = c < T ? A[(size_t)r * T + c] : 0.0f;
+            const float vT = c < T ? A[(size_t)c * T + r] : 0.0f;
+            const bool nz = c < T && v != 0.0f, nzT = c < T && vT != 0.0f;
+            const unsigned long long m = __ballot(nz), mT = __ballot(nzT);
+            if (nz) { const int k = o + __popcll(m & lt); col_idx[k] = c; if (label) label[k] = (int)v; }
+            if (nzT && colT_idx) colT_idx[oT + __popcll(mT & lt)] = c;
+            o += __popcll(m);
+            oT += __popcll(mT);
+        }
+    }
+}
+
+__global__ void csr_to_adj_kernel(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
+                                  const int32_t* __restrict__ label, int B, int T, float* __restrict__ adj) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= B * T) return;
+    const int b = r / T, i = r - b * T;
+    const int beg = row_ptr[(size_t)b * (T + 1) + i], end = row_ptr[(size_t)b * (T + 1) + i + 1];
+    for (int e = beg; e < end; ++e)
+        adj[((size_t)b * T + i) * T + col_idx[e]] = label ? (float)label[e] : 1.0f;
+}
+
+}  // namespace gcnpt
+
+using namespace gcnpt;
+
+extern "C" int gcnpt_prune_to_csr(void* stream, const int64_t* head, const int64_t* subj_pos, const int64_t* obj_pos,
+                                  const int64_t* deprel, const uint8_t* pad_mask, const int32_t* len, int B, int T,
+                                  int prune_k, int cap, int32_t* row_ptr, int32_t* col_idx, int32_t* label,
+                                  int32_t* rowT_ptr, int32_t* colT_idx, uint8_t* pool_mask, int32_t* status) {
+    GCNPT_REQUIRE(head && subj_pos && obj_pos && deprel && (pad_mask || len), "prune_to_csr: null input pointer");
+    GCNPT_REQUIRE(row_ptr && col_idx && status, "prune_to_csr: null output pointer");
+    GCNPT_REQUIRE(B > 0 && T > 0 && cap > 0, "prune_to_csr: B, T, cap must be positive (B=%d T=%d cap=%d)", B, T, cap);
+    GCNPT_REQUIRE((rowT_ptr == nullptr) == (colT_idx == nullptr), "prune_to_csr: rowT_ptr and colT_idx go together");
+    if (prune_k < 0)
+        return fail(GCNPT_E_PRUNE_NEGATIVE, "prune_k=%d: the reference fork only works with prune_k >= 0 "
+                    "(model/tree.py:194 reads Tree.head, which the unpruned branch never sets)", prune_k);
+    if ((long long)B * cap > 0x7fffffffLL) return fail(GCNPT_E_UNSUPPORTED, "prune_to_csr: B*cap overflows int32");
+    const size_t lds = sizeof(int) * ((size_t)5 * T + 2 + PRUNE_THREADS);
+    if (lds > 150 * 1024) return fail(GCNPT_E_UNSUPPORTED, "prune_to_csr: T=%d needs %zu B of LDS", T, lds);
+    hipStream_t s = (hipStream_t)stream;
+    GCNPT_HIP_CHECK(hipMemsetAsync(status + B, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(prune_to_csr_kernel, dim3(B), dim3(PRUNE_THREADS), lds, s, head, subj_pos, obj_pos, deprel,
+                       pad_mask, len, B, T, prune_k, cap, row_ptr, col_idx, label, rowT_ptr, colT_idx, pool_mask, status);
+    GCNPT_HIP_CHECK(hipGetLastError());
+    return GCNPT_OK;
+}
+
+extern "C" int gcnpt_adj_to_csr(void* stream, const float* adj, int B, int T, int cap, int32_t* row_ptr,
+                                int32_t* col_idx, int32_t* label, int32_t* rowT_ptr, int32_t* colT_idx,
+                                uint8_t* pool_mask, int32_t* status) {
+    GCNPT_REQUIRE(adj && row_ptr && col_idx && status, "adj_to_csr: null pointer");
+    GCNPT_REQUIRE(B > 0 && T > 0 && cap > 0, "adj_to_csr: B, T, cap must be positive");
+    GCNPT_REQUIRE((rowT_ptr == nullptr) == (colT_idx == nullptr), "adj_to_csr: rowT_ptr and colT_idx go together");
+    if ((long long)B * cap > 0x7fffffffLL) return fail(GCNPT_E_UNSUPPORTED, "adj_to_csr: B*cap overflows int32");
+    const size_t lds = sizeof(int) * ((size_t)2 * T + 2 + ADJ_THREADS);
+    if (lds > 150 * 1024) return fail(GCNPT_E_UNSUPPORTED, "adj_to_csr: T=%d needs %zu B of LDS", T, lds);
+    hipStream_t s = (hipStream_t)stream;
+    GCNPT_HIP_CHECK(hipMemsetAsync(status + B, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(adj_to_csr_kernel, dim3(B), dim3(ADJ_THREADS), lds, s, adj, B, T, cap, row_ptr, col_idx, label,
+                       rowT_ptr, colT_idx, pool_mask, status);
+    GCNPT_HIP_CHECK(hipGetLastError());
+    return GCNPT_OK;
+}
+
+extern "C" int gcnpt_csr_to_adj(void* stream, const int32_t* row_ptr, const int32_t* col_idx, const int32_t* label,
+                                int B, int T, float* adj) {
+    GCNPT_REQUIRE(row_ptr && col_idx && adj, "csr_to_adj: null pointer");
+    GCNPT_REQUIRE(B > 0 && T > 0, "csr_to_adj: B and T must be positive");
+    hipStream_t s = (hipStream_t)stream;
+    GCNPT_HIP_CHECK(hipMemsetAsync(adj, 0, sizeof(float) * (size_t)B * T * T, s));
+    const int rows = B * T;
+    hipLaunchKernelGGL(csr_to_adj_kernel, dim3(ceil_div(rows, 256)), dim3(256), 0, s, row_ptr, col_idx, label, B, T, adj);
+    GCNPT_HIP_CHECK(hipGetLastError());
+    return GCNPT_OK;
+}

@@ -1,0 +1,288 @@
+"""
+Host-side mirror of the reference's model/gcn.py for the `regular` GCN path, running on MI355X kernels.
+
+Same class names, constructor arguments, `opt` keys, parameter / state_dict names and forward()
+signatures as the reference, so `from model.gcn import GCNClassifier` can be swapped for
+`from gcn_over_pruned_trees_amd.model.gcn import GCNClassifier` in its trainer (model/trainer.py:82):
+
+  GCNClassifier(opt, emb_matrix=None).forward(inputs) -> (logits [B,C], pooling_output [B,H])   gcn.py:15-36
+  GCNRelationModel(opt, emb_matrix=None).forward(inputs) -> (outputs [B,H], h_out [B,H])        gcn.py:38-126
+  GCN(opt, embeddings, mem_dim, num_layers).forward(adj, inputs) -> (h [B,T,H], mask [B,T,1])   gcn.py:128-395
+  pool(h, mask, type)                                                                            gcn.py:473-483
+
+What is different underneath: the tree pruning + adjacency build (gcn.py:96-110) is one device kernel
+(model/tree.py here) and every iteration of the layer loop (gcn.py:266-393) is one fused HIP kernel per
+direction, reached through the C-ABI of include/gcnpt.h.  Embeddings, the optional BiLSTM, pooling and
+the output MLP stay ordinary PyTorch-ROCm modules, as in the reference.
+
+New optional `opt` keys (defaults reproduce the reference): `gcn_dtype` = 'fp32' | 'bf16' (MFMA operand /
+activation storage type inside the layer stack), `gcn_check_trees` = True (synchronise once per forward to
+raise on malformed trees the way the reference does; False keeps the step free of host syncs).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from ..utils import constant
+from .tree import PrunedTrees, adj_to_csr, prune_to_csr
+
+
+# ------------------------------------------------------------------------------------------------------
+# one GCN layer as an autograd op over the C-ABI
+# ------------------------------------------------------------------------------------------------------
+class _GCNLayerFn(torch.autograd.Function):
+    """out = dropout(relu((((A+I) h) W^T + 2 b) / (deg + 1)))  -- model/gcn.py:269-271, 390-393."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias, trees, drop_p, seed, compute, out_dtype, no_adj):
+        B, T, Din = h.shape
+        H = weight.shape[0]
+        if weight.shape[1] != Din:
+            raise RuntimeError("GCN layer: input width %d does not match weight %s" % (Din, tuple(weight.shape)))
+        if (B, T) != (trees.B, trees.T):
+            raise RuntimeError("GCN layer: inputs are [%d,%d,*] but the adjacency is for [%d,%d]" % (B, T, trees.B, trees.T))
+        L = _lib.lib()
+        h = h.contiguous()
+        w32 = weight.detach().to(torch.float32).contiguous()
+        b32 = bias.detach().to(torch.float32).contiguous()
+        w_fwd = torch.empty((L.gcnpt_packed_bytes(H, Din, compute),), dtype=torch.uint8, device=h.device)
+        w_bwd = torch.empty((L.gcnpt_packed_bytes(Din, H, compute),), dtype=torch.uint8, device=h.device)
+        st = _lib.stream()
+        _lib.check(L.gcnpt_pack_weights(st, _lib.ptr(w32), H, Din, compute, _lib.ptr(w_fwd), _lib.ptr(w_bwd)))
+        out = torch.empty((B, T, H), dtype=out_dtype, device=h.device)
+        g_row_ptr = trees.empty_row_ptr() if no_adj else trees.row_ptr
+        _lib.check(L.gcnpt_layer_fwd(st, _lib.ptr(h), _lib.dtype_code(h.dtype), _lib.ptr(w_fwd), _lib.ptr(b32),
+                                     _lib.ptr(g_row_ptr), _lib.ptr(trees.col_idx), _lib.ptr(trees.row_ptr), B, T, Din, H,
+                                     _lib.ptr(out), _lib.dtype_code(out_dtype), compute, float(drop_p), int(seed)))
+        ctx.save_for_backward(h, out, w_bwd)
+        ctx.trees, ctx.no_adj, ctx.compute = trees, no_adj, compute
+        ctx.scale = 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0
+        ctx.dims = (B, T, Din, H)
+        ctx.param_dtypes = (weight.dtype, bias.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        h, out, w_bwd = ctx.saved_tensors
+        trees, B, T, Din, H = ctx.trees, *ctx.dims
+        L, st = _lib.lib(), _lib.stream()
+        gout = gout.to(out.dtype).contiguous()
+        gd = _lib.dtype_code(out.dtype)
+        dh = dW = db = None
+        g_rowT = trees.empty_row_ptr() if ctx.no_adj else trees.rowT_ptr
+        g_row = trees.empty_row_ptr() if ctx.no_adj else trees.row_ptr
+        if ctx.needs_input_grad[0]:
+            dh = torch.empty_like(h)
+            _lib.check(L.gcnpt_layer_bwd_data(st, _lib.ptr(gout), _lib.ptr(out), gd, _lib.ptr(w_bwd), _lib.ptr(trees.row_ptr),
+                                              _lib.ptr(g_rowT), _lib.ptr(trees.colT_idx), B, T, Din, H, _lib.ptr(dh),
+                                              _lib.dtype_code(dh.dtype), ctx.compute, ctx.scale))
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dW = torch.empty((H, Din), dtype=torch.float32, device=h.device)
+            db = torch.empty((H,), dtype=torch.float32, device=h.device)
+            _lib.check(L.gcnpt_layer_bwd_weight(st, _lib.ptr(gout), _lib.ptr(out), gd, _lib.ptr(h), _lib.dtype_code(h.dtype),
+                                                _lib.ptr(g_row), _lib.ptr(trees.col_idx), _lib.ptr(trees.row_ptr), B, T, Din, H,
+                                                _lib.ptr(dW), _lib.ptr(db), ctx.compute, ctx.scale, 1))
+            dW, db = dW.to(ctx.param_dtypes[0]), db.to(ctx.param_dtypes[1])
+        return dh, dW, db, None, None, None, None, None, None
+
+
+def gcn_layer(h, weight, bias, trees, drop_p=0.0, seed=0, compute_dtype=torch.float32, out_dtype=None, no_adj=False):
+    """
+    Functional form of one iteration of the reference's layer loop.  h [B,T,Din] (float32 or bfloat16, CUDA),
+    weight [H,Din], bias [H] (nn.Linear layout), trees: PrunedTrees.  compute_dtype float32 = exact fp32 MFMA,
+    bfloat16 = bf16 operands with fp32 accumulation.
+    """
+    if not isinstance(trees, PrunedTrees):
+        raise TypeError("trees must be a PrunedTrees (see model.tree.prune_to_csr / adj_to_csr)")
+    compute = _lib.dtype_code(compute_dtype)
+    _lib.require_gpu(h)
+    if compute == _lib.F32 and h.dtype != torch.float32:
+        h = h.float()
+    out_dtype = out_dtype or h.dtype
+    if compute == _lib.F32:
+        out_dtype = torch.float32
+    return _GCNLayerFn.apply(h, weight, bias, trees, float(drop_p), int(seed), compute, out_dtype, bool(no_adj))
+
+
+# ------------------------------------------------------------------------------------------------------
+# modules with the reference's names and state_dict layout
+# ------------------------------------------------------------------------------------------------------
+class GCNClassifier(nn.Module):
+    """Reference model/gcn.py:15-36."""
+
+    def __init__(self, opt, emb_matrix=None):
+        super().__init__()
+        self.gcn_model = GCNRelationModel(opt, emb_matrix=emb_matrix)
+        self.classifier = nn.Linear(opt['hidden_dim'], opt['num_class'])
+        self.opt = opt
+
+    def conv_l2(self):
+        return self.gcn_model.gcn.conv_l2()
+
+    def forward(self, inputs):
+        outputs, pooling_output = self.gcn_model(inputs)
+        return self.classifier(outputs), pooling_output
+
+    def get_deprel_emb(self):
+        return self.gcn_model.get_deprel_embedding()
+
+    def get_gcn_parameters(self):
+        return self.gcn_model.get_gcn_parameters()
+
+
+class GCNRelationModel(nn.Module):
+    """Reference model/gcn.py:38-126; the tree build of lines 96-112 runs on the device."""
+
+    def __init__(self, opt, emb_matrix=None):
+        super().__init__()
+        self.opt = opt
+        self.emb_matrix = emb_matrix
+        if opt.get('adj_type', 'regular') != 'regular':
+            raise NotImplementedError("adj_type=%r: only the 'regular' adjacency path is built so far "
+                                      "(diagonal_deprel / full_deprel are the next rows of the scope table)" % opt['adj_type'])
+        self.emb = nn.Embedding(opt['vocab_size'], opt['emb_dim'], padding_idx=constant.PAD_ID)
+        self.pos_emb = nn.Embedding(constant.N_POS, opt['pos_dim']) if opt['pos_dim'] > 0 else None
+        self.ner_emb = nn.Embedding(constant.N_NER, opt['ner_dim']) if opt['ner_dim'] > 0 else None
+        # the reference keeps a 1-wide dummy table on the regular path (gcn.py:53-56); kept for checkpoints
+        self.deprel_emb = nn.Embedding(constant.N_DEPREL, 1, padding_idx=0)
+        self.init_embeddings()
+        self.gcn = GCN(opt, (self.emb, self.pos_emb, self.ner_emb, self.deprel_emb), opt['hidden_dim'], opt['num_layers'])
+        mlp = [nn.Linear(opt['hidden_dim'] * 3, opt['hidden_dim']), nn.ReLU()]
+        for _ in range(opt['mlp_layers'] - 1):
+            mlp += [nn.Linear(opt['hidden_dim'], opt['hidden_dim']), nn.ReLU()]
+        self.out_mlp = nn.Sequential(*mlp)
+
+    def get_deprel_embedding(self):
+        return self.deprel_emb.weight
+
+    def get_gcn_parameters(self):
+        return self.gcn.get_gcn_parameters()
+
+    def init_embeddings(self):
+        """gcn.py:73-88: uniform(-1,1) or the given matrix; topn decides which rows are fine-tuned."""
+        with torch.no_grad():
+            if self.emb_matrix is None:
+                self.emb.weight[1:, :].uniform_(-1.0, 1.0)
+            else:
+                m = self.emb_matrix
+                self.emb.weight.copy_(torch.from_numpy(m) if isinstance(m, np.ndarray) else m)
+        topn = self.opt.get('topn', self.opt['vocab_size'])
+        if topn <= 0:
+            self.emb.weight.requires_grad = False
+        elif topn < self.opt['vocab_size']:
+            def keep_top(grad, n=topn):
+                grad = grad.clone()
+                grad[n:].zero_()
+                return grad
+            self.emb.weight.register_hook(keep_top)
+
+    def forward(self, inputs):
+        if self.opt['dataset'] == 'tacred':
+            words, masks, pos, ner, deprel, head, subj_pos, obj_pos = inputs
+        else:
+            words, masks, pos, deprel, head, subj_pos, obj_pos = inputs
+        # lengths, head_to_tree, tree_to_adj and the upload (gcn.py:96-112) in one launch, no host round trip
+        trees = prune_to_csr(head, subj_pos, obj_pos, deprel, self.opt['prune_k'], masks=masks, want_label=False)
+        if self.opt.get('gcn_check_trees', True):
+            trees.check(expect_maxlen=head.shape[1])
+        h, pool_mask = self.gcn(trees, inputs)
+        subj_mask = subj_pos.ne(0).unsqueeze(2)      # gcn.py:116 (True = not a subject token)
+        obj_mask = obj_pos.ne(0).unsqueeze(2)
+        kind = self.opt['pooling']
+        h_out = pool(h, pool_mask, type=kind)
+        outputs = torch.cat([h_out, pool(h, subj_mask, type=kind), pool(h, obj_mask, type=kind)], dim=1)
+        return self.out_mlp(outputs), h_out
+
+
+class GCN(nn.Module):
+    """Reference model/gcn.py:128-395, `regular` adjacency.  `adj` may be a dense float32 [B,T,T] tensor
+    (as the reference passes) or a PrunedTrees from model.tree."""
+
+    def __init__(self, opt, embeddings, mem_dim, num_layers):
+        super().__init__()
+        self.opt = opt
+        self.layers = num_layers
+        self.use_cuda = opt.get('cuda', True)
+        self.mem_dim = mem_dim
+        tacred = opt['dataset'] == 'tacred'
+        self.in_dim = opt['emb_dim'] + opt['pos_dim'] + (opt['ner_dim'] if tacred else 0)
+        self.emb, self.pos_emb, self.ner_emb, self.deprel_emb = embeddings
+        if opt.get('adj_type', 'regular') != 'regular':
+            raise NotImplementedError("adj_type=%r is not built yet; only 'regular'" % opt['adj_type'])
+        if opt.get('rnn', False):
+            self.rnn = nn.LSTM(self.in_dim, opt['rnn_hidden'], opt['rnn_layers'], batch_first=True,
+                               dropout=opt['rnn_dropout'], bidirectional=True)
+            self.in_dim = opt['rnn_hidden'] * 2
+            self.rnn_drop = nn.Dropout(opt['rnn_dropout'])
+        self.in_drop = nn.Dropout(opt['input_dropout'])
+        self.gcn_drop = nn.Dropout(opt['gcn_dropout'])
+        self.emb_dropout = opt.get('emb_dropout', 0.0)
+        self.W = nn.ModuleList(nn.Linear(self.in_dim if l == 0 else mem_dim, mem_dim) for l in range(num_layers))
+        kind = opt.get('gcn_dtype', 'fp32')
+        if kind not in ('fp32', 'bf16'):
+            raise ValueError("gcn_dtype must be 'fp32' or 'bf16'")
+        self.compute_dtype = torch.float32 if kind == 'fp32' else torch.bfloat16
+
+    def conv_l2(self):
+        return sum(p.pow(2).sum() for lin in self.W for p in (lin.weight, lin.bias))
+
+    def get_gcn_parameters(self):
+        return self.W
+
+    def _word_embeddings(self, words):
+        """EmbeddingDropout of the reference (model/dropouts.py:23-39): in training, every word TYPE of a
+        sentence is dropped with probability emb_dropout and the rest is scaled by 1/(1-p)."""
+        embs = self.emb(words)
+        p = self.emb_dropout
+        if not self.training or p <= 0.0:
+            return embs
+        keep = torch.empty((words.shape[0], self.emb.num_embeddings), device=words.device).bernoulli_(1 - p)
+        return embs * torch.gather(keep, 1, words).unsqueeze(-1) / (1 - p)
+
+    def encode_with_rnn(self, rnn_inputs, masks, batch_size):
+        lens = masks.eq(0).long().sum(1).cpu()
+        shape = (self.opt['rnn_layers'] * 2, batch_size, self.opt['rnn_hidden'])
+        h0 = rnn_inputs.new_zeros(shape)
+        packed = nn.utils.rnn.pack_padded_sequence(rnn_inputs, lens, batch_first=True, enforce_sorted=False)
+        out, _ = self.rnn(packed, (h0, h0.clone()))
+        out, _ = nn.utils.rnn.pad_packed_sequence(out, batch_first=True)
+        return out
+
+    def forward(self, adj, inputs):
+        if self.opt['dataset'] == 'tacred':
+            words, masks, pos, ner, deprel, head, subj_pos, obj_pos = inputs
+        else:
+            words, masks, pos, deprel, head, subj_pos, obj_pos = inputs
+            ner = None
+        parts = [words if words.dim() > 2 else self._word_embeddings(words)]    # gcn.py:235-239
+        if self.opt['pos_dim'] > 0:
+            parts.append(self.pos_emb(pos))
+        if self.opt['ner_dim'] > 0 and ner is not None:
+            parts.append(self.ner_emb(ner))
+        embs = self.in_drop(torch.cat(parts, dim=2))
+        if self.opt.get('rnn', False):
+            gcn_inputs = self.rnn_drop(self.encode_with_rnn(embs, masks, words.size(0)))
+        else:
+            gcn_inputs = embs
+
+        trees = adj if isinstance(adj, PrunedTrees) else adj_to_csr(adj, want_label=False)   # gcn.py:260-262
+        no_adj = bool(self.opt.get('no_adj', False))                                           # gcn.py:264-265
+        x = gcn_inputs
+        for l in range(self.layers):
+            last = l == self.layers - 1
+            p = self.gcn_drop.p if (self.training and not last) else 0.0                      # gcn.py:393
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0              # CPU generator: no GPU sync
+            out_dtype = torch.float32 if last else self.compute_dtype
+            x = gcn_layer(x, self.W[l].weight, self.W[l].bias, trees, p, seed, self.compute_dtype, out_dtype, no_adj)
+        return x, trees.pool_mask
+
+
+def pool(h, mask, type='max'):
+    """Reference model/gcn.py:473-483 (mask True = excluded)."""
+    if type == 'max':
+        return h.masked_fill(mask, -constant.INFINITY_NUMBER).max(1)[0]
+    h = h.masked_fill(mask, 0)
+    if type == 'avg':
+        return h.sum(1) / (mask.size(1) - mask.float().sum(1))
+    return h.sum(1)

@@ -1,0 +1,166 @@
+"""
+Pruned dependency trees on the device -- host-side mirror of reference model/tree.py for the hot path.
+
+The reference builds one Python `Tree` per sentence on the host (model/tree.py:58 head_to_tree) and
+turns it into a dense float32 [T,T] matrix (model/tree.py:167 tree_to_adj), after copying six tensors
+back from the GPU (model/gcn.py:96-110).  Here the whole batch is pruned by one HIP kernel launch
+(csrc/tree_kernels.hip) straight from the loader tensors that already sit in HBM, and what comes out
+is the CSR pattern of that matrix (`PrunedTrees`).  `PrunedTrees.to_dense()` gives the reference's
+labelled adjacency back for callers that want it.
+
+No CPU path exists: these functions raise if the tensors are not on a GPU or libgcnpt.so is missing.
+"""
+import torch
+
+from .. import _lib
+
+# what the reference raises for each per-sentence status code (informational, see TreeError)
+REFERENCE_EXCEPTION = {
+    _lib.E_PRUNE_NEGATIVE: "AttributeError (model/tree.py:194, Tree has no .head when prune < 0)",
+    _lib.E_NO_SUBJECT: "AttributeError/TypeError (model/tree.py:109,113, no subject token)",
+    _lib.E_NO_LCA: "UnboundLocalError (model/tree.py:124, entities under different roots)",
+    _lib.E_CYCLE: "never returns (model/tree.py:91-94, head cycle)",
+    _lib.E_BAD_HEAD: "IndexError (model/tree.py:94, head points past the sentence)",
+    _lib.E_ASSERT: "AssertionError (model/tree.py:159)",
+    _lib.E_CAPACITY: "n/a (adjacency capacity exceeded)",
+}
+
+
+class TreeError(ValueError):
+    """A sentence of the batch has no valid pruned tree; `.sentence`, `.code`, `.reference` say which and why."""
+
+    def __init__(self, sentence, code):
+        self.sentence, self.code = int(sentence), int(code)
+        self.reference = REFERENCE_EXCEPTION.get(self.code, "unknown")
+        super().__init__("sentence %d: pruned-tree build failed with code %d; the reference raises %s"
+                         % (self.sentence, self.code, self.reference))
+
+
+class PrunedTrees(object):
+    """
+    CSR pattern of the batch adjacency in HBM (layout: include/gcnpt.h).
+
+    row_ptr  int32 [B*(T+1)]   col_idx / label  int32 [B*cap]   rowT_ptr / colT_idx: transposed pattern
+    pool_mask bool [B,T,1]     the `mask` GCN.forward returns (model/gcn.py:262)
+    status   int32 [B+1]       per-sentence code, [B] = longest sentence seen
+    """
+
+    def __init__(self, B, T, cap, row_ptr, col_idx, label, rowT_ptr, colT_idx, pool_mask, status):
+        self.B, self.T, self.cap = B, T, cap
+        self.row_ptr, self.col_idx, self.label = row_ptr, col_idx, label
+        self.rowT_ptr, self.colT_idx = rowT_ptr, colT_idx
+        self.pool_mask, self.status = pool_mask, status
+        self._empty = None
+
+    @property
+    def device(self):
+        return self.row_ptr.device
+
+    def empty_row_ptr(self):
+        """row_ptr of an adjacency with no entries (the `no_adj` ablation, model/gcn.py:264-265)."""
+        if self._empty is None:
+            self._empty = torch.zeros_like(self.row_ptr)
+        return self._empty
+
+    def check(self, expect_maxlen=None):
+        """
+        Synchronises and raises what the reference would have raised while building the trees.
+        expect_maxlen: the padded length T; the reference's bmm fails when max(len) != T (gcn.py:97,269).
+        """
+        st = self.status.cpu()
+        bad = torch.nonzero(st[:-1] != 0)
+        if bad.numel():
+            b = int(bad[0])
+            raise TreeError(b, int(st[b]))
+        if expect_maxlen is not None and int(st[-1]) != expect_maxlen:
+            raise ValueError("longest sentence has %d tokens but the batch is padded to %d: the reference builds "
+                             "adj as [B,%d,%d] and its bmm with [B,%d,D] inputs fails (model/gcn.py:97,269)"
+                             % (int(st[-1]), expect_maxlen, int(st[-1]), int(st[-1]), expect_maxlen))
+        return self
+
+    def nnz(self):
+        rp = self.row_ptr.view(self.B, self.T + 1)
+        return (rp[:, -1] - rp[:, 0]).to(torch.int64)
+
+    def to_dense(self):
+        """float32 [B,T,T] with the labels tree_to_adj writes (deprel id, +42 for the reverse edge, 84 on the diagonal)."""
+        adj = torch.empty((self.B, self.T, self.T), dtype=torch.float32, device=self.device)
+        _lib.check(_lib.lib().gcnpt_csr_to_adj(_lib.stream(), _lib.ptr(self.row_ptr), _lib.ptr(self.col_idx),
+                                               _lib.ptr(self.label), self.B, self.T, _lib.ptr(adj)))
+        return adj
+
+
+def _alloc(B, T, cap, device, want_label, want_transpose):
+    i32 = dict(dtype=torch.int32, device=device)
+    row_ptr = torch.empty((B * (T + 1),), **i32)
+    col_idx = torch.empty((B * cap,), **i32)
+    label = torch.empty((B * cap,), **i32) if want_label else None
+    rowT_ptr = torch.empty((B * (T + 1),), **i32) if want_transpose else None
+    colT_idx = torch.empty((B * cap,), **i32) if want_transpose else None
+    pool_mask = torch.empty((B, T, 1), dtype=torch.bool, device=device)
+    status = torch.empty((B + 1,), **i32)
+    return row_ptr, col_idx, label, rowT_ptr, colT_idx, pool_mask, status
+
+
+def _i64(t, name):
+    if t.dtype != torch.int64:
+        raise TypeError("%s must be an int64 tensor (as data/loader.py produces), got %s" % (name, t.dtype))
+    return t.contiguous()
+
+
+def prune_to_csr(head, subj_pos, obj_pos, deprel, prune_k, masks=None, lens=None, want_label=True):
+    """
+    Batch version of `tree_to_adj(maxlen, head_to_tree(head[i], words[i], l[i], prune, subj_pos[i],
+    obj_pos[i], deprel[i]), directed=False, self_loop=True)` for every sentence i (model/gcn.py:105-106),
+    on the device.  head/subj_pos/obj_pos/deprel: int64 [B,T] CUDA tensors straight from the loader;
+    masks: bool [B,T] (True = pad, model/gcn.py:96) or lens: int32 [B].
+    Asynchronous; call `.check()` on the result to surface per-sentence errors.
+    """
+    _lib.require_gpu(head)
+    head, subj_pos, obj_pos, deprel = (_i64(t, n) for t, n in ((head, "head"), (subj_pos, "subj_pos"),
+                                                                (obj_pos, "obj_pos"), (deprel, "deprel")))
+    B, T = head.shape
+    if masks is None and lens is None:
+        raise ValueError("give masks (True = pad) or lens")
+    if masks is not None:
+        masks = masks.contiguous()
+        if masks.dtype not in (torch.bool, torch.uint8) or tuple(masks.shape) != (B, T):
+            raise TypeError("masks must be bool/uint8 [B,T]")
+    if lens is not None:
+        lens = lens.to(device=head.device, dtype=torch.int32).contiguous()
+    cap = 3 * T
+    bufs = _alloc(B, T, cap, head.device, want_label, True)
+    row_ptr, col_idx, label, rowT_ptr, colT_idx, pool_mask, status = bufs
+    _lib.check(_lib.lib().gcnpt_prune_to_csr(
+        _lib.stream(), _lib.ptr(head), _lib.ptr(subj_pos), _lib.ptr(obj_pos), _lib.ptr(deprel),
+        _lib.ptr(masks) if masks is not None else None, _lib.ptr(lens) if masks is None else None,
+        B, T, int(prune_k), cap, _lib.ptr(row_ptr), _lib.ptr(col_idx), _lib.ptr(label), _lib.ptr(rowT_ptr),
+        _lib.ptr(colT_idx), _lib.ptr(pool_mask), _lib.ptr(status)))
+    return PrunedTrees(B, T, cap, *bufs)
+
+
+def adj_to_csr(adj, want_label=True):
+    """CSR of an explicit dense adjacency [B,T,T] (the `adj` argument of GCN.forward, model/gcn.py:229,260-262)."""
+    if adj.dtype != torch.float32 or adj.dim() != 3 or adj.shape[1] != adj.shape[2]:
+        raise TypeError("adj must be float32 [B,T,T]")
+    adj = _lib.require_gpu(adj).contiguous()
+    B, T, _ = adj.shape
+    cap = T * T
+    bufs = _alloc(B, T, cap, adj.device, want_label, True)
+    row_ptr, col_idx, label, rowT_ptr, colT_idx, pool_mask, status = bufs
+    _lib.check(_lib.lib().gcnpt_adj_to_csr(_lib.stream(), _lib.ptr(adj), B, T, cap, _lib.ptr(row_ptr), _lib.ptr(col_idx),
+                                           _lib.ptr(label), _lib.ptr(rowT_ptr), _lib.ptr(colT_idx), _lib.ptr(pool_mask),
+                                           _lib.ptr(status)))
+    return PrunedTrees(B, T, cap, *bufs)
+
+
+def inputs_to_tree_reps(head, words, l, prune, subj_pos, obj_pos, deprel):
+    """
+    Same signature and result as the closure of that name in GCNRelationModel.forward (model/gcn.py:102-110):
+    the dense labelled adjacency float32 [B,maxlen,maxlen], but built on the device.  `words` is unused (the
+    reference only stores it on the Tree nodes); `l` are the sentence lengths (any int sequence/tensor).
+    """
+    lens = torch.as_tensor(l, dtype=torch.int32, device=head.device)
+    trees = prune_to_csr(head, subj_pos, obj_pos, deprel, prune, lens=lens)
+    trees.check(expect_maxlen=head.shape[1])
+    return trees.to_dense()

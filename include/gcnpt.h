@@ -1,0 +1,129 @@
+/*
+ * gcnpt.h -- C-ABI of libgcnpt.so: the MI355X (gfx950) implementation of the pruned-tree GCN hot path
+ * of gstoica27/gcn-over-pruned-trees.
+ *
+ * The reference has NO foreign-function interface for this path: its boundary is the Python nn.Module
+ * surface (model/gcn.py:15-126 GCNClassifier / GCNRelationModel, model/gcn.py:128-395 GCN.forward,
+ * model/tree.py:58 head_to_tree, model/tree.py:167 tree_to_adj).  The entry points below are what a
+ * ctypes binding of that surface needs; each cites the reference lines it replaces.  The host-side
+ * mirror that binds them lives in gcn-over-pruned-trees_amd/model/{tree,gcn}.py; INTEGRATION.md shows
+ * the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C types only; every pointer marked [dev] is a DEVICE pointer owned by the caller
+ *     (PyTorch-ROCm allocations in practice); the library allocates nothing and keeps no global state.
+ *   - `stream` is a hipStream_t passed as void*.  Every call only ENQUEUES work on that stream and never
+ *     synchronises, so calls can be captured into a hipGraph.
+ *   - return value: 0 = enqueued, <0 = error (GCNPT_E_*); the text is in gcnpt_last_error() (thread-local).
+ *   - a "row" is one token slot: row r = b*T + i of the padded [B,T,*] tensors the reference uses.
+ *
+ * Pruned-tree adjacency in HBM ("CSR", shared by every kernel):
+ *   row_ptr  int32 [B*(T+1)]   entries of row (b,i) are col_idx[row_ptr[b*(T+1)+i] .. row_ptr[b*(T+1)+i+1])
+ *                              (offsets are absolute; sentence b owns the slice [b*cap, (b+1)*cap))
+ *   col_idx  int32 [B*cap]     sentence-local column (token) index, ascending inside a row
+ *   label    int32 [B*cap]     the value tree_to_adj writes (deprel id / +42 / 84), optional
+ *   rowT_ptr/colT_idx          the same for the transposed pattern (needed by backward)
+ *   cap >= 3*T for pruned trees (nnz = 3n-2), cap = T*T for an arbitrary dense adjacency.
+ */
+#ifndef GCNPT_H
+#define GCNPT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GCNPT_ABI_VERSION 1
+
+/* element types of activation / gradient buffers and of the MFMA operands */
+#define GCNPT_F32 0
+#define GCNPT_BF16 1
+
+/* return codes.  -2..-7 are the reference's per-sentence failures and are ALSO what the pruner writes
+ * into status[b] (they mirror oracle/prune_ref.c). */
+#define GCNPT_OK 0
+#define GCNPT_E_INVALID -1        /* bad argument (null pointer, non-positive size, unsupported dtype) */
+#define GCNPT_E_PRUNE_NEGATIVE -2 /* model/tree.py:67-79 + 194: prune < 0 crashes the fork (AttributeError) */
+#define GCNPT_E_NO_SUBJECT -3     /* model/tree.py:109,113: no token with subj_pos == 0 */
+#define GCNPT_E_NO_LCA -4         /* model/tree.py:112-124: entities under different roots (UnboundLocalError) */
+#define GCNPT_E_CYCLE -5          /* model/tree.py:91-94: a head cycle never terminates in the reference */
+#define GCNPT_E_BAD_HEAD -6       /* model/tree.py:94: head points past the sentence (IndexError) */
+#define GCNPT_E_ASSERT -7         /* model/tree.py:159 */
+#define GCNPT_E_CAPACITY -8       /* a sentence needs more than `cap` adjacency entries */
+#define GCNPT_E_HIP -9            /* a HIP runtime call failed */
+#define GCNPT_E_UNSUPPORTED -10   /* shape outside what the kernels are built for */
+
+int gcnpt_abi_version(void);
+const char* gcnpt_last_error(void);
+
+/* ---- A1-A4: model/gcn.py:96-110 (lengths, head_to_tree x B, tree_to_adj x B, upload) ------------------
+ * One workgroup per sentence prunes the dependency tree to the tokens within `prune_k` of the
+ * subject<->object path (model/tree.py:80-162) and emits the CSR of the labelled adjacency that
+ * tree_to_adj(directed=False, self_loop=True) would have produced (model/tree.py:167-204).
+ *   head, subj_pos, obj_pos, deprel  [dev] int64 [B,T]   exactly the loader tensors (data/loader.py:111-121)
+ *   pad_mask  [dev] uint8/bool [B,T], non-zero = pad (model/gcn.py:96); may be NULL if `len` is given
+ *   len       [dev] int32 [B], used when pad_mask is NULL
+ *   label, rowT_ptr, colT_idx may be NULL (not produced)
+ *   pool_mask [dev] uint8 [B*T]: 1 where (row sum + column sum == 0), the mask GCN.forward returns (gcn.py:262)
+ *   status    [dev] int32 [B+1]: status[b] = 0 or GCNPT_E_* for sentence b (its rows are then empty);
+ *             status[B] = max sentence length seen (the reference needs it to equal T, gcn.py:97,269)
+ */
+int gcnpt_prune_to_csr(void* stream, const int64_t* head, const int64_t* subj_pos, const int64_t* obj_pos,
+                       const int64_t* deprel, const uint8_t* pad_mask, const int32_t* len, int B, int T,
+                       int prune_k, int cap, int32_t* row_ptr, int32_t* col_idx, int32_t* label,
+                       int32_t* rowT_ptr, int32_t* colT_idx, uint8_t* pool_mask, int32_t* status);
+
+/* ---- A5: model/gcn.py:260-262 on an explicit dense adjacency (GCN.forward(adj, inputs)) ----------------
+ * adj [dev] float32 [B,T,T] -> CSR of (adj != 0) and of its transpose, pool_mask as above.  cap >= max nnz
+ * per sentence (T*T always suffices); status[b] = GCNPT_E_CAPACITY when exceeded. */
+int gcnpt_adj_to_csr(void* stream, const float* adj, int B, int T, int cap, int32_t* row_ptr, int32_t* col_idx,
+                     int32_t* label, int32_t* rowT_ptr, int32_t* colT_idx, uint8_t* pool_mask, int32_t* status);
+
+/* inverse of the above for callers that want the reference's dense float32 [B,T,T] adjacency
+ * (model/gcn.py:106-108); adj is fully overwritten. */
+int gcnpt_csr_to_adj(void* stream, const int32_t* row_ptr, const int32_t* col_idx, const int32_t* label, int B,
+                     int T, float* adj);
+
+/* ---- A8: nn.Linear parameters of GCN.W[l] (model/gcn.py:170-176) -> MFMA fragment order ---------------
+ * W [dev] float32 [H,Din] row-major.  Produces the B-operand images the layer kernels stream:
+ *   w_fwd  (for (A+I)h . W^T)   gcnpt_packed_bytes(H, Din, dtype) bytes
+ *   w_bwd  (for ((A+I)^T dZ) . W) gcnpt_packed_bytes(Din, H, dtype) bytes       (either may be NULL)
+ * Must be re-run whenever the optimizer changed W. */
+size_t gcnpt_packed_bytes(int n_out, int k_in, int dtype);
+int gcnpt_pack_weights(void* stream, const float* W, int H, int Din, int dtype, void* w_fwd, void* w_bwd);
+
+/* ---- A6: one GCN layer, model/gcn.py:269-271 + 390-393 --------------------------------------------------
+ *   out[r,:] = dropout( relu( ( (sum_{c in row r} h[c,:] + h[r,:]) . W^T + 2 b ) / (deg[r] + 1) ) )
+ * h [dev] [B*T, Din] of h_dtype; out [dev] [B*T, H] of out_dtype; bias [dev] float32 [H].
+ * compute_dtype = GCNPT_BF16 (bf16 MFMA operands, fp32 accumulate; h/out may be f32 or bf16) or
+ *                 GCNPT_F32 (exact fp32 MFMA; h/out must be f32).
+ * drop_p in [0,1): 0 disables dropout (eval mode / last layer, gcn.py:393); otherwise element e of the
+ * output is kept iff hash(seed, e) >= drop_p and scaled by 1/(1-drop_p).
+ * deg_row_ptr: NULL, or the row_ptr whose row lengths give deg when the aggregated pattern differs from it
+ * (the `no_adj` ablation, gcn.py:264-265: denominators from the real adjacency, aggregation over an empty one). */
+int gcnpt_layer_fwd(void* stream, const void* h, int h_dtype, const void* w_fwd, const float* bias,
+                    const int32_t* row_ptr, const int32_t* col_idx, const int32_t* deg_row_ptr, int B, int T,
+                    int Din, int H, void* out, int out_dtype, int compute_dtype, float drop_p, uint64_t seed);
+
+/* ---- A7: autograd of A6 -----------------------------------------------------------------------------------
+ * With dZ[r,:] = dY[r,:] * 1[Y[r,:] > 0] * scale / (deg[r] + 1)   (Y = the layer's stored output, which
+ * already carries the dropout zeros; scale = 1/(1-drop_p)):
+ *   data   : dh[r,:]  = (sum_{c in rowT r} dZ[c,:] + dZ[r,:]) . W                  -> [B*T, Din] of dh_dtype
+ *   weight : dW      += dZ^T ((A+I) h)   [H,Din] float32,   db += 2 * sum_r dZ[r,:]  [H] float32
+ * dY and Y share g_dtype.  row_ptr/col_idx are the forward pattern (degrees, (A+I)h), rowT_* the transposed one
+ * (for bwd_data `row_ptr` is only read for the degrees; bwd_weight takes deg_row_ptr as gcnpt_layer_fwd does).
+ * gcnpt_layer_bwd_weight ACCUMULATES into dW/db with float atomics: zero them first (or pass zero_first = 1,
+ * which enqueues the memsets on `stream`). */
+int gcnpt_layer_bwd_data(void* stream, const void* dY, const void* Y, int g_dtype, const void* w_bwd,
+                         const int32_t* row_ptr, const int32_t* rowT_ptr, const int32_t* colT_idx, int B, int T,
+                         int Din, int H, void* dh, int dh_dtype, int compute_dtype, float scale);
+int gcnpt_layer_bwd_weight(void* stream, const void* dY, const void* Y, int g_dtype, const void* h, int h_dtype,
+                           const int32_t* row_ptr, const int32_t* col_idx, const int32_t* deg_row_ptr, int B, int T,
+                           int Din, int H, float* dW, float* db, int compute_dtype, float scale, int zero_first);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCNPT_H */

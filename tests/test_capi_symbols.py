@@ -1,0 +1,77 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/gcnpt.h declares, argument validation works without a GPU, and the host-side mirror keeps the
+reference's names.  No compute is launched here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "gcnpt.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gcnpt_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from gcn_over_pruned_trees_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared()
+    assert len(names) == 10
+    for n in names:
+        assert hasattr(handle, n), "libgcnpt.so does not export %s" % n
+    assert sorted(_lib.SIGNATURES) == names                      # the ctypes binding covers the header, nothing else
+    assert _lib.lib().gcnpt_abi_version() == 1
+
+
+def test_argument_validation_needs_no_gpu():
+    from gcn_over_pruned_trees_amd import _lib
+    L = _lib.lib()
+    assert L.gcnpt_prune_to_csr(None, None, None, None, None, None, None, 1, 1, 1, 3, None, None, None, None, None, None, None) == _lib.E_INVALID
+    assert b"null" in L.gcnpt_last_error()
+    buf = ctypes.create_string_buffer(64)
+    p = ctypes.addressof(buf)
+    assert L.gcnpt_prune_to_csr(None, p, p, p, p, p, None, 1, 4, -1, 12, p, p, None, None, None, None, p) == _lib.E_PRUNE_NEGATIVE
+    assert L.gcnpt_layer_fwd(None, p, 0, p, p, p, p, None, 1, 1, 8, 8, p, 0, 7, 0.0, 0) == _lib.E_INVALID
+    assert L.gcnpt_layer_fwd(None, p, 0, p, p, p, p, None, 1, 1, 8, 8, p, 0, 0, 1.5, 0) == _lib.E_INVALID
+    assert L.gcnpt_packed_bytes(200, 360, _lib.BF16) == 13 * 12 * 64 * 16
+    assert L.gcnpt_packed_bytes(200, 360, _lib.F32) == 13 * 23 * 64 * 16
+    assert L.gcnpt_packed_bytes(0, 360, _lib.BF16) == 0
+
+
+def test_no_cpu_fallback():
+    import torch
+    from gcn_over_pruned_trees_amd.model import gcn, tree
+    head = torch.zeros((1, 4), dtype=torch.int64)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        tree.prune_to_csr(head, head, head, head, 1, lens=torch.tensor([4], dtype=torch.int32))
+    with pytest.raises(TypeError):
+        gcn.gcn_layer(torch.zeros(1, 4, 8), torch.zeros(8, 8), torch.zeros(8), trees=None)
+
+
+def test_host_mirror_keeps_reference_surface():
+    import inspect
+    from gcn_over_pruned_trees_amd.model import gcn
+    assert list(inspect.signature(gcn.GCNClassifier.__init__).parameters) == ["self", "opt", "emb_matrix"]
+    assert list(inspect.signature(gcn.GCNRelationModel.__init__).parameters) == ["self", "opt", "emb_matrix"]
+    assert list(inspect.signature(gcn.GCN.__init__).parameters) == ["self", "opt", "embeddings", "mem_dim", "num_layers"]
+    assert list(inspect.signature(gcn.GCN.forward).parameters) == ["self", "adj", "inputs"]
+    assert list(inspect.signature(gcn.pool).parameters) == ["h", "mask", "type"]
+    opt = dict(vocab_size=50, emb_dim=8, pos_dim=2, ner_dim=2, hidden_dim=16, num_layers=2, input_dropout=0.0, gcn_dropout=0.5,
+               prune_k=1, pooling="max", mlp_layers=2, rnn=True, rnn_hidden=4, rnn_layers=1, rnn_dropout=0.0, dataset="tacred",
+               num_class=42, topn=10, cuda=False)
+    m = gcn.GCNClassifier(opt)
+    keys = set(m.state_dict().keys())
+    for k in ("gcn_model.emb.weight", "gcn_model.gcn.emb.weight", "gcn_model.deprel_emb.weight", "gcn_model.gcn.W.0.weight",
+              "gcn_model.gcn.W.1.bias", "gcn_model.gcn.rnn.weight_ih_l0_reverse", "gcn_model.out_mlp.2.weight", "classifier.bias"):
+        assert k in keys, k
+    assert m.gcn_model.gcn.W[0].weight.shape == (16, 8) and m.gcn_model.deprel_emb.weight.shape == (85, 1)
+    assert float(m.conv_l2()) > 0
+    with pytest.raises(NotImplementedError):
+        gcn.GCNClassifier(dict(opt, adj_type="full_deprel"))

@@ -1,0 +1,350 @@
+"""
+Parity tests proper: the HIP path (through the C-ABI) against the golden vectors recorded from the
+reference and against the CPU oracle, on a real MI355X.  Run with `pytest -m gpu`.
+
+Tolerances (stated by SURVEY.md 8c / BASELINE.json north_star):
+  integer outputs of the pruner ............ exact
+  fp32 mode, forward ....................... max|err| <= 1e-5 * max|ref|
+  fp32 mode, gradients ..................... max|err| <= 1e-4 * max|ref|
+  bf16 mode vs the bf16-rounding oracle .... max|err| <= 2^-7 * max|ref|   (one bf16 ulp of the largest value x2)
+  bf16 mode vs the fp32 reference .......... forward 2e-2, gradients 6e-2 normwise (SURVEY.md 7 "hard parts")
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import dense_from_coo, load_golden
+from helpers import FWD_RTOL, GRAD_RTOL, LAYER_CASES, layer_case, max_rel
+
+pytestmark = pytest.mark.gpu
+
+BF16_TIGHT = 2.0 ** -7
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu-marked tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def api():
+    from gcn_over_pruned_trees_amd import _lib
+    from gcn_over_pruned_trees_amd.model import gcn, tree
+    _lib.lib()          # fails loudly when libgcnpt.so was not built
+    return gcn, tree
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _prune(tree, g, K, dev, B=None):
+    sl = slice(0, B)
+    T = g["head"].shape[1]
+    masks = np.arange(T)[None, :] >= g["lens"][sl, None]
+    return tree.prune_to_csr(_t(g["head"][sl], dev), _t(g["subj_pos"][sl], dev), _t(g["obj_pos"][sl], dev),
+                             _t(g["deprel"][sl], dev), K, masks=_t(masks, dev))
+
+
+def _oracle_mask(adj):
+    A = adj != 0
+    return ((A.sum(2) + A.sum(1)) == 0)[..., None]
+
+
+# ---------------------------------------------------------------------------------------------------
+# pruner (A1-A4): exact
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,Ks", [("trees_tacred_samples.npz", (0, 1, 2)), ("trees_random.npz", (0, 1, 2, 3))])
+def test_pruner_golden(api, dev, name, Ks):
+    _, tree = api
+    g = load_golden(name)
+    B, T = g["head"].shape
+    for K in Ks:
+        trees = _prune(tree, g, K, dev)
+        want = dense_from_coo(g["coo_k%d" % K], B, T)
+        got = trees.to_dense().cpu().numpy()
+        np.testing.assert_array_equal(got, want)
+        assert (trees.status.cpu().numpy()[:B] == 0).all()
+        np.testing.assert_array_equal(trees.pool_mask.cpu().numpy(), _oracle_mask(want))
+        # transposed pattern == pattern of the transposed matrix
+        tr = tree.adj_to_csr(_t(np.ascontiguousarray(want.transpose(0, 2, 1)), dev))
+        a = trees.rowT_ptr.view(B, T + 1).cpu().numpy() - (np.arange(B) * trees.cap)[:, None]
+        b = tr.row_ptr.view(B, T + 1).cpu().numpy() - (np.arange(B) * tr.cap)[:, None]
+        np.testing.assert_array_equal(a, b)
+        ca, cb = trees.colT_idx.view(B, -1).cpu().numpy(), tr.col_idx.view(B, -1).cpu().numpy()
+        for s in range(0, B, 7):
+            n = a[s, -1]
+            np.testing.assert_array_equal(ca[s, :n], cb[s, :n])
+
+
+def test_pruner_edge_cases(api, dev):
+    _, tree = api
+    g = load_golden("trees_edge_cases.npz")
+    B, T = g["head"].shape
+    for K in (0, 1, 2):
+        trees = _prune(tree, g, K, dev)
+        st = trees.status.cpu().numpy()
+        np.testing.assert_array_equal(st[:B], g["status_k%d" % K])
+        assert st[B] == T
+        ok = g["status_k%d" % K] == 0
+        want = dense_from_coo(g["coo_k%d" % K], B, T)
+        got = trees.to_dense().cpu().numpy()
+        np.testing.assert_array_equal(got[ok], want[ok])
+        assert (got[~ok] == 0).all()
+        with pytest.raises(tree.TreeError) as ei:
+            trees.check()
+        assert ei.value.sentence == 2 and ei.value.code == -4       # the forest sentence, UnboundLocalError in the reference
+
+
+def test_pruner_errors(api, dev):
+    from gcn_over_pruned_trees_amd import _lib
+    _, tree = api
+    g = load_golden("trees_edge_cases.npz")
+    with pytest.raises(_lib.GcnptError) as ei:                       # prune_k < 0 crashes the fork (tree.py:194)
+        _prune(tree, g, -1, dev)
+    assert ei.value.code == _lib.E_PRUNE_NEGATIVE
+    head = g["head"][:1].copy()
+    head[0, :3] = [2, 3, 1]                                          # a head cycle hangs the reference; we report it
+    T = head.shape[1]
+    trees = tree.prune_to_csr(_t(head, dev), _t(g["subj_pos"][:1], dev), _t(g["obj_pos"][:1], dev), _t(g["deprel"][:1], dev), 1,
+                              lens=torch.tensor([T], dtype=torch.int32))
+    assert int(trees.status.cpu()[0]) == _lib.E_CYCLE
+    with pytest.raises(RuntimeError):                                # no CPU path
+        tree.prune_to_csr(torch.from_numpy(head), torch.from_numpy(head), torch.from_numpy(head), torch.from_numpy(head), 1,
+                          lens=torch.tensor([T], dtype=torch.int32))
+    # a batch whose longest sentence is shorter than the padding: the reference's bmm would fail
+    short = tree.prune_to_csr(_t(g["head"][:1], dev), _t(g["subj_pos"][:1], dev), _t(g["obj_pos"][:1], dev),
+                              _t(g["deprel"][:1], dev), 1, lens=torch.tensor([T - 1], dtype=torch.int32))
+    with pytest.raises(ValueError):
+        short.check(expect_maxlen=T)
+
+
+@pytest.mark.parametrize("B,T,K,lengths", [(50, 100, 1, "full"), (50, 100, 1, "tacred"), (128, 300, 2, "tacred"), (3, 1000, 3, "full")])
+def test_pruner_vs_oracle_full_size(api, dev, B, T, K, lengths):
+    from gcn_over_pruned_trees_amd.utils import synthetic
+    from oracle import prune_ref
+    _, tree = api
+    g = synthetic.random_tree_batch(1234 + B + T, B, T, lengths, overlap_frac=0.1)
+    want = prune_ref.batch_adj(g["head"], g["subj_pos"], g["obj_pos"], g["deprel"], g["lens"], K)
+    assert want["rc"] == 0
+    trees = _prune(tree, g, K, dev)
+    np.testing.assert_array_equal(trees.to_dense().cpu().numpy(), want["adj"])
+    np.testing.assert_array_equal(trees.pool_mask.cpu().numpy(), _oracle_mask(want["adj"]))
+    # nnz = 3n - 2 for an n-node tree with at least one edge
+    n = want["kept"].sum(1).astype(np.int64)
+    nnz = trees.nnz().cpu().numpy()
+    np.testing.assert_array_equal(nnz[n > 1], 3 * n[n > 1] - 2)
+    trees.check(expect_maxlen=T)
+
+
+def test_dense_adjacency_roundtrip(api, dev):
+    """GCN.forward(adj, ...) accepts any dense matrix, not only trees (gcn.py:260)."""
+    _, tree = api
+    rng = np.random.RandomState(3)
+    adj = (rng.random_sample((5, 37, 37)) < 0.08) * rng.randint(1, 85, size=(5, 37, 37))
+    adj = adj.astype(np.float32)
+    adj[2] = 0
+    adj[3] = rng.randint(1, 85, size=(37, 37))                      # completely dense sentence
+    trees = tree.adj_to_csr(_t(adj, dev))
+    np.testing.assert_array_equal(trees.to_dense().cpu().numpy(), adj)
+    np.testing.assert_array_equal(trees.pool_mask.cpu().numpy(), _oracle_mask(adj))
+    assert (trees.status.cpu().numpy()[:5] == 0).all()
+
+
+# ---------------------------------------------------------------------------------------------------
+# layers (A5-A7)
+# ---------------------------------------------------------------------------------------------------
+def _run_stack(api, dev, g, compute, x_dtype=torch.float32, trees=None, drop=None, no_adj=False):
+    gcn, tree = api
+    if trees is None:
+        trees = _prune(tree, g, int(g["prune_k"]), dev)
+    x = _t(g["x"], dev).to(x_dtype).requires_grad_()
+    Ws = [_t(w, dev).requires_grad_() for w in g["Ws"]]
+    bs = [_t(b, dev).requires_grad_() for b in g["bs"]]
+    L = len(Ws)
+    h = x
+    outs = []
+    for l in range(L):
+        last = l == L - 1
+        p, seed = (drop if (drop and not last) else (0.0, 0))
+        h = gcn.gcn_layer(h, Ws[l], bs[l], trees, p, seed, compute, torch.float32 if last else compute, no_adj)
+        outs.append(h)
+    h.backward(_t(g["gy"], dev))
+    return dict(h=h.detach().float().cpu().numpy(), dx=x.grad.float().cpu().numpy(),
+                dW=[w.grad.cpu().numpy() for w in Ws], db=[b.grad.cpu().numpy() for b in bs],
+                mask=trees.pool_mask.cpu().numpy(), outs=[o.detach().float().cpu().numpy() for o in outs])
+
+
+@pytest.mark.parametrize("name", LAYER_CASES)
+def test_layers_fp32_golden(api, dev, name):
+    g = layer_case(name)
+    r = _run_stack(api, dev, g, torch.float32)
+    np.testing.assert_array_equal(r["mask"], g["mask"])
+    assert max_rel(r["h"], g["h"]) <= FWD_RTOL
+    assert max_rel(r["dx"], g["dx"]) <= GRAD_RTOL
+    for l in range(int(g["layers"])):
+        assert max_rel(r["dW"][l], g["dW%d" % l]) <= GRAD_RTOL
+        assert max_rel(r["db"][l], g["db%d" % l]) <= GRAD_RTOL
+
+
+@pytest.mark.parametrize("name", LAYER_CASES)
+def test_layers_bf16_golden(api, dev, name):
+    from oracle import gcn_ref
+    g = layer_case(name)
+    r = _run_stack(api, dev, g, torch.bfloat16)
+    h16, _, _ = gcn_ref.gcn_forward_bf16(g["adj"], g["x"], g["Ws"], g["bs"])
+    # final output is stored as fp32 by the stack; the oracle rounds it to bf16: compare against both
+    assert max_rel(gcn_ref.round_bf16(r["h"]), h16) <= BF16_TIGHT
+    assert max_rel(r["h"], g["h"]) <= 2e-2
+    assert max_rel(r["dx"], g["dx"]) <= 6e-2
+    for l in range(int(g["layers"])):
+        assert max_rel(r["dW"][l], g["dW%d" % l]) <= 6e-2
+        assert max_rel(r["db"][l], g["db%d" % l]) <= 6e-2
+
+
+def test_layers_dense_adj_path_and_no_adj(api, dev):
+    """explicit dense adjacency (gcn.py:229) gives the same numbers as the pruner path; no_adj ablation (gcn.py:264)."""
+    from oracle import gcn_ref
+    gcn, tree = api
+    g = layer_case("layers_c1_l2.npz")
+    r = _run_stack(api, dev, g, torch.float32, trees=tree.adj_to_csr(_t(g["adj"], dev)))
+    assert max_rel(r["h"], g["h"]) <= FWD_RTOL and max_rel(r["dx"], g["dx"]) <= GRAD_RTOL
+    assert max_rel(r["dW"][0], g["dW0"]) <= GRAD_RTOL
+    r = _run_stack(api, dev, g, torch.float32, no_adj=True)
+    h, mask = gcn_ref.gcn_forward(g["adj"], g["x"], g["Ws"], g["bs"], no_adj=True)
+    dx, dWs, dbs = gcn_ref.gcn_backward(g["adj"], g["x"], g["Ws"], g["bs"], g["gy"], no_adj=True)
+    np.testing.assert_array_equal(r["mask"], mask)
+    assert max_rel(r["h"], h) <= FWD_RTOL and max_rel(r["dx"], dx) <= GRAD_RTOL
+    assert max_rel(r["dW"][1], dWs[1]) <= GRAD_RTOL and max_rel(r["db"][0], dbs[0]) <= GRAD_RTOL
+
+
+def test_layers_nonsymmetric_dense_adjacency(api, dev):
+    """backward uses the TRANSPOSED pattern: check it on an adjacency that is not symmetric."""
+    from oracle import gcn_ref
+    _, tree = api
+    rng = np.random.RandomState(11)
+    B, T, din, hid = 3, 23, 40, 24                                   # widths that are not multiples of 16/32
+    adj = ((rng.random_sample((B, T, T)) < 0.15) * rng.randint(1, 40, size=(B, T, T))).astype(np.float32)
+    g = dict(x=rng.standard_normal((B, T, din)).astype(np.float32), gy=rng.standard_normal((B, T, hid)).astype(np.float32),
+             Ws=[rng.uniform(-.3, .3, (hid, din)).astype(np.float32), rng.uniform(-.3, .3, (hid, hid)).astype(np.float32)],
+             bs=[rng.uniform(-.3, .3, (hid,)).astype(np.float32), rng.uniform(-.3, .3, (hid,)).astype(np.float32)])
+    r = _run_stack(api, dev, g, torch.float32, trees=tree.adj_to_csr(_t(adj, dev)))
+    h, _ = gcn_ref.gcn_forward(adj, g["x"], g["Ws"], g["bs"])
+    dx, dWs, dbs = gcn_ref.gcn_backward(adj, g["x"], g["Ws"], g["bs"], g["gy"])
+    assert max_rel(r["h"], h) <= FWD_RTOL and max_rel(r["dx"], dx) <= GRAD_RTOL
+    for l in range(2):
+        assert max_rel(r["dW"][l], dWs[l]) <= GRAD_RTOL and max_rel(r["db"][l], dbs[l]) <= GRAD_RTOL
+
+
+@pytest.mark.parametrize("din,hid", [(37, 19), (200, 200), (44, 300)])
+def test_layers_odd_widths_bf16(api, dev, din, hid):
+    from oracle import gcn_ref
+    from gcn_over_pruned_trees_amd.utils import synthetic
+    from oracle import prune_ref
+    tb = synthetic.random_tree_batch(77, 6, 33, "tacred")
+    adj = prune_ref.batch_adj(tb["head"], tb["subj_pos"], tb["obj_pos"], tb["deprel"], tb["lens"], 1)["adj"]
+    Ws, bs = synthetic.layer_params(5, [din, hid, hid])
+    g = dict(tb, x=synthetic.normal(6, (6, 33, din)), gy=synthetic.normal(7, (6, 33, hid)), Ws=Ws, bs=bs, prune_k=1)
+    for compute, ftol, gtol in ((torch.float32, FWD_RTOL, GRAD_RTOL), (torch.bfloat16, 2e-2, 6e-2)):
+        r = _run_stack(api, dev, g, compute)
+        h, _ = gcn_ref.gcn_forward(adj, g["x"], Ws, bs)
+        dx, dWs, dbs = gcn_ref.gcn_backward(adj, g["x"], Ws, bs, g["gy"])
+        assert max_rel(r["h"], h) <= ftol and max_rel(r["dx"], dx) <= gtol
+        for l in range(2):
+            assert max_rel(r["dW"][l], dWs[l]) <= gtol and max_rel(r["db"][l], dbs[l]) <= gtol
+
+
+def test_dropout(api, dev):
+    """In-kernel dropout: rate, 1/(1-p) scaling, determinism per seed, and a backward that uses the same mask."""
+    from oracle import gcn_ref
+    g = layer_case("layers_c2s.npz")
+    base = _run_stack(api, dev, g, torch.float32)
+    p = 0.5
+    r1 = _run_stack(api, dev, g, torch.float32, drop=(p, 12345))
+    r2 = _run_stack(api, dev, g, torch.float32, drop=(p, 12345))
+    r3 = _run_stack(api, dev, g, torch.float32, drop=(p, 999))
+    y, yd = base["outs"][0], r1["outs"][0]
+    np.testing.assert_array_equal(yd, r2["outs"][0])
+    kept = yd != 0
+    pos = y > 0
+    assert not kept[~pos].any()
+    np.testing.assert_allclose(yd[kept], y[kept] * 2.0, rtol=1e-6)
+    rate = kept[pos].mean()
+    assert abs(rate - (1 - p)) < 0.01
+    assert (r3["outs"][0] != 0)[pos].mean() != rate                   # another seed, another mask
+    mask = np.where(pos, kept, True).astype(np.float32)              # where y == 0 the mask is irrelevant
+    h, _ = gcn_ref.gcn_forward(g["adj"], g["x"], g["Ws"], g["bs"], drop_masks=[mask], drop_p=p)
+    dx, dWs, dbs = gcn_ref.gcn_backward(g["adj"], g["x"], g["Ws"], g["bs"], g["gy"], drop_masks=[mask], drop_p=p)
+    assert max_rel(r1["h"], h) <= FWD_RTOL and max_rel(r1["dx"], dx) <= GRAD_RTOL
+    for l in range(2):
+        assert max_rel(r1["dW"][l], dWs[l]) <= GRAD_RTOL and max_rel(r1["db"][l], dbs[l]) <= GRAD_RTOL
+    # a column-wise / row-wise look at the mask: no structure along either axis
+    m = kept[0] | ~pos[0]
+    assert abs(m.mean(0) - m.mean()).max() < 0.2 and abs(m.mean(1) - m.mean()).max() < 0.2
+
+
+@pytest.mark.parametrize("cfg", [dict(B=50, T=100, din=360, hid=200, K=1, lengths="full"),
+                                 dict(B=50, T=100, din=400, hid=200, K=1, lengths="tacred"),
+                                 dict(B=128, T=300, din=600, hid=300, K=2, lengths="tacred")])
+def test_layers_full_size_vs_oracle(api, dev, cfg):
+    """BASELINE.json configs 2, 3 (GCN part) and 5 at FULL size against the CPU oracle, both precisions."""
+    from gcn_over_pruned_trees_amd.utils import synthetic
+    from oracle import gcn_ref, prune_ref
+    B, T, din, hid, K = cfg["B"], cfg["T"], cfg["din"], cfg["hid"], cfg["K"]
+    tb = synthetic.random_tree_batch(1234, B, T, cfg["lengths"])
+    adj = prune_ref.batch_adj(tb["head"], tb["subj_pos"], tb["obj_pos"], tb["deprel"], tb["lens"], K)["adj"]
+    Ws, bs = synthetic.layer_params(2, [din, hid, hid])
+    g = dict(tb, x=synthetic.normal(3, (B, T, din)), gy=synthetic.normal(4, (B, T, hid)), Ws=Ws, bs=bs, prune_k=K)
+    h, mask = gcn_ref.gcn_forward(adj, g["x"], Ws, bs)
+    dx, dWs, dbs = gcn_ref.gcn_backward(adj, g["x"], Ws, bs, g["gy"])
+    res = {}
+    for compute, ftol, gtol in ((torch.float32, FWD_RTOL, GRAD_RTOL), (torch.bfloat16, 2e-2, 6e-2)):
+        r = res[compute] = _run_stack(api, dev, g, compute)
+        np.testing.assert_array_equal(r["mask"], mask)
+        assert max_rel(r["h"], h) <= ftol and max_rel(r["dx"], dx) <= gtol
+        for l in range(2):
+            assert max_rel(r["dW"][l], dWs[l]) <= gtol and max_rel(r["db"][l], dbs[l]) <= gtol
+    # size-independent property: the layer is positively homogeneous in (x, b): f(2x, 2b) = 2 f(x, b)
+    g2 = dict(g, x=2 * g["x"], bs=[2 * b for b in bs])
+    r2 = _run_stack(api, dev, g2, torch.float32)
+    assert max_rel(r2["outs"][0], 2 * res[torch.float32]["outs"][0]) <= 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------
+# drop-in boundary: the reference's module surface
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["gcn", "cgcn"])
+def test_classifier_end_to_end_golden(api, dev, tag):
+    import json
+    gcn, _ = api
+    g = load_golden("e2e_%s.npz" % tag)
+    opt = json.loads(str(g["opt"]))
+    opt["cuda"] = True
+    model = gcn.GCNClassifier(opt)
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd:")}
+    model.load_state_dict(sd, strict=True)                           # the reference's checkpoint layout loads as is
+    model.to(dev).eval()
+    inputs = tuple(_t(g[k], dev) for k in ("words", "masks", "pos", "ner", "deprel", "head", "subj_pos", "obj_pos"))
+    with torch.no_grad():
+        logits, pooled = model(inputs)
+    assert max_rel(logits.cpu().numpy(), g["logits"]) <= 1e-4
+    assert max_rel(pooled.cpu().numpy(), g["pooling_output"]) <= 1e-4
+    # training mode: a full update step runs (dropout on, grads reach every parameter of the layer stack)
+    model.train()
+    logits, pooled = model(inputs)
+    loss = logits.logsumexp(1).mean() + 0.003 * (pooled ** 2).sum(1).mean() + 1e-3 * model.conv_l2()
+    loss.backward()
+    for lin in model.get_gcn_parameters():
+        assert lin.weight.grad is not None and torch.isfinite(lin.weight.grad).all() and lin.weight.grad.abs().sum() > 0
+    assert model.gcn_model.emb.weight.grad.abs().sum() > 0
+
+
+def test_inputs_to_tree_reps_matches_reference_layout(api, dev):
+    _, tree = api
+    g = load_golden("trees_tacred_samples.npz")
+    B, T = g["head"].shape
+    order = np.argsort(-g["lens"], kind="stable")
+    adj = tree.inputs_to_tree_reps(_t(g["head"][order], dev), None, g["lens"][order], 1, _t(g["subj_pos"][order], dev),
+                                   _t(g["obj_pos"][order], dev), _t(g["deprel"][order], dev))
+    np.testing.assert_array_equal(adj.cpu().numpy(), dense_from_coo(g["coo_k1"], B, T)[order])

@@ -1,0 +1,127 @@
+"""
+The N > 1 path on CPU: world_size-2 `gloo` process groups exercising shard.py (sentence sharding,
+flat-bucket gradient all-reduce, overlapped double-buffered exchange, pooled all-gather).  The compute
+inside is a small torch module -- the HIP kernels need a GPU -- but the exchange code is the same one
+bench.py and a DP training loop use.
+"""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gcn_over_pruned_trees_amd import shard
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _spawn(fn, world=2, *args):
+    port = _free_port()
+    mp.spawn(_entry, args=(world, port, fn) + args, nprocs=world, join=True)
+
+
+def _entry(rank, world, port, fn, *args):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fn(rank, world, *args)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_sentences_balance():
+    rng = np.random.RandomState(0)
+    lens = np.clip(np.rint(rng.lognormal(3.45, 0.45, size=401)), 8, 300).astype(np.int64)
+    shards = shard.shard_sentences(lens, 8)
+    allidx = np.sort(np.concatenate(shards))
+    np.testing.assert_array_equal(allidx, np.arange(401))                    # a partition
+    counts = [len(s) for s in shards]
+    assert max(counts) - min(counts) <= 1
+    loads = np.array([lens[s].sum() for s in shards])
+    assert loads.max() - loads.min() <= lens.max()                           # within one sentence of each other
+    for s in shards:
+        assert (np.diff(lens[s]) <= 0).all()                                 # sorted by decreasing length
+
+
+def _model():
+    torch.manual_seed(7)
+    return torch.nn.Sequential(torch.nn.Linear(12, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+
+
+def _data():
+    g = torch.Generator().manual_seed(3)
+    return torch.randn(10, 12, generator=g), torch.randn(10, 3, generator=g)
+
+
+def _dp_grads(rank, world, unequal):
+    x, y = _data()
+    idx = [torch.arange(0, 7), torch.arange(7, 10)] if unequal else [torch.arange(0, 5), torch.arange(5, 10)]
+    m = _model()
+    bucket = shard.FlatGradBucket(m.parameters())
+    bucket.zero()
+    xs, ys = x[idx[rank]], y[idx[rank]]
+    loss = ((m(xs) - ys) ** 2).sum(1).mean()                                  # mean over the LOCAL sentences
+    loss.backward()
+    bucket.all_reduce(dist, weight=len(idx[rank]) / 10.0)
+    ref = _model()
+    ((ref(x) - y) ** 2).sum(1).mean().backward()                              # one process, whole batch
+    for p, q in zip(m.parameters(), ref.parameters()):
+        assert torch.allclose(p.grad, q.grad, atol=1e-6), (rank, (p.grad - q.grad).abs().max())
+
+
+def test_flat_bucket_equals_single_process_equal_shards():
+    _spawn(_dp_grads, 2, False)
+
+
+def test_flat_bucket_equals_single_process_unequal_shards():
+    _spawn(_dp_grads, 2, True)
+
+
+def _overlapped(rank, world):
+    buckets = [torch.zeros(1000), torch.zeros(1000)]
+    red = shard.OverlappedAllReduce(buckets, dist, average=True)
+    seen = []
+    for i in range(7):
+        k = i & 1
+        red.before_write(k)
+        if i >= 2:
+            seen.append((i - 2, buckets[k].clone()))                           # result of step i-2 is complete here
+        buckets[k].fill_(float((rank + 1) * (i + 1)))                          # "the kernels of step i write bucket k"
+        red.after_write(k)
+    red.finish()
+    for step, val in seen:
+        assert torch.all(val == 1.5 * (step + 1)), (step, val[0])              # average of (1,2)*(step+1)
+    assert torch.all(buckets[0] == 1.5 * 7) and torch.all(buckets[1] == 1.5 * 6)
+
+
+def test_overlapped_all_reduce():
+    _spawn(_overlapped, 2)
+
+
+def _gather(rank, world):
+    sizes = [3, 2]
+    pooled = torch.full((sizes[rank], 4), float(rank))
+    out = shard.all_gather_pooled(dist, pooled, sizes)
+    assert out.shape == (5, 4) and torch.all(out[:3] == 0) and torch.all(out[3:] == 1)
+    same = shard.all_gather_pooled(dist, torch.full((2, 4), float(rank)))
+    assert same.shape == (4, 4) and torch.all(same[2:] == 1)
+
+
+def test_all_gather_pooled():
+    _spawn(_gather, 2)
+
+
+def test_take_shard_trims_padding():
+    words = torch.tensor([[5, 6, 7, 8], [1, 2, 0, 0], [3, 0, 0, 0]])
+    masks = words.eq(0)
+    rels = torch.tensor([1, 2, 3])
+    w, m, r = shard.take_shard((words, masks, rels), [1, 2])
+    assert w.shape == (2, 2) and m.shape == (2, 2) and r.tolist() == [2, 3]

@@ -73,14 +73,22 @@ def gcn_forward(adj, x, weights, biases, drop_masks=None, drop_p=0.0, no_adj=Fal
     return h, mask
 
 
-def gcn_backward(adj, x, weights, biases, gy, drop_masks=None, drop_p=0.0, no_adj=False):
+def gcn_backward(adj, x, weights, biases, gy, drop_masks=None, drop_p=0.0, no_adj=False, acts=None):
     """
     What torch autograd produces for gcn_forward:
       dZ = dY * 1[out != 0] * dropscale / denom ;  dS = dZ W ;  dh = A^T dS + dS
       dW = dZ^T (A h + h) ;  db = 2 * sum dZ
     returns (dx, [dW_l], [db_l])
+
+    acts: optional list of the L layer OUTPUTS to differentiate through instead of recomputing them
+    (layer l then reads acts[l-1] as its input and takes its relu/dropout mask from acts[l] > 0).
+    Used to check a reduced-precision backward on its own: relu' is a step function, so a forward that
+    differs in the last bit near zero legitimately flips whole gradient terms.
     """
     h_L, _, (A, denom, saved) = gcn_forward(adj, x, weights, biases, drop_masks, drop_p, no_adj, True)
+    if acts is not None:
+        ins = [np.asarray(x, dtype=np.float32)] + [np.asarray(a, dtype=np.float32) for a in acts[:-1]]
+        saved = [(ins[l], np.matmul(A, ins[l]), np.asarray(acts[l], dtype=np.float32)) for l in range(len(weights))]
     L = len(weights)
     g = np.asarray(gy, dtype=np.float32)
     dWs, dbs = [None] * L, [None] * L

@@ -16,6 +16,13 @@ def max_rel(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
+def fro_rel(a, b):
+    """||a-b||_F / ||b||_F."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.sqrt(((a - b) ** 2).sum()) / max(np.sqrt((b ** 2).sum()), 1e-30))
+
+
 def layer_case(name):
     """Load a layers_*.npz fixture; regenerate seed-defined inputs and verify their checksums."""
     g = load_golden(name)

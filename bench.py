@@ -7,7 +7,7 @@ bench.py -- BASELINE.json metric: GCN-layer fwd+bwd sentences/sec at batch=50 se
 One "step" = the hot path over one synthetic TACRED-shaped batch of 50 sentences x 100 tokens
 (BASELINE.json configs[1]: 2-layer GCN, no LSTM, Din 360 -> 200 -> 200, prune_k 1, bf16 storage,
 fp32 accumulation, dropout 0.5 between the layers), entirely through the C-ABI of include/gcnpt.h:
-    pack W0,W1 -> layer0 fwd -> layer1 fwd -> layer1 bwd (weight, data) -> layer0 bwd (weight, data)
+    pack W0,W1 -> layer0 fwd -> layer1 fwd -> layer1 bwd (data, weight) -> layer0 bwd (data, weight)
 Inputs (x, gy, weights, the loader's integer tensors) are resident in HBM before the timed region.
 `value` is the layer stack alone, as the metric says; `with_prune` repeats the measurement with the
 pruned-tree adjacency build (gcnpt_prune_to_csr) inside every step.
@@ -84,6 +84,9 @@ class Stack(object):
         dims = [(H, Din), (H, H)]
         self.wf = [torch.empty((self.L.gcnpt_packed_bytes(h, d, self.compute),), dtype=torch.uint8, device=dev) for h, d in dims]
         self.wb = [torch.empty((self.L.gcnpt_packed_bytes(d, h, self.compute),), dtype=torch.uint8, device=dev) for h, d in dims]
+        # saved operands in MFMA fragment order: S_l = (A+I)h_l written by fwd, dZ_l written by bwd_data
+        self.sf = [torch.empty((self.L.gcnpt_frag_bytes(B * T, d, self.compute),), dtype=torch.uint8, device=dev) for h, d in dims]
+        self.zf = [torch.empty((self.L.gcnpt_frag_bytes(B * T, h, self.compute),), dtype=torch.uint8, device=dev) for h, d in dims]
         # two flat gradient buckets [dW0, db0, dW1, db1] so that the all-reduce of step i overlaps step i+1
         self.n_grad = H * Din + H + H * H + H
         self.buckets = [torch.zeros((self.n_grad,), dtype=torch.float32, device=dev) for _ in range(2)]
@@ -116,33 +119,37 @@ class Stack(object):
         H, Din = self.W[l].shape
         p = self.args.drop if l == 0 else 0.0
         self._lib.check(self.L.gcnpt_layer_fwd(self._lib.stream(), P(src), self.act, P(self.wf[l]), P(self.b[l]), P(tr.row_ptr), P(tr.col_idx),
-                                               None, self.B, self.T, Din, H, P(dst), self.act, self.compute, p, 0x5eed))
+                                               None, self.B, self.T, Din, H, P(dst), self.act, self.compute, p, 0x5eed, P(self.sf[l])))
 
-    def bwd_data(self, l):
+    def _dw_db(self, l, k):
+        g = self.grads(k)
+        return (g[0], g[1]) if l == 0 else (g[2], g[3])
+
+    def bwd_data(self, l, k=0):
+        """dh, the dZ fragment image, and cleared dW/db accumulators for bwd_weight(l, k)."""
         P, tr = self._lib.ptr, self.trees
         dy, y, dst = (self.gy, self.h2, self.dh1) if l == 1 else (self.dh1, self.h1, self.dx)
         H, Din = self.W[l].shape
         sc = self.scale if l == 0 else 1.0
+        dW, db = self._dw_db(l, k)
         self._lib.check(self.L.gcnpt_layer_bwd_data(self._lib.stream(), P(dy), P(y), self.act, P(self.wb[l]), P(tr.row_ptr), P(tr.rowT_ptr),
-                                                    P(tr.colT_idx), self.B, self.T, Din, H, P(dst), self.act, self.compute, sc))
+                                                    P(tr.colT_idx), self.B, self.T, Din, H, P(dst), self.act, self.compute, sc,
+                                                    P(self.zf[l]), P(dW), P(db)))
 
     def bwd_weight(self, l, k=0):
-        P, tr = self._lib.ptr, self.trees
-        dy, y, h = (self.gy, self.h2, self.h1) if l == 1 else (self.dh1, self.h1, self.x)
+        P = self._lib.ptr
         H, Din = self.W[l].shape
-        g = self.grads(k)
-        dW, db = (g[0], g[1]) if l == 0 else (g[2], g[3])
-        sc = self.scale if l == 0 else 1.0
-        self._lib.check(self.L.gcnpt_layer_bwd_weight(self._lib.stream(), P(dy), P(y), self.act, P(h), self.act, P(tr.row_ptr), P(tr.col_idx),
-                                                      None, self.B, self.T, Din, H, P(dW), P(db), self.compute, sc, 1))
+        dW, db = self._dw_db(l, k)
+        self._lib.check(self.L.gcnpt_layer_bwd_weight(self._lib.stream(), P(self.zf[l]), P(self.sf[l]), self.B, self.T, Din, H,
+                                                      P(dW), P(db), self.compute))
 
     def step(self, k=0, with_prune=False):
         if with_prune:
             self.prune()
         self.pack(0); self.pack(1)
         self.fwd(0); self.fwd(1)
-        self.bwd_weight(1, k); self.bwd_data(1)
-        self.bwd_weight(0, k); self.bwd_data(0)
+        self.bwd_data(1, k); self.bwd_weight(1, k)
+        self.bwd_data(0, k); self.bwd_weight(0, k)
 
     # ---- algorithmic bytes per launch (DESIGN.md "Measurement"; SURVEY.md 8d) ----
     def algorithmic_bytes(self):
@@ -152,9 +159,9 @@ class Stack(object):
         out = {}
         for l, (H, Din) in enumerate([tuple(w.shape) for w in self.W]):
             wp = self.wf[l].numel()
-            out["fwd%d" % l] = e * N * (Din + H) + wp + 4 * H + csr
-            out["bwd_data%d" % l] = e * N * (2 * H + Din) + self.wb[l].numel() + 2 * csr
-            out["bwd_weight%d" % l] = e * N * (2 * H + Din) + 4 * (H * Din + H) + csr
+            out["fwd%d" % l] = e * N * (Din + H) + wp + 4 * H + csr + self.sf[l].numel()
+            out["bwd_data%d" % l] = e * N * (2 * H + Din) + self.wb[l].numel() + 2 * csr + self.zf[l].numel() + 4 * (H * Din + H)
+            out["bwd_weight%d" % l] = self.zf[l].numel() + self.sf[l].numel() + 4 * (H * Din + H)
             out["pack%d" % l] = 4 * H * Din + self.wf[l].numel() + self.wb[l].numel()
         out["prune"] = 4 * 8 * N + N + 2 * csr + N + 4 * (B + 1)
         return out
@@ -199,8 +206,8 @@ def timed(run, steps, warmup, barrier):
 def kernel_breakdown(stack, use_graph, reps=50, rounds=20):
     """Average duration of each kernel of the step: `reps` back-to-back launches replayed as one hipGraph, HIP events around it."""
     calls = [("pack0", lambda: stack.pack(0)), ("pack1", lambda: stack.pack(1)), ("fwd0", lambda: stack.fwd(0)),
-             ("fwd1", lambda: stack.fwd(1)), ("bwd_weight1", lambda: stack.bwd_weight(1)), ("bwd_data1", lambda: stack.bwd_data(1)),
-             ("bwd_weight0", lambda: stack.bwd_weight(0)), ("bwd_data0", lambda: stack.bwd_data(0)), ("prune", stack.prune)]
+             ("fwd1", lambda: stack.fwd(1)), ("bwd_data1", lambda: stack.bwd_data(1)), ("bwd_weight1", lambda: stack.bwd_weight(1)),
+             ("bwd_data0", lambda: stack.bwd_data(0)), ("bwd_weight0", lambda: stack.bwd_weight(0)), ("prune", stack.prune)]
     stack.step()
     torch.cuda.synchronize()
     out = {}

@@ -1,0 +1,91 @@
+// Helpers shared by the layer kernels (gfx950): typed 8-element loads, LDS tile stores, dropout hash.
+#pragma once
+#include <algorithm>
+
+#include "gcnpt_common.h"
+
+namespace gcnpt {
+
+// ---------------------------------------------------------------------------------------------------
+// element access: 8 consecutive elements <-> 8 floats
+// ---------------------------------------------------------------------------------------------------
+template <typename T> struct io;
+
+template <> struct io<float> {
+    static __device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+        const float4 a = *reinterpret_cast<const float4*>(p);
+        const float4 b = *reinterpret_cast<const float4*>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    static __device__ __forceinline__ float load1(const float* p) { return *p; }
+    static __device__ __forceinline__ void store1(float* p, float v) { *p = v; }
+};
+
+template <> struct io<bf16_t> {
+    static __device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
+        const uint4 u = *reinterpret_cast<const uint4*>(p);
+        v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+        v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+        v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+        v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+    }
+    static __device__ __forceinline__ float load1(const bf16_t* p) { return bf16_to_f32(*p); }
+    static __device__ __forceinline__ void store1(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// 8 elements of row `row` starting at column k0 of a dense [*, K] matrix; columns >= K read as 0
+template <typename T>
+__device__ __forceinline__ void load_row8(const T* base, size_t row, int K, int k0, bool vec, float (&v)[8]) {
+    const T* p = base + row * (size_t)K + k0;
+    if (vec && k0 + 8 <= K) {
+        io<T>::load8(p, v);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (k0 + j < K) ? io<T>::load1(p + j) : 0.0f;
+    }
+}
+
+// LDS tile element type for each compute type, and how 8 floats are parked in it
+template <typename CT> struct tile;
+template <> struct tile<bf16_t> {
+    static __device__ __forceinline__ void put8(bf16_t* p, const float (&v)[8]) {
+        uint4 u;
+        u.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+        u.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+        u.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+        u.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+        *reinterpret_cast<uint4*>(p) = u;
+    }
+};
+template <> struct tile<float> {
+    static __device__ __forceinline__ void put8(float* p, const float (&v)[8]) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+};
+
+// LDS row stride in dwords: >= payload, == 8 (mod 16) so the 16 rows x 4 k-groups that one
+// ds_read_b128 wave-instruction touches fall on distinct banks (bank = dword % 64, 16-lane groups)
+__host__ __device__ inline int lds_stride_dw(int payload_dw) {
+    int s = round_up(payload_dw, 4);
+    while ((s & 15) != 8) s += 4;
+    return s;
+}
+
+// counter-based dropout decision for output element e: uniform 24-bit value from (seed, e)
+__device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t e, unsigned thresh24) {
+    unsigned x = (unsigned)e ^ (unsigned)seed;
+    unsigned y = (unsigned)(e >> 32) ^ (unsigned)(seed >> 32) ^ 0x9E3779B9u;
+    x *= 0x85EBCA6Bu; x ^= x >> 15; x += y * 0xC2B2AE35u;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return (x >> 8) >= thresh24;
+}
+
+
+// host-side argument helpers of the C-ABI wrappers
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline int kstep_of(int dtype) { return dtype == GCNPT_BF16 ? 32 : 16; }
+static inline size_t esize(int dtype) { return dtype == GCNPT_BF16 ? 2 : 4; }
+static inline bool dtype_ok(int d) { return d == GCNPT_F32 || d == GCNPT_BF16; }
+
+}  // namespace gcnpt

@@ -1,0 +1,460 @@
+// GCN layer forward and backward-data for gfx950 (CDNA4): reference model/gcn.py:269-271, 390-393.
+//
+//   forward        out = dropout(relu((((A+I) h) W^T + 2 b) / (deg + 1)))
+//   backward-data  dh  = ((A+I)^T dZ) W            with dZ = dY * 1[Y>0] * scale / (deg + 1)
+//
+// Both are ONE row-tile kernel.  A workgroup (8 waves) owns ROWS = 32 consecutive token rows and is the
+// only workgroup on its CU (157 workgroups at B=50, T=100), so it is built to have every byte it
+// needs in flight at once rather than for occupancy:
+//   (0) each wave issues the loads of ALL weight fragments it will use (registers, up to KSMAX k-steps);
+//   (1) 32 lanes fetch the rows' CSR extents, degrees and first neighbours -> LDS;
+//       meanwhile every thread issues the loads of its share of the tile's own rows;
+//   (2) neighbour rows (<= 3 per kept token of a pruned tree) are added in fp32 and the tile is parked
+//       in LDS in the MFMA operand type;
+//   (3) the tile meets the register-resident weight fragments on the matrix cores;
+//   (4) the epilogue runs on the accumulators, the result is staged through LDS and leaves as
+//       whole rows in 16-byte stores.
+// The dense [B,T,T] bmm of the reference (gcn.py:269) never exists: aggregation is a gather.
+#include "layer_common.h"
+
+namespace gcnpt {
+
+constexpr int ROWS = 32;             // token rows per workgroup (two 16-row MFMA tiles)
+constexpr int RT_THREADS = 512;      // 8 waves; wave w owns output tiles w, w+8, ...
+constexpr int RT_WAVES = RT_THREADS / WAVE;
+constexpr int NB_INLINE = 4;         // neighbours per row staged in LDS next to the extents
+
+struct RowTileParams {
+    const void* src;        // fwd: h [N,K]      bwd: dY [N,K]
+    const void* yref;       // bwd: Y [N,K] (stored layer output)
+    const void* wfrag;      // packed B operand, gcnpt_pack_weights
+    const float* bias;      // fwd: [NOUT]
+    const int32_t* g_row_ptr;   // pattern gathered over (fwd: A, bwd: A^T)
+    const int32_t* g_col_idx;
+    const int32_t* d_row_ptr;   // pattern whose row length gives deg (always A)
+    void* out;              // [N,NOUT]; NULL = only the side outputs below are wanted
+    void* frag_out;         // NULL or fragment image (include/gcnpt.h) of the tile: fwd S = (A+I)h, bwd dZ
+    float* zero_a;          // NULL or accumulators to clear for the kernel that follows (bwd: dW, db)
+    float* zero_b;
+    int zero_a_n, zero_b_n;
+    int N, T, K, NOUT, Kpad;
+    int vec_in, vec_out;    // rows may be read / written 16 bytes at a time
+    float scale;            // bwd: 1/(1-p) of the dropout applied to Y; fwd: 1/(1-drop_p)
+    float drop_p;           // fwd
+    unsigned drop_thresh24;
+    uint64_t seed;
+};
+
+template <typename IT> struct raw8 { uint4 a, b; };      // 8 elements as loaded (bf16: a only)
+
+template <typename IT>
+__device__ __forceinline__ void issue8(const IT* base, size_t row, int K, int k0, bool vec, raw8<IT>& r) {
+    const IT* p = base + row * (size_t)K + k0;
+    if (vec && k0 + 8 <= K) {
+        r.a = *reinterpret_cast<const uint4*>(p);
+        if constexpr (sizeof(IT) == 4) r.b = *reinterpret_cast<const uint4*>(p + 4);
+    } else {                                             // ragged tail / unaligned: element loads
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (k0 + j < K) ? io<IT>::load1(p + j) : 0.0f;
+        if constexpr (sizeof(IT) == 4) {
+            r.a = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+            r.b = make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7]));
+        } else {
+            r.a.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+            r.a.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+            r.a.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+            r.a.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+        }
+    }
+}
+
+template <typename IT>
+__device__ __forceinline__ void unpack8(const raw8<IT>& r, float (&v)[8]) {
+    if constexpr (sizeof(IT) == 4) {
+        v[0] = __uint_as_float(r.a.x); v[1] = __uint_as_float(r.a.y); v[2] = __uint_as_float(r.a.z); v[3] = __uint_as_float(r.a.w);
+        v[4] = __uint_as_float(r.b.x); v[5] = __uint_as_float(r.b.y); v[6] = __uint_as_float(r.b.z); v[7] = __uint_as_float(r.b.w);
+    } else {
+        v[0] = __uint_as_float(r.a.x << 16); v[1] = __uint_as_float(r.a.x & 0xffff0000u);
+        v[2] = __uint_as_float(r.a.y << 16); v[3] = __uint_as_float(r.a.y & 0xffff0000u);
+        v[4] = __uint_as_float(r.a.z << 16); v[5] = __uint_as_float(r.a.z & 0xffff0000u);
+        v[6] = __uint_as_float(r.a.w << 16); v[7] = __uint_as_float(r.a.w & 0xffff0000u);
+    }
+}
+
+// out-tile row stride in dwords: 16-byte aligned rows, == 4 (mod 8) to spread the 4 row groups of an
+// accumulator store over the banks
+__host__ __device__ inline int out_stride_dw(int payload_dw) {
+    int s = round_up(payload_dw, 4);
+    while ((s & 7) != 4) s += 4;
+    return s;
+}
+
+template <typename CT, typename IT, typename OT, bool BWD, int NTW, int KSMAX>
+__global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTileParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int KSTEP = sizeof(CT) == 2 ? 32 : 16;            // K consumed per fragment
+    constexpr bool WIDE = BWD && sizeof(IT) == 4;               // two fp32 streams per row: fewer rows in flight per thread
+    constexpr int ITEMS = WIDE ? 2 : 3;                         // 8-element chunks a thread gathers per batch
+    constexpr int NBU = WIDE ? 2 : NB_INLINE;                   // neighbour rows fetched together
+    const int stride = lds_stride_dw(p.Kpad * (int)sizeof(CT) / 4) * 4 / (int)sizeof(CT);     // S row stride, CT elements
+    const int ncols_pass = RT_WAVES * NTW * 16;
+    const int ostride = out_stride_dw(min(round_up(p.NOUT, 16), ncols_pass) * (int)sizeof(OT) / 4) * 4 / (int)sizeof(OT);
+    const size_t s_bytes = (size_t)ROWS * stride * sizeof(CT);
+    CT* S = reinterpret_cast<CT*>(smem_raw);
+    CT* Z = reinterpret_cast<CT*>(smem_raw + s_bytes);          // bwd only: the tile's own dZ rows (before aggregation)
+    OT* O = reinterpret_cast<OT*>(smem_raw + (BWD ? 2 : 1) * s_bytes);
+    int* meta = reinterpret_cast<int*>(smem_raw + (BWD ? 2 : 1) * s_bytes + (size_t)ROWS * ostride * sizeof(OT));
+    int* rbeg = meta;                         // [ROWS]
+    int* rend = meta + ROWS;                  // [ROWS]
+    float* rinv = reinterpret_cast<float*>(meta + 2 * ROWS);   // [ROWS] fwd: deg+1   bwd: scale/(deg+1)
+    int* rnbr = meta + 3 * ROWS;              // [ROWS][NB_INLINE] absolute neighbour rows
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = blockIdx.x * ROWS;
+    const IT* src = static_cast<const IT*>(p.src);
+    const IT* yref = static_cast<const IT*>(p.yref);
+    const uint4* wfrag = static_cast<const uint4*>(p.wfrag);
+    const int n_tiles = ceil_div(p.NOUT, 16);
+    const int ksteps = p.Kpad / KSTEP;
+
+    // (0) weight fragments of the first pass / first K chunk: issued before anything else
+    uint4 wreg[KSMAX][NTW];
+    auto load_w = [&](int pass, int kc0) {
+#pragma unroll
+        for (int ks = 0; ks < KSMAX; ++ks)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                const int tl = pass * RT_WAVES * NTW + j * RT_WAVES + wave;
+                if (kc0 + ks < ksteps && tl < n_tiles) wreg[ks][j] = wfrag[((size_t)tl * ksteps + kc0 + ks) * 64 + lane];
+            }
+    };
+    if (p.out) load_w(0, 0);
+
+    // (1) row metadata -> LDS (32 lanes), own-row loads of the first batch (everyone)
+    if (tid < ROWS) {
+        const int r = r0 + tid;
+        int beg = 0, end = 0;
+        float dn = 1.0f;
+        if (r < p.N) {
+            const int b = r / p.T, i = r - b * p.T;
+            const size_t q = (size_t)b * (p.T + 1) + i;
+            beg = p.g_row_ptr[q]; end = p.g_row_ptr[q + 1];
+            dn = (float)(p.d_row_ptr[q + 1] - p.d_row_ptr[q] + 1);          // gcn.py:261
+#pragma unroll
+            for (int e = 0; e < NB_INLINE; ++e)
+                rnbr[tid * NB_INLINE + e] = (beg + e < end) ? b * p.T + p.g_col_idx[beg + e] : 0;
+        }
+        rbeg[tid] = beg; rend[tid] = end;
+        rinv[tid] = BWD ? p.scale / dn : dn;
+    }
+    const int nchunk = p.Kpad / 8;
+    const int n_items = ROWS * nchunk;
+
+    raw8<IT> self[ITEMS], selfy[ITEMS];
+    auto issue_self = [&](int batch) {
+#pragma unroll
+        for (int u = 0; u < ITEMS; ++u) {
+            const int it = (batch * ITEMS + u) * RT_THREADS + tid;
+            const int row = it / nchunk, k0 = (it - row * nchunk) * 8;
+            const int r = r0 + row;
+            if (it < n_items && r < p.N && k0 < p.K) {
+                issue8<IT>(src, (size_t)r, p.K, k0, p.vec_in, self[u]);
+                if (BWD) issue8<IT>(yref, (size_t)r, p.K, k0, p.vec_in, selfy[u]);
+            }
+        }
+    };
+    issue_self(0);
+    __syncthreads();
+
+    // (2) finish the gather batch by batch: S[row,:] = x[row,:] + sum_{c in pattern row} x[c,:]
+    const int n_batches = ceil_div(n_items, ITEMS * RT_THREADS);
+    for (int batch = 0; batch < n_batches; ++batch) {
+        if (batch > 0) issue_self(batch);
+#pragma unroll
+        for (int u = 0; u < ITEMS; ++u) {
+            const int it = (batch * ITEMS + u) * RT_THREADS + tid;
+            if (it >= n_items) continue;
+            const int row = it / nchunk, k0 = (it - row * nchunk) * 8;
+            const int r = r0 + row;
+            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (r < p.N && k0 < p.K) {
+                unpack8<IT>(self[u], acc);                              // the explicit W(h) term, gcn.py:271
+                if (BWD) {
+                    float y[8];
+                    unpack8<IT>(selfy[u], y);
+                    const float inv = rinv[row];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = (y[j] > 0.0f) ? acc[j] * inv : 0.0f;
+                }
+            }
+            if (BWD && p.frag_out) tile<CT>::put8(Z + (size_t)row * stride + k0, acc);
+            if (p.out && r < p.N && k0 < p.K) {
+                const int beg = rbeg[row], n = rend[row] - beg;
+                for (int e0 = 0; e0 < n; e0 += NBU) {                   // gcn.py:269, <= 3 neighbours for a pruned tree
+                    raw8<IT> nb[NBU], nby[NBU];
+                    float ninv[NBU];
+#pragma unroll
+                    for (int e = 0; e < NBU; ++e) {
+                        if (e0 + e < n) {
+                            const int c = (e0 + e < NB_INLINE) ? rnbr[row * NB_INLINE + e0 + e]
+                                                               : (r / p.T) * p.T + p.g_col_idx[beg + e0 + e];
+                            issue8<IT>(src, (size_t)c, p.K, k0, p.vec_in, nb[e]);
+                            if (BWD) {
+                                issue8<IT>(yref, (size_t)c, p.K, k0, p.vec_in, nby[e]);
+                                const int cb = c / p.T;
+                                const size_t q = (size_t)cb * (p.T + 1) + (c - cb * p.T);
+                                ninv[e] = p.scale / (float)(p.d_row_ptr[q + 1] - p.d_row_ptr[q] + 1);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < NBU; ++e) {
+                        if (e0 + e < n) {
+                            float v[8];
+                            unpack8<IT>(nb[e], v);
+                            if (BWD) {
+                                float y[8];
+                                unpack8<IT>(nby[e], y);
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) acc[j] += (y[j] > 0.0f) ? v[j] * ninv[e] : 0.0f;
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) acc[j] += v[j];
+                            }
+                        }
+                    }
+                }
+            }
+            tile<CT>::put8(S + (size_t)row * stride + k0, acc);
+        }
+    }
+    __syncthreads();
+
+    // side outputs: the tile in MFMA fragment order for the weight gradient (rows are its contraction index),
+    // and cleared accumulators for the kernel that follows
+    if (p.frag_out) {
+        uint4* F = static_cast<uint4*>(p.frag_out);
+        const CT* X = BWD ? Z : S;
+        const int w_tiles = ceil_div(p.K, 16);
+        if constexpr (sizeof(CT) == 2) {
+            const int i = lane & 15, g = lane >> 4, q4 = i >> 2, pp = i & 3;
+            const size_t nks = gridDim.x;
+            for (int t = wave; t < w_tiles; t += RT_WAVES) {
+                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4_t*)(X + (size_t)(8 * g + q4) * stride + 16 * t + 4 * pp));
+                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4_t*)(X + (size_t)(8 * g + 4 + q4) * stride + 16 * t + 4 * pp));
+                uint4 u;
+                u.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
+                u.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
+                u.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
+                u.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
+                F[((size_t)t * nks + blockIdx.x) * 64 + lane] = u;
+            }
+        } else {
+            const int i = lane & 15, g = lane >> 4;
+            const size_t nks = (size_t)gridDim.x * 2;
+            for (int tk = wave; tk < w_tiles * 2; tk += RT_WAVES) {
+                const int t = tk >> 1, kk = tk & 1;
+                uint4 u;
+                u.x = __float_as_uint(X[(size_t)(16 * kk + 4 * g + 0) * stride + 16 * t + i]);
+                u.y = __float_as_uint(X[(size_t)(16 * kk + 4 * g + 1) * stride + 16 * t + i]);
+                u.z = __float_as_uint(X[(size_t)(16 * kk + 4 * g + 2) * stride + 16 * t + i]);
+                u.w = __float_as_uint(X[(size_t)(16 * kk + 4 * g + 3) * stride + 16 * t + i]);
+                F[((size_t)t * nks + 2 * blockIdx.x + kk) * 64 + lane] = u;
+            }
+        }
+    }
+    if (p.zero_a)
+        for (int i = blockIdx.x * RT_THREADS + tid; i < p.zero_a_n; i += gridDim.x * RT_THREADS) p.zero_a[i] = 0.0f;
+    if (p.zero_b)
+        for (int i = blockIdx.x * RT_THREADS + tid; i < p.zero_b_n; i += gridDim.x * RT_THREADS) p.zero_b[i] = 0.0f;
+    if (!p.out) return;
+
+    // (3) + (4)
+    OT* out = static_cast<OT*>(p.out);
+    const int arow = lane & 15, kgrp = lane >> 4;
+    const int n_pass = ceil_div(n_tiles, RT_WAVES * NTW);
+
+    for (int pass = 0; pass < n_pass; ++pass) {
+        f32x4_t acc[2][NTW];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) { acc[0][j] = (f32x4_t){0, 0, 0, 0}; acc[1][j] = (f32x4_t){0, 0, 0, 0}; }
+        const int tile0 = pass * RT_WAVES * NTW + wave;
+
+        for (int kc0 = 0; kc0 < ksteps; kc0 += KSMAX) {
+            if (pass > 0 || kc0 > 0) load_w(pass, kc0);
+#pragma unroll
+            for (int ks = 0; ks < KSMAX; ++ks) {
+                if (kc0 + ks >= ksteps) continue;
+                const int kk = kc0 + ks;
+                if constexpr (sizeof(CT) == 2) {
+                    const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(S + (size_t)arow * stride + kk * 32 + kgrp * 8);
+                    const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(S + (size_t)(arow + 16) * stride + kk * 32 + kgrp * 8);
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) {
+                        if (tile0 + j * RT_WAVES < n_tiles) {
+                            const bf16x8_t bq = __builtin_bit_cast(bf16x8_t, wreg[ks][j]);
+                            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bq, acc[0][j], 0, 0, 0);
+                            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bq, acc[1][j], 0, 0, 0);
+                        }
+                    }
+                } else {
+                    const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(S + (size_t)arow * stride + kk * 16 + kgrp * 4);
+                    const f32x4_t a1 = *reinterpret_cast<const f32x4_t*>(S + (size_t)(arow + 16) * stride + kk * 16 + kgrp * 4);
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) {
+                        if (tile0 + j * RT_WAVES < n_tiles) {
+                            const f32x4_t bq = __builtin_bit_cast(f32x4_t, wreg[ks][j]);
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) {
+                                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], bq[s], acc[0][j], 0, 0, 0);
+                                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], bq[s], acc[1][j], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+
+        // epilogue on the accumulators -> LDS out tile
+        if (pass > 0) __syncthreads();                                   // previous pass's rows have left O
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int tl = tile0 + j * RT_WAVES;
+            if (tl >= n_tiles) continue;
+            const int col = tl * 16 + (lane & 15);
+            const int lcol = col - pass * ncols_pass;
+            const float b2 = (BWD || col >= p.NOUT) ? 0.0f : 2.0f * p.bias[col];   // bias enters twice, gcn.py:270-271
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int row = mt * 16 + (lane >> 4) * 4 + g;
+                    float v = acc[mt][j][g];
+                    if (!BWD) {
+                        v = (v + b2) / rinv[row];                        // gcn.py:390
+                        v = v > 0.0f ? v : 0.0f;                         // gcn.py:392
+                        if (p.drop_p > 0.0f) {                            // gcn.py:393
+                            const uint64_t e = (uint64_t)(r0 + row) * (uint64_t)p.NOUT + (uint64_t)col;
+                            v = drop_keep(p.seed, e, p.drop_thresh24) ? v * p.scale : 0.0f;
+                        }
+                    }
+                    io<OT>::store1(O + (size_t)row * ostride + lcol, v);
+                }
+            }
+        }
+        __syncthreads();
+
+        // whole rows leave in 16-byte pieces
+        const int c_lo = pass * ncols_pass, c_hi = min(p.NOUT, c_lo + ncols_pass);
+        const int width = c_hi - c_lo;
+        constexpr int PER = 16 / (int)sizeof(OT);
+        if (p.vec_out && (width % PER) == 0 && (c_lo % PER) == 0) {
+            const int pieces = width / PER;
+            for (int it = tid; it < ROWS * pieces; it += RT_THREADS) {
+                const int row = it / pieces, pc = it - row * pieces;
+                const int r = r0 + row;
+                if (r < p.N)
+                    *reinterpret_cast<uint4*>(out + (size_t)r * p.NOUT + c_lo + pc * PER) =
+                        *reinterpret_cast<const uint4*>(O + (size_t)row * ostride + pc * PER);
+            }
+        } else {
+            for (int it = tid; it < ROWS * width; it += RT_THREADS) {
+                const int row = it / width, c = it - row * width;
+                const int r = r0 + row;
+                if (r < p.N) out[(size_t)r * p.NOUT + c_lo + c] = O[(size_t)row * ostride + c];
+            }
+        }
+    }
+}
+
+}  // namespace gcnpt
+
+// =====================================================================================================
+// C-ABI
+// =====================================================================================================
+using namespace gcnpt;
+
+template <typename CT, typename IT, typename OT, bool BWD, int NTW, int KSMAX>
+static int launch_rowtile_cfg(hipStream_t s, const RowTileParams& p) {
+    const int stride = lds_stride_dw(p.Kpad * (int)sizeof(CT) / 4) * 4 / (int)sizeof(CT);
+    const int ncols_pass = RT_WAVES * NTW * 16;
+    const int ostride = out_stride_dw(std::min(round_up(p.NOUT, 16), ncols_pass) * (int)sizeof(OT) / 4) * 4 / (int)sizeof(OT);
+    const size_t lds = (size_t)(BWD ? 2 : 1) * ROWS * stride * sizeof(CT) + (size_t)ROWS * ostride * sizeof(OT) +
+                       (size_t)ROWS * (3 + NB_INLINE) * sizeof(int);
+    if (lds > 160 * 1024) return fail(GCNPT_E_UNSUPPORTED, "layer: K=%d needs %zu B of LDS per workgroup", p.K, lds);
+    auto kern = rowtile_kernel<CT, IT, OT, BWD, NTW, KSMAX>;
+    if (lds > 64 * 1024)
+        GCNPT_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(ceil_div(p.N, ROWS)), dim3(RT_THREADS), lds, s, p);
+    GCNPT_HIP_CHECK(hipGetLastError());
+    return GCNPT_OK;
+}
+
+// output tiles per wave: the smallest of {2,3,4} that covers NOUT in one pass (8 waves x NTW x 16 columns),
+// with as many K-steps of weight fragments resident in registers as ~128 VGPRs allow
+template <typename CT, typename IT, typename OT, bool BWD>
+static int launch_rowtile(hipStream_t s, const RowTileParams& p) {
+    const int n_tiles = ceil_div(p.NOUT, 16);
+    if (n_tiles <= RT_WAVES * 2) return launch_rowtile_cfg<CT, IT, OT, BWD, 2, 16>(s, p);
+    if (n_tiles <= RT_WAVES * 3) return launch_rowtile_cfg<CT, IT, OT, BWD, 3, 10>(s, p);
+    return launch_rowtile_cfg<CT, IT, OT, BWD, 4, 8>(s, p);
+}
+
+template <bool BWD>
+static int dispatch_rowtile(hipStream_t s, const RowTileParams& p, int in_dtype, int out_dtype, int compute) {
+    if (compute == GCNPT_F32) {
+        if (in_dtype != GCNPT_F32 || out_dtype != GCNPT_F32)
+            return fail(GCNPT_E_UNSUPPORTED, "compute_dtype f32 needs f32 activations");
+        return launch_rowtile<float, float, float, BWD>(s, p);
+    }
+    if (in_dtype == GCNPT_F32 && out_dtype == GCNPT_F32) return launch_rowtile<bf16_t, float, float, BWD>(s, p);
+    if (in_dtype == GCNPT_F32 && out_dtype == GCNPT_BF16) return launch_rowtile<bf16_t, float, bf16_t, BWD>(s, p);
+    if (in_dtype == GCNPT_BF16 && out_dtype == GCNPT_F32) return launch_rowtile<bf16_t, bf16_t, float, BWD>(s, p);
+    return launch_rowtile<bf16_t, bf16_t, bf16_t, BWD>(s, p);
+}
+
+extern "C" int gcnpt_layer_fwd(void* stream, const void* h, int h_dtype, const void* w_fwd, const float* bias,
+                               const int32_t* row_ptr, const int32_t* col_idx, const int32_t* deg_row_ptr, int B, int T,
+                               int Din, int H, void* out, int out_dtype, int compute_dtype, float drop_p, uint64_t seed,
+                               void* s_frag) {
+    GCNPT_REQUIRE(h && w_fwd && bias && row_ptr && col_idx && out, "layer_fwd: null pointer");
+    GCNPT_REQUIRE(B > 0 && T > 0 && Din > 0 && H > 0, "layer_fwd: sizes must be positive");
+    GCNPT_REQUIRE(dtype_ok(h_dtype) && dtype_ok(out_dtype) && dtype_ok(compute_dtype), "layer_fwd: bad dtype");
+    GCNPT_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "layer_fwd: drop_p=%f outside [0,1)", (double)drop_p);
+    if ((long long)B * T > 0x7fffffffLL / 2) return fail(GCNPT_E_UNSUPPORTED, "layer_fwd: B*T too large");
+    RowTileParams p{};
+    p.src = h; p.yref = nullptr; p.wfrag = w_fwd; p.bias = bias;
+    p.g_row_ptr = row_ptr; p.g_col_idx = col_idx; p.d_row_ptr = deg_row_ptr ? deg_row_ptr : row_ptr; p.out = out;
+    p.frag_out = s_frag;
+    p.N = B * T; p.T = T; p.K = Din; p.NOUT = H; p.Kpad = round_up(Din, kstep_of(compute_dtype));
+    p.vec_in = (Din % 8 == 0) && aligned16(h);
+    p.vec_out = ((H * esize(out_dtype)) % 16 == 0) && aligned16(out);
+    p.drop_p = drop_p; p.scale = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    p.drop_thresh24 = (unsigned)((double)drop_p * 16777216.0);
+    p.seed = seed;
+    return dispatch_rowtile<false>((hipStream_t)stream, p, h_dtype, out_dtype, compute_dtype);
+}
+
+extern "C" int gcnpt_layer_bwd_data(void* stream, const void* dY, const void* Y, int g_dtype, const void* w_bwd,
+                                    const int32_t* row_ptr, const int32_t* rowT_ptr, const int32_t* colT_idx, int B,
+                                    int T, int Din, int H, void* dh, int dh_dtype, int compute_dtype, float scale,
+                                    void* z_frag, float* zero_dW, float* zero_db) {
+    GCNPT_REQUIRE(dY && Y && w_bwd && row_ptr && rowT_ptr && colT_idx, "layer_bwd_data: null pointer");
+    GCNPT_REQUIRE(dh || z_frag, "layer_bwd_data: nothing to produce (dh and z_frag both NULL)");
+    GCNPT_REQUIRE(B > 0 && T > 0 && Din > 0 && H > 0, "layer_bwd_data: sizes must be positive");
+    GCNPT_REQUIRE(dtype_ok(g_dtype) && dtype_ok(dh_dtype) && dtype_ok(compute_dtype), "layer_bwd_data: bad dtype");
+    if ((long long)B * T > 0x7fffffffLL / 2) return fail(GCNPT_E_UNSUPPORTED, "layer_bwd_data: B*T too large");
+    RowTileParams p{};
+    p.src = dY; p.yref = Y; p.wfrag = w_bwd; p.bias = nullptr;
+    p.g_row_ptr = rowT_ptr; p.g_col_idx = colT_idx; p.d_row_ptr = row_ptr; p.out = dh;
+    p.frag_out = z_frag;
+    p.zero_a = zero_dW; p.zero_a_n = H * Din; p.zero_b = zero_db; p.zero_b_n = H;
+    p.N = B * T; p.T = T; p.K = H; p.NOUT = Din; p.Kpad = round_up(H, kstep_of(compute_dtype));
+    p.vec_in = (H % 8 == 0) && aligned16(dY) && aligned16(Y);
+    p.vec_out = dh && ((Din * esize(dh_dtype)) % 16 == 0) && aligned16(dh);
+    p.scale = scale; p.drop_p = 0.0f;
+    return dispatch_rowtile<true>((hipStream_t)stream, p, g_dtype, dh_dtype, compute_dtype);
+}

@@ -1,0 +1,235 @@
+// Weight-side kernels (gfx950): nn.Linear weights -> MFMA fragment order, and the weight/bias gradient
+// dW += dZ^T ((A+I) h), db += 2 sum dZ of reference model/gcn.py:270-271 (autograd).
+#include "layer_common.h"
+
+namespace gcnpt {
+
+constexpr int LAYER_THREADS = 256;
+
+// ---------------------------------------------------------------------------------------------------
+// nn.Linear weight [H,Din] fp32 -> MFMA B-operand fragments
+//   fragment (tile, kstep, lane) = 16 bytes:
+//     bf16: 8 values  B[k = 32 kstep + 8 (lane>>4) + j][n = 16 tile + (lane&15)],  j = 0..7
+//     f32 : 4 values  B[k = 16 kstep + 4 (lane>>4) + s][n = 16 tile + (lane&15)],  s = 0..3
+//   forward image : B[k][n] = W[n][k]  (n over H,   k over Din)
+//   backward image: B[k][n] = W[k][n]  (n over Din, k over H)
+// ---------------------------------------------------------------------------------------------------
+template <typename CT>
+__global__ void pack_weights_kernel(const float* __restrict__ W, int H, int Din, uint4* __restrict__ wf,
+                                    uint4* __restrict__ wb) {
+    constexpr int KSTEP = sizeof(CT) == 2 ? 32 : 16;
+    constexpr int PER = sizeof(CT) == 2 ? 8 : 4;
+    const int ksf = round_up(Din, KSTEP) / KSTEP, ntf = ceil_div(H, 16);
+    const int ksb = round_up(H, KSTEP) / KSTEP, ntb = ceil_div(Din, 16);
+    const long long nf = wf ? (long long)ntf * ksf * 64 : 0;
+    const long long nb = wb ? (long long)ntb * ksb * 64 : 0;
+    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < nf + nb;
+         id += (long long)gridDim.x * blockDim.x) {
+        const bool bwd = id >= nf;
+        const long long f = bwd ? id - nf : id;
+        const int ks_n = bwd ? ksb : ksf;
+        const int lane = (int)(f & 63);
+        const int ks = (int)((f >> 6) % ks_n), tl = (int)((f >> 6) / ks_n);
+        const int n = tl * 16 + (lane & 15);
+        const int kb = ks * KSTEP + (lane >> 4) * PER;
+        float v[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int k = kb + j;
+            float x = 0.0f;
+            if (!bwd) { if (n < H && k < Din) x = W[(size_t)n * Din + k]; }
+            else      { if (k < H && n < Din) x = W[(size_t)k * Din + n]; }
+            v[j] = x;
+        }
+        uint4 u;
+        if constexpr (sizeof(CT) == 2) {
+            u.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+            u.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+            u.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+            u.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+        } else {
+            u.x = __float_as_uint(v[0]); u.y = __float_as_uint(v[1]); u.z = __float_as_uint(v[2]); u.w = __float_as_uint(v[3]);
+        }
+        (bwd ? wb : wf)[f] = u;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward-weight: dW[H,Din] += dZ^T S,  db[H] += 2 sum_r dZ[r,:]      (S = (A+I) h)
+//
+// Both operands arrive as fragment images (include/gcnpt.h) written by the row-tile kernels, so every
+// operand fetch is one fully coalesced 1-KiB wave load straight into registers: no LDS, no transposes,
+// no CSR.  A workgroup owns a (4 x 3)-tile block of dW and one slice of the contraction (row) range;
+// its 4 waves take every 4th k-step of the slice, issue up to WG_KB k-steps of loads at once, and meet
+// in LDS at the end; the slices of different workgroups are combined with float atomics.
+// ---------------------------------------------------------------------------------------------------
+constexpr int WG_MT = 4, WG_NT = 3, WG_KB = 5;
+
+struct WeightGradParams {
+    const uint4* zf;     // fragment image of dZ  [m_tiles][nks][64]
+    const uint4* sf;     // fragment image of S   [n_tiles][nks][64]
+    float* dW; float* db;
+    int H, Din, m_tiles, n_tiles, nks, ks_per_wg;
+};
+
+template <typename CT>
+__device__ __forceinline__ float frag_sum(const uint4& u) {
+    if constexpr (sizeof(CT) == 2) {
+        return (__uint_as_float(u.x << 16) + __uint_as_float(u.x & 0xffff0000u)) + (__uint_as_float(u.y << 16) + __uint_as_float(u.y & 0xffff0000u)) +
+               (__uint_as_float(u.z << 16) + __uint_as_float(u.z & 0xffff0000u)) + (__uint_as_float(u.w << 16) + __uint_as_float(u.w & 0xffff0000u));
+    } else {
+        return (__uint_as_float(u.x) + __uint_as_float(u.y)) + (__uint_as_float(u.z) + __uint_as_float(u.w));
+    }
+}
+
+template <typename CT>
+__global__ __launch_bounds__(LAYER_THREADS) void weight_grad_kernel(const WeightGradParams p) {
+    __shared__ f32x4_t red[4][WG_MT * WG_NT][WAVE];        // 48 KiB: per-wave partial tiles
+    __shared__ float dbred[4][WG_MT][16];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * WG_MT, n0 = blockIdx.y * WG_NT;
+    const int ks_lo = blockIdx.z * p.ks_per_wg, ks_hi = min(p.nks, ks_lo + p.ks_per_wg);
+    const bool want_db = blockIdx.y == 0;
+
+    f32x4_t acc[WG_MT][WG_NT];
+    float dbp[WG_MT];
+#pragma unroll
+    for (int i = 0; i < WG_MT; ++i) {
+        dbp[i] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < WG_NT; ++j) acc[i][j] = (f32x4_t){0, 0, 0, 0};
+    }
+
+    for (int base = ks_lo + wave; base < ks_hi; base += 4 * WG_KB) {
+        uint4 a[WG_KB][WG_MT], b[WG_KB][WG_NT];
+#pragma unroll
+        for (int u = 0; u < WG_KB; ++u) {
+            const int ks = base + 4 * u;
+            if (ks < ks_hi) {
+#pragma unroll
+                for (int i = 0; i < WG_MT; ++i)
+                    if (m0 + i < p.m_tiles) a[u][i] = p.zf[((size_t)(m0 + i) * p.nks + ks) * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < WG_NT; ++j)
+                    if (n0 + j < p.n_tiles) b[u][j] = p.sf[((size_t)(n0 + j) * p.nks + ks) * 64 + lane];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < WG_KB; ++u) {
+            const int ks = base + 4 * u;
+            if (ks >= ks_hi) continue;
+#pragma unroll
+            for (int i = 0; i < WG_MT; ++i) {
+                if (m0 + i >= p.m_tiles) continue;
+                if (want_db) dbp[i] += frag_sum<CT>(a[u][i]);
+#pragma unroll
+                for (int j = 0; j < WG_NT; ++j) {
+                    if (n0 + j >= p.n_tiles) continue;
+                    if constexpr (sizeof(CT) == 2) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[u][i]),
+                                                                             __builtin_bit_cast(bf16x8_t, b[u][j]), acc[i][j], 0, 0, 0);
+                    } else {
+                        const f32x4_t af = __builtin_bit_cast(f32x4_t, a[u][i]), bf = __builtin_bit_cast(f32x4_t, b[u][j]);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], bf[s], acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // waves meet in LDS; wave w then owns tiles w, w+4, w+8 of the block
+#pragma unroll
+    for (int i = 0; i < WG_MT; ++i)
+#pragma unroll
+        for (int j = 0; j < WG_NT; ++j) red[wave][i * WG_NT + j][lane] = acc[i][j];
+    if (want_db) {
+#pragma unroll
+        for (int i = 0; i < WG_MT; ++i) {
+            float v = dbp[i];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (lane < 16) dbred[wave][i][lane] = v;
+        }
+    }
+    __syncthreads();
+    for (int tt = wave; tt < WG_MT * WG_NT; tt += 4) {
+        const int i = tt / WG_NT, j = tt - i * WG_NT;
+        if (m0 + i >= p.m_tiles || n0 + j >= p.n_tiles) continue;
+        const f32x4_t v = red[0][tt][lane] + red[1][tt][lane] + red[2][tt][lane] + red[3][tt][lane];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int m = (m0 + i) * 16 + (lane >> 4) * 4 + g;
+            const int n = (n0 + j) * 16 + (lane & 15);
+            if (m < p.H && n < p.Din) atomicAdd(p.dW + (size_t)m * p.Din + n, v[g]);
+        }
+    }
+    if (want_db && tid < WG_MT * 16) {
+        const int i = tid >> 4, c = tid & 15;
+        const int m = (m0 + i) * 16 + c;
+        if (m0 + i < p.m_tiles && m < p.H)
+            atomicAdd(p.db + m, 2.0f * (dbred[0][i][c] + dbred[1][i][c] + dbred[2][i][c] + dbred[3][i][c]));   // bias enters twice
+    }
+}
+
+}  // namespace gcnpt
+
+// =====================================================================================================
+// C-ABI
+// =====================================================================================================
+using namespace gcnpt;
+
+
+extern "C" size_t gcnpt_packed_bytes(int n_out, int k_in, int dtype) {
+    if (n_out <= 0 || k_in <= 0 || (dtype != GCNPT_F32 && dtype != GCNPT_BF16)) return 0;
+    const int ks = round_up(k_in, kstep_of(dtype)) / kstep_of(dtype);
+    return (size_t)ceil_div(n_out, 16) * ks * 64 * 16;
+}
+
+extern "C" int gcnpt_pack_weights(void* stream, const float* W, int H, int Din, int dtype, void* w_fwd, void* w_bwd) {
+    GCNPT_REQUIRE(W && (w_fwd || w_bwd), "pack_weights: null pointer");
+    GCNPT_REQUIRE(H > 0 && Din > 0, "pack_weights: H and Din must be positive");
+    GCNPT_REQUIRE(dtype == GCNPT_F32 || dtype == GCNPT_BF16, "pack_weights: dtype %d", dtype);
+    const size_t frags = (w_fwd ? gcnpt_packed_bytes(H, Din, dtype) : 0) / 16 + (w_bwd ? gcnpt_packed_bytes(Din, H, dtype) : 0) / 16;
+    const int grid = (int)((frags + 255) / 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GCNPT_BF16)
+        hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, W, H, Din, (uint4*)w_fwd, (uint4*)w_bwd);
+    else
+        hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(grid), dim3(256), 0, s, W, H, Din, (uint4*)w_fwd, (uint4*)w_bwd);
+    GCNPT_HIP_CHECK(hipGetLastError());
+    return GCNPT_OK;
+}
+
+extern "C" size_t gcnpt_frag_bytes(int rows, int width, int dtype) {
+    if (rows <= 0 || width <= 0 || !dtype_ok(dtype)) return 0;
+    const size_t ksteps = (size_t)ceil_div(rows, 32) * (dtype == GCNPT_BF16 ? 1 : 2);
+    return (size_t)ceil_div(width, 16) * ksteps * 64 * 16;
+}
+
+extern "C" int gcnpt_layer_bwd_weight(void* stream, const void* z_frag, const void* s_frag, int B, int T, int Din, int H,
+                                      float* dW, float* db, int compute_dtype) {
+    GCNPT_REQUIRE(z_frag && s_frag && dW && db, "layer_bwd_weight: null pointer");
+    GCNPT_REQUIRE(B > 0 && T > 0 && Din > 0 && H > 0, "layer_bwd_weight: sizes must be positive");
+    GCNPT_REQUIRE(dtype_ok(compute_dtype), "layer_bwd_weight: bad dtype");
+    WeightGradParams p{};
+    p.zf = static_cast<const uint4*>(z_frag); p.sf = static_cast<const uint4*>(s_frag);
+    p.dW = dW; p.db = db; p.H = H; p.Din = Din;
+    p.m_tiles = ceil_div(H, 16); p.n_tiles = ceil_div(Din, 16);
+    p.nks = ceil_div(B * T, 32) * (compute_dtype == GCNPT_BF16 ? 1 : 2);
+    const int mb = ceil_div(p.m_tiles, WG_MT), nb = ceil_div(p.n_tiles, WG_NT);
+    // one workgroup per CU: split the contraction so that blocks x slices ~ 256, at least one k-step per wave
+    int slices = std::max(1, std::min(ceil_div(p.nks, 4), ceil_div(256, mb * nb)));
+    p.ks_per_wg = ceil_div(p.nks, slices);
+    slices = ceil_div(p.nks, p.ks_per_wg);
+    const dim3 grid(mb, nb, slices);
+    hipStream_t s = (hipStream_t)stream;
+    if (compute_dtype == GCNPT_BF16)
+        hipLaunchKernelGGL(weight_grad_kernel<bf16_t>, grid, dim3(LAYER_THREADS), 0, s, p);
+    else
+        hipLaunchKernelGGL(weight_grad_kernel<float>, grid, dim3(LAYER_THREADS), 0, s, p);
+    GCNPT_HIP_CHECK(hipGetLastError());
+    return GCNPT_OK;
+}

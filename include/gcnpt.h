@@ -94,6 +94,16 @@ int gcnpt_csr_to_adj(void* stream, const int32_t* row_ptr, const int32_t* col_id
 size_t gcnpt_packed_bytes(int n_out, int k_in, int dtype);
 int gcnpt_pack_weights(void* stream, const float* W, int H, int Din, int dtype, void* w_fwd, void* w_bwd);
 
+/* ---- saved operands in MFMA fragment order ------------------------------------------------------------
+ * The weight gradient contracts over the ROW index, so its MFMA operands need 8 consecutive rows per lane.
+ * Instead of transposing later, the forward kernel saves its gathered tile S = (A+I) h, and backward-data its
+ * dZ tile, already in that order ("fragment image"):
+ *   image[tile t][k-step ks][lane l] = 16 bytes
+ *     bf16: 8 values X[32 ks + 8 (l>>4) + j][16 t + (l&15)], j = 0..7        (rows >= B*T and columns >= width are 0)
+ *     f32 : 4 values X[16 ks + 4 (l>>4) + s][16 t + (l&15)], s = 0..3
+ * gcnpt_frag_bytes(rows, width, dtype) is the size of one image. */
+size_t gcnpt_frag_bytes(int rows, int width, int dtype);
+
 /* ---- A6: one GCN layer, model/gcn.py:269-271 + 390-393 --------------------------------------------------
  *   out[r,:] = dropout( relu( ( (sum_{c in row r} h[c,:] + h[r,:]) . W^T + 2 b ) / (deg[r] + 1) ) )
  * h [dev] [B*T, Din] of h_dtype; out [dev] [B*T, H] of out_dtype; bias [dev] float32 [H].
@@ -102,26 +112,31 @@ int gcnpt_pack_weights(void* stream, const float* W, int H, int Din, int dtype, 
  * drop_p in [0,1): 0 disables dropout (eval mode / last layer, gcn.py:393); otherwise element e of the
  * output is kept iff hash(seed, e) >= drop_p and scaled by 1/(1-drop_p).
  * deg_row_ptr: NULL, or the row_ptr whose row lengths give deg when the aggregated pattern differs from it
- * (the `no_adj` ablation, gcn.py:264-265: denominators from the real adjacency, aggregation over an empty one). */
+ * (the `no_adj` ablation, gcn.py:264-265: denominators from the real adjacency, aggregation over an empty one).
+ * s_frag: NULL (inference), or gcnpt_frag_bytes(B*T, Din, compute_dtype) bytes that receive the fragment image
+ * of S = (A+I) h for gcnpt_layer_bwd_weight. */
 int gcnpt_layer_fwd(void* stream, const void* h, int h_dtype, const void* w_fwd, const float* bias,
                     const int32_t* row_ptr, const int32_t* col_idx, const int32_t* deg_row_ptr, int B, int T,
-                    int Din, int H, void* out, int out_dtype, int compute_dtype, float drop_p, uint64_t seed);
+                    int Din, int H, void* out, int out_dtype, int compute_dtype, float drop_p, uint64_t seed,
+                    void* s_frag);
 
 /* ---- A7: autograd of A6 -----------------------------------------------------------------------------------
  * With dZ[r,:] = dY[r,:] * 1[Y[r,:] > 0] * scale / (deg[r] + 1)   (Y = the layer's stored output, which
  * already carries the dropout zeros; scale = 1/(1-drop_p)):
  *   data   : dh[r,:]  = (sum_{c in rowT r} dZ[c,:] + dZ[r,:]) . W                  -> [B*T, Din] of dh_dtype
- *   weight : dW      += dZ^T ((A+I) h)   [H,Din] float32,   db += 2 * sum_r dZ[r,:]  [H] float32
- * dY and Y share g_dtype.  row_ptr/col_idx are the forward pattern (degrees, (A+I)h), rowT_* the transposed one
- * (for bwd_data `row_ptr` is only read for the degrees; bwd_weight takes deg_row_ptr as gcnpt_layer_fwd does).
- * gcnpt_layer_bwd_weight ACCUMULATES into dW/db with float atomics: zero them first (or pass zero_first = 1,
- * which enqueues the memsets on `stream`). */
+ *   weight : dW       = dZ^T ((A+I) h)   [H,Din] float32,   db = 2 * sum_r dZ[r,:]  [H] float32
+ * gcnpt_layer_bwd_data: dY and Y share g_dtype; row_ptr is the forward pattern (degrees), rowT_* the transposed
+ * one.  dh may be NULL (input needs no gradient).  z_frag: NULL or gcnpt_frag_bytes(B*T, H, compute_dtype) bytes
+ * receiving the fragment image of dZ; zero_dW [H*Din] / zero_db [H]: NULL or the accumulators the FOLLOWING
+ * gcnpt_layer_bwd_weight adds into, cleared here so that no separate memset is needed.
+ * gcnpt_layer_bwd_weight: streams the two fragment images (z_frag from bwd_data, s_frag from fwd) and adds the
+ * K-slices into dW/db with float atomics; dW/db must be zero on entry (see zero_dW/zero_db above). */
 int gcnpt_layer_bwd_data(void* stream, const void* dY, const void* Y, int g_dtype, const void* w_bwd,
                          const int32_t* row_ptr, const int32_t* rowT_ptr, const int32_t* colT_idx, int B, int T,
-                         int Din, int H, void* dh, int dh_dtype, int compute_dtype, float scale);
-int gcnpt_layer_bwd_weight(void* stream, const void* dY, const void* Y, int g_dtype, const void* h, int h_dtype,
-                           const int32_t* row_ptr, const int32_t* col_idx, const int32_t* deg_row_ptr, int B, int T,
-                           int Din, int H, float* dW, float* db, int compute_dtype, float scale, int zero_first);
+                         int Din, int H, void* dh, int dh_dtype, int compute_dtype, float scale, void* z_frag,
+                         float* zero_dW, float* zero_db);
+int gcnpt_layer_bwd_weight(void* stream, const void* z_frag, const void* s_frag, int B, int T, int Din, int H,
+                           float* dW, float* db, int compute_dtype);
 
 #ifdef __cplusplus
 }

@@ -10,6 +10,31 @@ namespace gcnpt {
 
 // ---- error reporting across the C boundary (no exceptions leave the library) -------------------
 char* err_buf();   // thread-local, defined in capi.hip
+extern int g_debug_knob;      // diagnostic builds: timing-experiment switches (results become wrong)
+extern void* g_debug_stamps;   // diagnostic builds (-DGCNPT_STAMPS): device buffer for in-kernel time stamps
+
+#ifdef GCNPT_STAMPS
+// one stamp = shader-clock counter of wave 0 / lane 0 of the workgroup; slot 15 = 100 MHz real time at entry
+#define GCNPT_STAMP(buf, slot)                                                                           \
+    do {                                                                                                 \
+        if ((buf) && threadIdx.x == 0) {                                                                 \
+            unsigned long long _t;                                                                       \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                  \
+            (buf)[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 16 + (slot)] = _t; \
+        }                                                                                                \
+    } while (0)
+#define GCNPT_STAMP_REAL(buf)                                                                            \
+    do {                                                                                                 \
+        if ((buf) && threadIdx.x == 0) {                                                                 \
+            unsigned long long _t;                                                                       \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");              \
+            (buf)[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 16 + 15] = _t; \
+        }                                                                                                \
+    } while (0)
+#else
+#define GCNPT_STAMP(buf, slot) do {} while (0)
+#define GCNPT_STAMP_REAL(buf) do {} while (0)
+#endif
 int fail(int code, const char* fmt, ...);
 
 #define GCNPT_HIP_CHECK(expr)                                                                  \

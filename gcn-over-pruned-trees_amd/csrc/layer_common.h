@@ -1,6 +1,7 @@
 // Helpers shared by the layer kernels (gfx950): typed 8-element loads, LDS tile stores, dropout hash.
 #pragma once
 #include <algorithm>
+#include <type_traits>
 
 #include "gcnpt_common.h"
 
@@ -72,15 +73,25 @@ __host__ __device__ inline int lds_stride_dw(int payload_dw) {
     return s;
 }
 
-// counter-based dropout decision for output element e: uniform 24-bit value from (seed, e)
-__device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t e, unsigned thresh24) {
-    unsigned x = (unsigned)e ^ (unsigned)seed;
-    unsigned y = (unsigned)(e >> 32) ^ (unsigned)(seed >> 32) ^ 0x9E3779B9u;
-    x *= 0x85EBCA6Bu; x ^= x >> 15; x += y * 0xC2B2AE35u;
+// counter-based dropout: one 32-bit hash of (seed, row pair, column) decides the two rows of the pair with
+// 16 bits each, so the mask is a pure function of (seed, row, col) whatever the kernel's tiling is
+__device__ __forceinline__ unsigned drop_hash(uint64_t seed, unsigned row_pair, unsigned col) {
+    unsigned x = row_pair * 0x9E3779B1u + col * 0x85EBCA77u + (unsigned)seed;
     x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-    return (x >> 8) >= thresh24;
+    x += (unsigned)(seed >> 32) * 0xC2B2AE3Du;
+    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12;
+    return x;
+}
+__device__ __forceinline__ bool drop_keep(unsigned hash, unsigned row, unsigned thresh16) {
+    return ((row & 1u) ? (hash >> 16) : (hash & 0xffffu)) >= thresh16;
 }
 
+// v / d for d = deg + 1 given r = 1/d: one Newton step on the quotient gives the correctly rounded result
+// in all but rare half-ulp cases (<= 1 ulp then), at 3 FMAs instead of a full IEEE division sequence
+__device__ __forceinline__ float div_by(float v, float d, float r) {
+    const float q = v * r;
+    return __builtin_fmaf(__builtin_fmaf(-q, d, v), r, q);
+}
 
 // host-side argument helpers of the C-ABI wrappers
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

@@ -22,7 +22,7 @@ namespace gcnpt {
 constexpr int ROWS = 32;             // token rows per workgroup (two 16-row MFMA tiles)
 constexpr int RT_THREADS = 512;      // 8 waves; wave w owns output tiles w, w+8, ...
 constexpr int RT_WAVES = RT_THREADS / WAVE;
-constexpr int NB_INLINE = 4;         // neighbours per row staged in LDS next to the extents
+constexpr int NB_INLINE = 8;         // neighbours per row staged in LDS next to the extents
 
 struct RowTileParams {
     const void* src;        // fwd: h [N,K]      bwd: dY [N,K]
@@ -38,25 +38,34 @@ struct RowTileParams {
     float* zero_b;
     int zero_a_n, zero_b_n;
     int N, T, K, NOUT, Kpad;
-    int vec_in, vec_out;    // rows may be read / written 16 bytes at a time
+    int vec_in, vec_out;    // rows may be read / written 16 bytes at a time (vec_in selects the VEC instantiation)
     float scale;            // bwd: 1/(1-p) of the dropout applied to Y; fwd: 1/(1-drop_p)
     float drop_p;           // fwd
-    unsigned drop_thresh24;
+    unsigned drop_thresh16;
     uint64_t seed;
+    unsigned long long* stamps;   // diagnostic builds only
+    int knob;
 };
 
 template <typename IT> struct raw8 { uint4 a, b; };      // 8 elements as loaded (bf16: a only)
 
-template <typename IT>
-__device__ __forceinline__ void issue8(const IT* base, size_t row, int K, int k0, bool vec, raw8<IT>& r) {
-    const IT* p = base + row * (size_t)K + k0;
-    if (vec && k0 + 8 <= K) {
+// 8 elements of row `row` from column k0.  NO load here is behind a condition: hipcc puts every conditional
+// load in its own basic block with an s_waitcnt vmcnt(0) in front, which turns a batch of loads into a chain
+// of round trips.  Callers pass a (row, k0) that is valid memory (clamped) and zero the result if it was not wanted.
+template <typename IT, bool VEC>
+__device__ __forceinline__ void issue8(const IT* base, size_t row, int K, int k0, raw8<IT>& r) {
+    if constexpr (VEC) {                                    // K % 8 == 0, 16-byte aligned base, k0 + 8 <= K
+        const IT* p = base + row * (size_t)K + k0;
         r.a = *reinterpret_cast<const uint4*>(p);
         if constexpr (sizeof(IT) == 4) r.b = *reinterpret_cast<const uint4*>(p + 4);
-    } else {                                             // ragged tail / unaligned: element loads
+    } else {                                                // any K / alignment: 8 clamped element loads
+        const IT* p = base + row * (size_t)K;
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (k0 + j < K) ? io<IT>::load1(p + j) : 0.0f;
+        for (int j = 0; j < 8; ++j) {
+            const float x = io<IT>::load1(p + min(k0 + j, K - 1));
+            v[j] = (k0 + j < K) ? x : 0.0f;
+        }
         if constexpr (sizeof(IT) == 4) {
             r.a = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
             r.b = make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7]));
@@ -69,16 +78,20 @@ __device__ __forceinline__ void issue8(const IT* base, size_t row, int K, int k0
     }
 }
 
+// the 8 floats of a raw8, all zero when !live
 template <typename IT>
-__device__ __forceinline__ void unpack8(const raw8<IT>& r, float (&v)[8]) {
+__device__ __forceinline__ void unpack8(const raw8<IT>& r, bool live, float (&v)[8]) {
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    const uint4 a = live ? r.a : z;
     if constexpr (sizeof(IT) == 4) {
-        v[0] = __uint_as_float(r.a.x); v[1] = __uint_as_float(r.a.y); v[2] = __uint_as_float(r.a.z); v[3] = __uint_as_float(r.a.w);
-        v[4] = __uint_as_float(r.b.x); v[5] = __uint_as_float(r.b.y); v[6] = __uint_as_float(r.b.z); v[7] = __uint_as_float(r.b.w);
+        const uint4 b = live ? r.b : z;
+        v[0] = __uint_as_float(a.x); v[1] = __uint_as_float(a.y); v[2] = __uint_as_float(a.z); v[3] = __uint_as_float(a.w);
+        v[4] = __uint_as_float(b.x); v[5] = __uint_as_float(b.y); v[6] = __uint_as_float(b.z); v[7] = __uint_as_float(b.w);
     } else {
-        v[0] = __uint_as_float(r.a.x << 16); v[1] = __uint_as_float(r.a.x & 0xffff0000u);
-        v[2] = __uint_as_float(r.a.y << 16); v[3] = __uint_as_float(r.a.y & 0xffff0000u);
-        v[4] = __uint_as_float(r.a.z << 16); v[5] = __uint_as_float(r.a.z & 0xffff0000u);
-        v[6] = __uint_as_float(r.a.w << 16); v[7] = __uint_as_float(r.a.w & 0xffff0000u);
+        v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+        v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+        v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
+        v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
     }
 }
 
@@ -90,13 +103,13 @@ __host__ __device__ inline int out_stride_dw(int payload_dw) {
     return s;
 }
 
-template <typename CT, typename IT, typename OT, bool BWD, int NTW, int KSMAX>
+template <typename CT, typename IT, typename OT, bool BWD, bool VEC, int NTW, int KSMAX>
 __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTileParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int KSTEP = sizeof(CT) == 2 ? 32 : 16;            // K consumed per fragment
     constexpr bool WIDE = BWD && sizeof(IT) == 4;               // two fp32 streams per row: fewer rows in flight per thread
     constexpr int ITEMS = WIDE ? 2 : 3;                         // 8-element chunks a thread gathers per batch
-    constexpr int NBU = WIDE ? 2 : NB_INLINE;                   // neighbour rows fetched together
+    constexpr int NBU = WIDE ? 2 : 4;                           // neighbour rows fetched together
     const int stride = lds_stride_dw(p.Kpad * (int)sizeof(CT) / 4) * 4 / (int)sizeof(CT);     // S row stride, CT elements
     const int ncols_pass = RT_WAVES * NTW * 16;
     const int ostride = out_stride_dw(min(round_up(p.NOUT, 16), ncols_pass) * (int)sizeof(OT) / 4) * 4 / (int)sizeof(OT);
@@ -107,8 +120,9 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
     int* meta = reinterpret_cast<int*>(smem_raw + (BWD ? 2 : 1) * s_bytes + (size_t)ROWS * ostride * sizeof(OT));
     int* rbeg = meta;                         // [ROWS]
     int* rend = meta + ROWS;                  // [ROWS]
-    float* rinv = reinterpret_cast<float*>(meta + 2 * ROWS);   // [ROWS] fwd: deg+1   bwd: scale/(deg+1)
-    int* rnbr = meta + 3 * ROWS;              // [ROWS][NB_INLINE] absolute neighbour rows
+    float* rinv = reinterpret_cast<float*>(meta + 2 * ROWS);   // [ROWS] fwd: 1/(deg+1)   bwd: scale/(deg+1)
+    float* rden = reinterpret_cast<float*>(meta + 3 * ROWS);   // [ROWS] deg+1
+    int* rnbr = meta + 4 * ROWS;              // [ROWS][NB_INLINE] absolute neighbour rows
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = blockIdx.x * ROWS;
@@ -117,55 +131,72 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
     const uint4* wfrag = static_cast<const uint4*>(p.wfrag);
     const int n_tiles = ceil_div(p.NOUT, 16);
     const int ksteps = p.Kpad / KSTEP;
+    GCNPT_STAMP_REAL(p.stamps);
+    GCNPT_STAMP(p.stamps, 0);
 
-    // (0) weight fragments of the first pass / first K chunk: issued before anything else
-    uint4 wreg[KSMAX][NTW];
-    auto load_w = [&](int pass, int kc0) {
-#pragma unroll
-        for (int ks = 0; ks < KSMAX; ++ks)
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) {
-                const int tl = pass * RT_WAVES * NTW + j * RT_WAVES + wave;
-                if (kc0 + ks < ksteps && tl < n_tiles) wreg[ks][j] = wfrag[((size_t)tl * ksteps + kc0 + ks) * 64 + lane];
-            }
-    };
-    if (p.out) load_w(0, 0);
-
-    // (1) row metadata -> LDS (32 lanes), own-row loads of the first batch (everyone)
+    // (1) row metadata -> LDS (32 lanes of wave 0).  Loads return in issue order per wave, so this
+    //     latency-critical chain (extents -> first neighbours) goes out before the bulk loads.
     if (tid < ROWS) {
-        const int r = r0 + tid;
-        int beg = 0, end = 0;
-        float dn = 1.0f;
-        if (r < p.N) {
-            const int b = r / p.T, i = r - b * p.T;
-            const size_t q = (size_t)b * (p.T + 1) + i;
-            beg = p.g_row_ptr[q]; end = p.g_row_ptr[q + 1];
-            dn = (float)(p.d_row_ptr[q + 1] - p.d_row_ptr[q] + 1);          // gcn.py:261
+        const int r = min(r0 + tid, p.N - 1);
+        const int b = r / p.T, i = r - b * p.T;
+        const size_t q = (size_t)b * (p.T + 1) + i;
+        int beg = p.g_row_ptr[q], end = p.g_row_ptr[q + 1];
+        const float dn = (float)(p.d_row_ptr[q + 1] - p.d_row_ptr[q] + 1);          // gcn.py:261
+        if (r0 + tid >= p.N) end = beg;
+        const int safe = end > beg ? end - 1 : 0;                 // some valid entry for the lanes past the row's end
 #pragma unroll
-            for (int e = 0; e < NB_INLINE; ++e)
-                rnbr[tid * NB_INLINE + e] = (beg + e < end) ? b * p.T + p.g_col_idx[beg + e] : 0;
-        }
+        for (int e = 0; e < NB_INLINE; ++e)
+            rnbr[tid * NB_INLINE + e] = b * p.T + p.g_col_idx[beg + e < end ? beg + e : safe];
         rbeg[tid] = beg; rend[tid] = end;
-        rinv[tid] = BWD ? p.scale / dn : dn;
+        rinv[tid] = (BWD ? p.scale : 1.0f) / dn;
+        rden[tid] = dn;
     }
+
+    // own rows of the first batch (everyone), then (0): this wave's weight fragments, all of them
     const int nchunk = p.Kpad / 8;
     const int n_items = ROWS * nchunk;
-
+    const int kmax8 = VEC ? p.K - 8 : p.K - 1;
     raw8<IT> self[ITEMS], selfy[ITEMS];
     auto issue_self = [&](int batch) {
 #pragma unroll
         for (int u = 0; u < ITEMS; ++u) {
             const int it = (batch * ITEMS + u) * RT_THREADS + tid;
             const int row = it / nchunk, k0 = (it - row * nchunk) * 8;
-            const int r = r0 + row;
-            if (it < n_items && r < p.N && k0 < p.K) {
-                issue8<IT>(src, (size_t)r, p.K, k0, p.vec_in, self[u]);
-                if (BWD) issue8<IT>(yref, (size_t)r, p.K, k0, p.vec_in, selfy[u]);
-            }
+            const size_t r = (size_t)min(r0 + row, p.N - 1);
+            issue8<IT, VEC>(src, r, p.K, min(k0, kmax8), self[u]);
+            if (BWD) issue8<IT, VEC>(yref, r, p.K, min(k0, kmax8), selfy[u]);
         }
     };
     issue_self(0);
+
+    uint4 wreg[KSMAX][NTW];
+    auto load_w = [&](int pass, int kc0) {
+#pragma unroll
+        for (int ks = 0; ks < KSMAX; ++ks)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                const int tl = min(pass * RT_WAVES * NTW + j * RT_WAVES + wave, n_tiles - 1);
+                const int kk = min(kc0 + ks, ksteps - 1);
+#ifdef GCNPT_STAMPS
+                if (p.knob & 1) { wreg[ks][j] = wfrag[lane]; continue; }          // experiment: no weight traffic
+#endif
+                wreg[ks][j] = wfrag[((size_t)tl * ksteps + kk) * 64 + lane];
+            }
+    };
+    float bias2[NTW];                                          // fwd epilogue operand, fetched now, used last
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) bias2[j] = 0.0f;
+    if (p.out) {
+        load_w(0, 0);                                          // 156 KB per workgroup at Din=360, H=200
+        if constexpr (!BWD) {
+#pragma unroll
+            for (int j = 0; j < NTW; ++j)
+                bias2[j] = 2.0f * p.bias[min((j * RT_WAVES + wave) * 16 + (lane & 15), p.NOUT - 1)];   // enters twice, gcn.py:270-271
+        }
+    }
+    GCNPT_STAMP(p.stamps, 1);
     __syncthreads();
+    GCNPT_STAMP(p.stamps, 2);
 
     // (2) finish the gather batch by batch: S[row,:] = x[row,:] + sum_{c in pattern row} x[c,:]
     const int n_batches = ceil_div(n_items, ITEMS * RT_THREADS);
@@ -177,59 +208,65 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
             if (it >= n_items) continue;
             const int row = it / nchunk, k0 = (it - row * nchunk) * 8;
             const int r = r0 + row;
-            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (r < p.N && k0 < p.K) {
-                unpack8<IT>(self[u], acc);                              // the explicit W(h) term, gcn.py:271
-                if (BWD) {
-                    float y[8];
-                    unpack8<IT>(selfy[u], y);
-                    const float inv = rinv[row];
+            const bool live = r < p.N && k0 < p.K;
+            const int k0c = min(k0, kmax8);
+            float acc[8];
+            unpack8<IT>(self[u], live, acc);                            // the explicit W(h) term, gcn.py:271
+            if (BWD) {
+                float y[8];
+                unpack8<IT>(selfy[u], live, y);
+                const float inv = rinv[row];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[j] = (y[j] > 0.0f) ? acc[j] * inv : 0.0f;
-                }
+                for (int j = 0; j < 8; ++j) acc[j] = (y[j] > 0.0f) ? acc[j] * inv : 0.0f;
+                if (p.frag_out) tile<CT>::put8(Z + (size_t)row * stride + k0, acc);
             }
-            if (BWD && p.frag_out) tile<CT>::put8(Z + (size_t)row * stride + k0, acc);
-            if (p.out && r < p.N && k0 < p.K) {
-                const int beg = rbeg[row], n = rend[row] - beg;
-                for (int e0 = 0; e0 < n; e0 += NBU) {                   // gcn.py:269, <= 3 neighbours for a pruned tree
-                    raw8<IT> nb[NBU], nby[NBU];
-                    float ninv[NBU];
+            const int beg = rbeg[row];
+            const int n = (live && p.out) ? rend[row] - beg : 0;
+            const size_t rc = (size_t)min(r, p.N - 1);
+            // gcn.py:269: <= 3 neighbours per kept token of a pruned tree.  The first NB_INLINE come from LDS, the
+            // (rare) rest from col_idx; lanes without an e-th neighbour load their own row and drop it.
+            auto round = [&](int e0, auto from_lds) {
+                raw8<IT> nb[NBU], nby[NBU];
+                float ninv[NBU];
 #pragma unroll
-                    for (int e = 0; e < NBU; ++e) {
-                        if (e0 + e < n) {
-                            const int c = (e0 + e < NB_INLINE) ? rnbr[row * NB_INLINE + e0 + e]
-                                                               : (r / p.T) * p.T + p.g_col_idx[beg + e0 + e];
-                            issue8<IT>(src, (size_t)c, p.K, k0, p.vec_in, nb[e]);
-                            if (BWD) {
-                                issue8<IT>(yref, (size_t)c, p.K, k0, p.vec_in, nby[e]);
-                                const int cb = c / p.T;
-                                const size_t q = (size_t)cb * (p.T + 1) + (c - cb * p.T);
-                                ninv[e] = p.scale / (float)(p.d_row_ptr[q + 1] - p.d_row_ptr[q] + 1);
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int e = 0; e < NBU; ++e) {
-                        if (e0 + e < n) {
-                            float v[8];
-                            unpack8<IT>(nb[e], v);
-                            if (BWD) {
-                                float y[8];
-                                unpack8<IT>(nby[e], y);
-#pragma unroll
-                                for (int j = 0; j < 8; ++j) acc[j] += (y[j] > 0.0f) ? v[j] * ninv[e] : 0.0f;
-                            } else {
-#pragma unroll
-                                for (int j = 0; j < 8; ++j) acc[j] += v[j];
-                            }
-                        }
+                for (int e = 0; e < NBU; ++e) {
+                    const bool on = e0 + e < n;
+                    size_t c;
+                    if constexpr (decltype(from_lds)::value) c = (size_t)rnbr[row * NB_INLINE + min(e0 + e, NB_INLINE - 1)];
+                    else c = (size_t)((r / p.T) * p.T + p.g_col_idx[on ? beg + e0 + e : beg]);
+                    c = on ? c : rc;
+                    issue8<IT, VEC>(src, c, p.K, k0c, nb[e]);
+                    if (BWD) {
+                        issue8<IT, VEC>(yref, c, p.K, k0c, nby[e]);
+                        const int cb = (int)(c / p.T);
+                        const size_t q = (size_t)cb * (p.T + 1) + (c - (size_t)cb * p.T);
+                        ninv[e] = p.scale / (float)(p.d_row_ptr[q + 1] - p.d_row_ptr[q] + 1);
                     }
                 }
-            }
+#pragma unroll
+                for (int e = 0; e < NBU; ++e) {
+                    const bool on = e0 + e < n;
+                    float v[8];
+                    unpack8<IT>(nb[e], on, v);
+                    if (BWD) {
+                        float y[8];
+                        unpack8<IT>(nby[e], on, y);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[j] += (y[j] > 0.0f) ? v[j] * ninv[e] : 0.0f;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[j] += v[j];
+                    }
+                }
+            };
+            for (int e0 = 0; e0 < min(n, NB_INLINE); e0 += NBU) round(e0, std::true_type{});
+            for (int e0 = NB_INLINE; e0 < n; e0 += NBU) round(e0, std::false_type{});
             tile<CT>::put8(S + (size_t)row * stride + k0, acc);
         }
     }
+    GCNPT_STAMP(p.stamps, 3);
     __syncthreads();
+    GCNPT_STAMP(p.stamps, 4);
 
     // side outputs: the tile in MFMA fragment order for the weight gradient (rows are its contraction index),
     // and cleared accumulators for the kernel that follows
@@ -270,6 +307,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
         for (int i = blockIdx.x * RT_THREADS + tid; i < p.zero_a_n; i += gridDim.x * RT_THREADS) p.zero_a[i] = 0.0f;
     if (p.zero_b)
         for (int i = blockIdx.x * RT_THREADS + tid; i < p.zero_b_n; i += gridDim.x * RT_THREADS) p.zero_b[i] = 0.0f;
+    GCNPT_STAMP(p.stamps, 5);
     if (!p.out) return;
 
     // (3) + (4)
@@ -285,28 +323,27 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
 
         for (int kc0 = 0; kc0 < ksteps; kc0 += KSMAX) {
             if (pass > 0 || kc0 > 0) load_w(pass, kc0);
+            // A fragments are read one k-step ahead of the MFMAs that use them
+            constexpr int AW = sizeof(CT) == 2 ? 8 : 4;                  // CT elements per lane per k-step (16 bytes)
+            uint4 a_cur[2], a_nxt[2];
+            auto read_a = [&](int kk, uint4 (&dst)[2]) {
+                dst[0] = *reinterpret_cast<const uint4*>(S + (size_t)arow * stride + kk * KSTEP + kgrp * AW);
+                dst[1] = *reinterpret_cast<const uint4*>(S + (size_t)(arow + 16) * stride + kk * KSTEP + kgrp * AW);
+            };
+            read_a(kc0, a_cur);
 #pragma unroll
             for (int ks = 0; ks < KSMAX; ++ks) {
-                if (kc0 + ks >= ksteps) continue;
-                const int kk = kc0 + ks;
-                if constexpr (sizeof(CT) == 2) {
-                    const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(S + (size_t)arow * stride + kk * 32 + kgrp * 8);
-                    const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(S + (size_t)(arow + 16) * stride + kk * 32 + kgrp * 8);
+                if (kc0 + ks < ksteps) {                                 // wave-uniform, no global load inside
+                    read_a(min(kc0 + ks + 1, ksteps - 1), a_nxt);
 #pragma unroll
                     for (int j = 0; j < NTW; ++j) {
-                        if (tile0 + j * RT_WAVES < n_tiles) {
+                        if constexpr (sizeof(CT) == 2) {
                             const bf16x8_t bq = __builtin_bit_cast(bf16x8_t, wreg[ks][j]);
-                            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bq, acc[0][j], 0, 0, 0);
-                            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bq, acc[1][j], 0, 0, 0);
-                        }
-                    }
-                } else {
-                    const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(S + (size_t)arow * stride + kk * 16 + kgrp * 4);
-                    const f32x4_t a1 = *reinterpret_cast<const f32x4_t*>(S + (size_t)(arow + 16) * stride + kk * 16 + kgrp * 4);
-#pragma unroll
-                    for (int j = 0; j < NTW; ++j) {
-                        if (tile0 + j * RT_WAVES < n_tiles) {
+                            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a_cur[0]), bq, acc[0][j], 0, 0, 0);
+                            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a_cur[1]), bq, acc[1][j], 0, 0, 0);
+                        } else {
                             const f32x4_t bq = __builtin_bit_cast(f32x4_t, wreg[ks][j]);
+                            const f32x4_t a0 = __builtin_bit_cast(f32x4_t, a_cur[0]), a1 = __builtin_bit_cast(f32x4_t, a_cur[1]);
 #pragma unroll
                             for (int s = 0; s < 4; ++s) {
                                 acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], bq[s], acc[0][j], 0, 0, 0);
@@ -314,11 +351,13 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
                             }
                         }
                     }
+                    a_cur[0] = a_nxt[0]; a_cur[1] = a_nxt[1];
                 }
             }
         }
 
-        // epilogue on the accumulators -> LDS out tile
+        GCNPT_STAMP(p.stamps, 6);
+        // epilogue on the accumulators -> LDS out tile (tiles past the last real one hold duplicates: not stored)
         if (pass > 0) __syncthreads();                                   // previous pass's rows have left O
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
@@ -326,19 +365,21 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
             if (tl >= n_tiles) continue;
             const int col = tl * 16 + (lane & 15);
             const int lcol = col - pass * ncols_pass;
-            const float b2 = (BWD || col >= p.NOUT) ? 0.0f : 2.0f * p.bias[col];   // bias enters twice, gcn.py:270-271
+            float b2 = 0.0f;
+            if constexpr (!BWD) b2 = pass == 0 ? bias2[j] : 2.0f * p.bias[min(col, p.NOUT - 1)];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
+                unsigned dh = 0;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int row = mt * 16 + (lane >> 4) * 4 + g;
+                    const int row = mt * 16 + (lane >> 4) * 4 + g;      // rows 4k..4k+3: (g, g+1) are a hash pair
                     float v = acc[mt][j][g];
                     if (!BWD) {
-                        v = (v + b2) / rinv[row];                        // gcn.py:390
+                        v = div_by(v + b2, rden[row], rinv[row]);        // gcn.py:390
                         v = v > 0.0f ? v : 0.0f;                         // gcn.py:392
                         if (p.drop_p > 0.0f) {                            // gcn.py:393
-                            const uint64_t e = (uint64_t)(r0 + row) * (uint64_t)p.NOUT + (uint64_t)col;
-                            v = drop_keep(p.seed, e, p.drop_thresh24) ? v * p.scale : 0.0f;
+                            if ((g & 1) == 0) dh = drop_hash(p.seed, (unsigned)(r0 + row) >> 1, (unsigned)col);
+                            v = drop_keep(dh, (unsigned)(r0 + row), p.drop_thresh16) ? v * p.scale : 0.0f;
                         }
                     }
                     io<OT>::store1(O + (size_t)row * ostride + lcol, v);
@@ -346,6 +387,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
             }
         }
         __syncthreads();
+        GCNPT_STAMP(p.stamps, 7);
 
         // whole rows leave in 16-byte pieces
         const int c_lo = pass * ncols_pass, c_hi = min(p.NOUT, c_lo + ncols_pass);
@@ -368,6 +410,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
             }
         }
     }
+    GCNPT_STAMP(p.stamps, 8);
 }
 
 }  // namespace gcnpt
@@ -377,15 +420,15 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
 // =====================================================================================================
 using namespace gcnpt;
 
-template <typename CT, typename IT, typename OT, bool BWD, int NTW, int KSMAX>
+template <typename CT, typename IT, typename OT, bool BWD, bool VEC, int NTW, int KSMAX>
 static int launch_rowtile_cfg(hipStream_t s, const RowTileParams& p) {
     const int stride = lds_stride_dw(p.Kpad * (int)sizeof(CT) / 4) * 4 / (int)sizeof(CT);
     const int ncols_pass = RT_WAVES * NTW * 16;
     const int ostride = out_stride_dw(std::min(round_up(p.NOUT, 16), ncols_pass) * (int)sizeof(OT) / 4) * 4 / (int)sizeof(OT);
     const size_t lds = (size_t)(BWD ? 2 : 1) * ROWS * stride * sizeof(CT) + (size_t)ROWS * ostride * sizeof(OT) +
-                       (size_t)ROWS * (3 + NB_INLINE) * sizeof(int);
+                       (size_t)ROWS * (4 + NB_INLINE) * sizeof(int);
     if (lds > 160 * 1024) return fail(GCNPT_E_UNSUPPORTED, "layer: K=%d needs %zu B of LDS per workgroup", p.K, lds);
-    auto kern = rowtile_kernel<CT, IT, OT, BWD, NTW, KSMAX>;
+    auto kern = rowtile_kernel<CT, IT, OT, BWD, VEC, NTW, KSMAX>;
     if (lds > 64 * 1024)
         GCNPT_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(ceil_div(p.N, ROWS)), dim3(RT_THREADS), lds, s, p);
@@ -394,13 +437,15 @@ static int launch_rowtile_cfg(hipStream_t s, const RowTileParams& p) {
 }
 
 // output tiles per wave: the smallest of {2,3,4} that covers NOUT in one pass (8 waves x NTW x 16 columns),
-// with as many K-steps of weight fragments resident in registers as ~128 VGPRs allow
+// with as many K-steps of weight fragments resident in registers as ~128 VGPRs allow.  Rows that cannot be
+// read 16 bytes at a time (width not a multiple of 8, unaligned base) take the element-load instantiation.
 template <typename CT, typename IT, typename OT, bool BWD>
 static int launch_rowtile(hipStream_t s, const RowTileParams& p) {
     const int n_tiles = ceil_div(p.NOUT, 16);
-    if (n_tiles <= RT_WAVES * 2) return launch_rowtile_cfg<CT, IT, OT, BWD, 2, 16>(s, p);
-    if (n_tiles <= RT_WAVES * 3) return launch_rowtile_cfg<CT, IT, OT, BWD, 3, 10>(s, p);
-    return launch_rowtile_cfg<CT, IT, OT, BWD, 4, 8>(s, p);
+    if (!p.vec_in) return launch_rowtile_cfg<CT, IT, OT, BWD, false, 4, 4>(s, p);
+    if (n_tiles <= RT_WAVES * 2) return launch_rowtile_cfg<CT, IT, OT, BWD, true, 2, 12>(s, p);
+    if (n_tiles <= RT_WAVES * 3) return launch_rowtile_cfg<CT, IT, OT, BWD, true, 3, 7>(s, p);
+    return launch_rowtile_cfg<CT, IT, OT, BWD, true, 4, 5>(s, p);
 }
 
 template <bool BWD>
@@ -426,6 +471,7 @@ extern "C" int gcnpt_layer_fwd(void* stream, const void* h, int h_dtype, const v
     GCNPT_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "layer_fwd: drop_p=%f outside [0,1)", (double)drop_p);
     if ((long long)B * T > 0x7fffffffLL / 2) return fail(GCNPT_E_UNSUPPORTED, "layer_fwd: B*T too large");
     RowTileParams p{};
+    p.stamps = static_cast<unsigned long long*>(g_debug_stamps); p.knob = g_debug_knob;
     p.src = h; p.yref = nullptr; p.wfrag = w_fwd; p.bias = bias;
     p.g_row_ptr = row_ptr; p.g_col_idx = col_idx; p.d_row_ptr = deg_row_ptr ? deg_row_ptr : row_ptr; p.out = out;
     p.frag_out = s_frag;
@@ -433,7 +479,7 @@ extern "C" int gcnpt_layer_fwd(void* stream, const void* h, int h_dtype, const v
     p.vec_in = (Din % 8 == 0) && aligned16(h);
     p.vec_out = ((H * esize(out_dtype)) % 16 == 0) && aligned16(out);
     p.drop_p = drop_p; p.scale = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
-    p.drop_thresh24 = (unsigned)((double)drop_p * 16777216.0);
+    p.drop_thresh16 = (unsigned)((double)drop_p * 65536.0);
     p.seed = seed;
     return dispatch_rowtile<false>((hipStream_t)stream, p, h_dtype, out_dtype, compute_dtype);
 }
@@ -448,6 +494,7 @@ extern "C" int gcnpt_layer_bwd_data(void* stream, const void* dY, const void* Y,
     GCNPT_REQUIRE(dtype_ok(g_dtype) && dtype_ok(dh_dtype) && dtype_ok(compute_dtype), "layer_bwd_data: bad dtype");
     if ((long long)B * T > 0x7fffffffLL / 2) return fail(GCNPT_E_UNSUPPORTED, "layer_bwd_data: B*T too large");
     RowTileParams p{};
+    p.stamps = static_cast<unsigned long long*>(g_debug_stamps); p.knob = g_debug_knob;
     p.src = dY; p.yref = Y; p.wfrag = w_bwd; p.bias = nullptr;
     p.g_row_ptr = rowT_ptr; p.g_col_idx = colT_idx; p.d_row_ptr = row_ptr; p.out = dh;
     p.frag_out = z_frag;

@@ -36,10 +36,10 @@ __global__ void pack_weights_kernel(const float* __restrict__ W, int H, int Din,
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
             const int k = kb + j;
-            float x = 0.0f;
-            if (!bwd) { if (n < H && k < Din) x = W[(size_t)n * Din + k]; }
-            else      { if (k < H && n < Din) x = W[(size_t)k * Din + n]; }
-            v[j] = x;
+            // unconditional clamped load + select (a conditional load would serialise the 8 of them)
+            const int rr = bwd ? k : n, cc = bwd ? n : k;
+            const float x = W[(size_t)min(rr, H - 1) * Din + min(cc, Din - 1)];
+            v[j] = (rr < H && cc < Din) ? x : 0.0f;
         }
         uint4 u;
         if constexpr (sizeof(CT) == 2) {
@@ -70,6 +70,9 @@ struct WeightGradParams {
     const uint4* sf;     // fragment image of S   [n_tiles][nks][64]
     float* dW; float* db;
     int H, Din, m_tiles, n_tiles, nks, ks_per_wg;
+    int mb, nb, slices;  // block grid; the launch grid is 1-D so that the block -> (m, n, slice) map can follow the XCDs
+    unsigned long long* stamps;   // diagnostic builds only
+    int knob;
 };
 
 template <typename CT>
@@ -88,9 +91,20 @@ __global__ __launch_bounds__(LAYER_THREADS) void weight_grad_kernel(const Weight
     __shared__ float dbred[4][WG_MT][16];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * WG_MT, n0 = blockIdx.y * WG_NT;
-    const int ks_lo = blockIdx.z * p.ks_per_wg, ks_hi = min(p.nks, ks_lo + p.ks_per_wg);
-    const bool want_db = blockIdx.y == 0;
+    // Workgroups are dealt round-robin over the 8 XCDs (id % 8 labels the XCD group), each with its own L2.
+    // All blocks of one contraction slice read the same rows of both images, so a slice is pinned to one
+    // XCD group: its rows cross the fabric once and every other read hits that XCD's L2.  (Speed only.)
+    const int id = blockIdx.x, xg = id & 7, rest = id >> 3;
+    int slice, blk;
+    if ((p.slices & 7) == 0) { const int sp = p.slices >> 3; slice = xg + 8 * (rest % sp); blk = rest / sp; }
+    else                     { const int gp = 8 / p.slices;  slice = xg % p.slices;       blk = rest * gp + xg / p.slices; }
+    if (blk >= p.mb * p.nb) return;
+    const int bm = blk % p.mb, bn = blk / p.mb;
+    const int m0 = bm * WG_MT, n0 = bn * WG_NT;
+    const int ks_lo = slice * p.ks_per_wg, ks_hi = min(p.nks, ks_lo + p.ks_per_wg);
+    const bool want_db = bn == 0;
+    GCNPT_STAMP_REAL(p.stamps);
+    GCNPT_STAMP(p.stamps, 0);
 
     f32x4_t acc[WG_MT][WG_NT];
     float dbp[WG_MT];
@@ -101,36 +115,36 @@ __global__ __launch_bounds__(LAYER_THREADS) void weight_grad_kernel(const Weight
         for (int j = 0; j < WG_NT; ++j) acc[i][j] = (f32x4_t){0, 0, 0, 0};
     }
 
+    // Every load below is unconditional (clamped indices): a load behind a runtime condition gets its own basic
+    // block and an s_waitcnt vmcnt(0) from hipcc, which would turn this batch into 35 serial round trips.
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
     for (int base = ks_lo + wave; base < ks_hi; base += 4 * WG_KB) {
         uint4 a[WG_KB][WG_MT], b[WG_KB][WG_NT];
 #pragma unroll
         for (int u = 0; u < WG_KB; ++u) {
-            const int ks = base + 4 * u;
-            if (ks < ks_hi) {
+            int ks = min(base + 4 * u, p.nks - 1);
+#ifdef GCNPT_STAMPS
+            if (p.knob & 2) ks = 0;                                       // experiment: every load hits the same lines
+#endif
 #pragma unroll
-                for (int i = 0; i < WG_MT; ++i)
-                    if (m0 + i < p.m_tiles) a[u][i] = p.zf[((size_t)(m0 + i) * p.nks + ks) * 64 + lane];
+            for (int i = 0; i < WG_MT; ++i) a[u][i] = p.zf[((size_t)min(m0 + i, p.m_tiles - 1) * p.nks + ks) * 64 + lane];
 #pragma unroll
-                for (int j = 0; j < WG_NT; ++j)
-                    if (n0 + j < p.n_tiles) b[u][j] = p.sf[((size_t)(n0 + j) * p.nks + ks) * 64 + lane];
-            }
+            for (int j = 0; j < WG_NT; ++j) b[u][j] = p.sf[((size_t)min(n0 + j, p.n_tiles - 1) * p.nks + ks) * 64 + lane];
         }
 #pragma unroll
         for (int u = 0; u < WG_KB; ++u) {
-            const int ks = base + 4 * u;
-            if (ks >= ks_hi) continue;
+            const bool live = base + 4 * u < ks_hi;                       // past the slice: contributes zeros
 #pragma unroll
             for (int i = 0; i < WG_MT; ++i) {
-                if (m0 + i >= p.m_tiles) continue;
-                if (want_db) dbp[i] += frag_sum<CT>(a[u][i]);
+                const uint4 av = live ? a[u][i] : zero4;
+                dbp[i] += frag_sum<CT>(av);
 #pragma unroll
                 for (int j = 0; j < WG_NT; ++j) {
-                    if (n0 + j >= p.n_tiles) continue;
                     if constexpr (sizeof(CT) == 2) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[u][i]),
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av),
                                                                              __builtin_bit_cast(bf16x8_t, b[u][j]), acc[i][j], 0, 0, 0);
                     } else {
-                        const f32x4_t af = __builtin_bit_cast(f32x4_t, a[u][i]), bf = __builtin_bit_cast(f32x4_t, b[u][j]);
+                        const f32x4_t af = __builtin_bit_cast(f32x4_t, av), bf = __builtin_bit_cast(f32x4_t, b[u][j]);
 #pragma unroll
                         for (int s = 0; s < 4; ++s)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], bf[s], acc[i][j], 0, 0, 0);
@@ -140,6 +154,7 @@ __global__ __launch_bounds__(LAYER_THREADS) void weight_grad_kernel(const Weight
         }
     }
 
+    GCNPT_STAMP(p.stamps, 1);
     // waves meet in LDS; wave w then owns tiles w, w+4, w+8 of the block
 #pragma unroll
     for (int i = 0; i < WG_MT; ++i)
@@ -155,6 +170,7 @@ __global__ __launch_bounds__(LAYER_THREADS) void weight_grad_kernel(const Weight
         }
     }
     __syncthreads();
+    GCNPT_STAMP(p.stamps, 2);
     for (int tt = wave; tt < WG_MT * WG_NT; tt += 4) {
         const int i = tt / WG_NT, j = tt - i * WG_NT;
         if (m0 + i >= p.m_tiles || n0 + j >= p.n_tiles) continue;
@@ -172,6 +188,7 @@ __global__ __launch_bounds__(LAYER_THREADS) void weight_grad_kernel(const Weight
         if (m0 + i < p.m_tiles && m < p.H)
             atomicAdd(p.db + m, 2.0f * (dbred[0][i][c] + dbred[1][i][c] + dbred[2][i][c] + dbred[3][i][c]));   // bias enters twice
     }
+    GCNPT_STAMP(p.stamps, 3);
 }
 
 }  // namespace gcnpt
@@ -215,16 +232,20 @@ extern "C" int gcnpt_layer_bwd_weight(void* stream, const void* z_frag, const vo
     GCNPT_REQUIRE(B > 0 && T > 0 && Din > 0 && H > 0, "layer_bwd_weight: sizes must be positive");
     GCNPT_REQUIRE(dtype_ok(compute_dtype), "layer_bwd_weight: bad dtype");
     WeightGradParams p{};
+    p.stamps = static_cast<unsigned long long*>(g_debug_stamps); p.knob = g_debug_knob;
     p.zf = static_cast<const uint4*>(z_frag); p.sf = static_cast<const uint4*>(s_frag);
     p.dW = dW; p.db = db; p.H = H; p.Din = Din;
     p.m_tiles = ceil_div(H, 16); p.n_tiles = ceil_div(Din, 16);
     p.nks = ceil_div(B * T, 32) * (compute_dtype == GCNPT_BF16 ? 1 : 2);
     const int mb = ceil_div(p.m_tiles, WG_MT), nb = ceil_div(p.n_tiles, WG_NT);
-    // one workgroup per CU: split the contraction so that blocks x slices ~ 256, at least one k-step per wave
-    int slices = std::max(1, std::min(ceil_div(p.nks, 4), ceil_div(256, mb * nb)));
+    // one workgroup per CU: split the contraction so that blocks x slices ~ 256 with at least one k-step per
+    // wave; slices is 1, 2, 4 or a multiple of 8 so that each slice maps onto whole XCD groups
+    int want = std::max(1, std::min(ceil_div(p.nks, 4), ceil_div(256, mb * nb)));
+    int slices = want >= 8 ? (want + 4) / 8 * 8 : (want >= 4 ? 4 : (want >= 2 ? 2 : 1));
     p.ks_per_wg = ceil_div(p.nks, slices);
-    slices = ceil_div(p.nks, p.ks_per_wg);
-    const dim3 grid(mb, nb, slices);
+    p.mb = mb; p.nb = nb; p.slices = slices;
+    const int per_group = (slices & 7) == 0 ? mb * nb * (slices / 8) : ceil_div(mb * nb, 8 / slices);
+    const dim3 grid(8 * per_group);
     hipStream_t s = (hipStream_t)stream;
     if (compute_dtype == GCNPT_BF16)
         hipLaunchKernelGGL(weight_grad_kernel<bf16_t>, grid, dim3(LAYER_THREADS), 0, s, p);

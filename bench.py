@@ -106,7 +106,7 @@ class Stack(object):
         tr, P, st = self.trees, self._lib.ptr, self._lib.stream()
         self._lib.check(self.L.gcnpt_prune_to_csr(st, P(self.head), P(self.subj), P(self.obj), P(self.deprel), P(self.masks), None,
                                                   self.B, self.T, self.args.prune_k, tr.cap, P(tr.row_ptr), P(tr.col_idx), None,
-                                                  P(tr.rowT_ptr), P(tr.colT_idx), P(tr.pool_mask), P(tr.status)))
+                                                  P(tr.rowT_ptr), P(tr.colT_idx), P(tr.ell), P(tr.ellT), P(tr.pool_mask), P(tr.status)))
 
     def pack(self, l):
         P = self._lib.ptr
@@ -119,7 +119,7 @@ class Stack(object):
         H, Din = self.W[l].shape
         p = self.args.drop if l == 0 else 0.0
         self._lib.check(self.L.gcnpt_layer_fwd(self._lib.stream(), P(src), self.act, P(self.wf[l]), P(self.b[l]), P(tr.row_ptr), P(tr.col_idx),
-                                               None, self.B, self.T, Din, H, P(dst), self.act, self.compute, p, 0x5eed, P(self.sf[l])))
+                                               P(tr.ell), None, self.B, self.T, Din, H, P(dst), self.act, self.compute, p, 0x5eed, P(self.sf[l])))
 
     def _dw_db(self, l, k):
         g = self.grads(k)
@@ -132,8 +132,8 @@ class Stack(object):
         H, Din = self.W[l].shape
         sc = self.scale if l == 0 else 1.0
         dW, db = self._dw_db(l, k)
-        self._lib.check(self.L.gcnpt_layer_bwd_data(self._lib.stream(), P(dy), P(y), self.act, P(self.wb[l]), P(tr.row_ptr), P(tr.rowT_ptr),
-                                                    P(tr.colT_idx), self.B, self.T, Din, H, P(dst), self.act, self.compute, sc,
+        self._lib.check(self.L.gcnpt_layer_bwd_data(self._lib.stream(), P(dy), P(y), self.act, P(self.wb[l]), P(tr.ell), P(tr.rowT_ptr),
+                                                    P(tr.colT_idx), P(tr.ellT), self.B, self.T, Din, H, P(dst), self.act, self.compute, sc,
                                                     P(self.zf[l]), P(dW), P(db)))
 
     def bwd_weight(self, l, k=0):
@@ -155,7 +155,7 @@ class Stack(object):
     def algorithmic_bytes(self):
         e = 2 if self.args.dtype == "bf16" else 4
         N, B, T = self.B * self.T, self.B, self.T
-        csr = 4 * B * (T + 1) + 4 * self.nnz
+        csr = 32 * N            # one ELL head (count + 7 columns) per row; the CSR arrays are only touched by rows with > 7 entries
         out = {}
         for l, (H, Din) in enumerate([tuple(w.shape) for w in self.W]):
             wp = self.wf[l].numel()
@@ -163,7 +163,7 @@ class Stack(object):
             out["bwd_data%d" % l] = e * N * (2 * H + Din) + self.wb[l].numel() + 2 * csr + self.zf[l].numel() + 4 * (H * Din + H)
             out["bwd_weight%d" % l] = self.zf[l].numel() + self.sf[l].numel() + 4 * (H * Din + H)
             out["pack%d" % l] = 4 * H * Din + self.wf[l].numel() + self.wb[l].numel()
-        out["prune"] = 4 * 8 * N + N + 2 * csr + N + 4 * (B + 1)
+        out["prune"] = 4 * 8 * N + N + 2 * (csr + 4 * B * (T + 1) + 4 * self.nnz) + N + 4 * (B + 1)
         return out
 
 

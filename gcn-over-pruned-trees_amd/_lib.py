@@ -17,14 +17,14 @@ _p, _i, _f, _u64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_
 SIGNATURES = {
     "gcnpt_abi_version": (_i, []),
     "gcnpt_last_error": (ctypes.c_char_p, []),
-    "gcnpt_prune_to_csr": (_i, [_p] * 7 + [_i] * 4 + [_p] * 7),
-    "gcnpt_adj_to_csr": (_i, [_p, _p, _i, _i, _i] + [_p] * 7),
+    "gcnpt_prune_to_csr": (_i, [_p] * 7 + [_i] * 4 + [_p] * 9),
+    "gcnpt_adj_to_csr": (_i, [_p, _p, _i, _i, _i] + [_p] * 9),
     "gcnpt_csr_to_adj": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "gcnpt_packed_bytes": (_sz, [_i, _i, _i]),
     "gcnpt_pack_weights": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "gcnpt_frag_bytes": (_sz, [_i, _i, _i]),
-    "gcnpt_layer_fwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _f, _u64, _p]),
-    "gcnpt_layer_bwd_data": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _f, _p, _p, _p]),
+    "gcnpt_layer_fwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _f, _u64, _p]),
+    "gcnpt_layer_bwd_data": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _f, _p, _p, _p]),
     "gcnpt_layer_bwd_weight": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _i]),
 }
 

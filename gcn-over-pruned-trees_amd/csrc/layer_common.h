@@ -73,17 +73,17 @@ __host__ __device__ inline int lds_stride_dw(int payload_dw) {
     return s;
 }
 
-// counter-based dropout: one 32-bit hash of (seed, row pair, column) decides the two rows of the pair with
+// counter-based dropout: one 32-bit hash of (seed, row, column pair) decides the two columns of the pair with
 // 16 bits each, so the mask is a pure function of (seed, row, col) whatever the kernel's tiling is
-__device__ __forceinline__ unsigned drop_hash(uint64_t seed, unsigned row_pair, unsigned col) {
-    unsigned x = row_pair * 0x9E3779B1u + col * 0x85EBCA77u + (unsigned)seed;
+__device__ __forceinline__ unsigned drop_hash(uint64_t seed, unsigned row, unsigned col_pair) {
+    unsigned x = row * 0x9E3779B1u + col_pair * 0x85EBCA77u + (unsigned)seed;
     x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
     x += (unsigned)(seed >> 32) * 0xC2B2AE3Du;
     x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12;
     return x;
 }
-__device__ __forceinline__ bool drop_keep(unsigned hash, unsigned row, unsigned thresh16) {
-    return ((row & 1u) ? (hash >> 16) : (hash & 0xffffu)) >= thresh16;
+__device__ __forceinline__ bool drop_keep(unsigned hash, unsigned col, unsigned thresh16) {
+    return ((col & 1u) ? (hash >> 16) : (hash & 0xffffu)) >= thresh16;
 }
 
 // v / d for d = deg + 1 given r = 1/d: one Newton step on the quotient gives the correctly rounded result

@@ -22,16 +22,17 @@ namespace gcnpt {
 constexpr int ROWS = 32;             // token rows per workgroup (two 16-row MFMA tiles)
 constexpr int RT_THREADS = 512;      // 8 waves; wave w owns output tiles w, w+8, ...
 constexpr int RT_WAVES = RT_THREADS / WAVE;
-constexpr int NB_INLINE = 8;         // neighbours per row staged in LDS next to the extents
+constexpr int NB_INLINE = 7;         // neighbours per row that the ELL head carries (include/gcnpt.h)
 
 struct RowTileParams {
     const void* src;        // fwd: h [N,K]      bwd: dY [N,K]
     const void* yref;       // bwd: Y [N,K] (stored layer output)
     const void* wfrag;      // packed B operand, gcnpt_pack_weights
     const float* bias;      // fwd: [NOUT]
-    const int32_t* g_row_ptr;   // pattern gathered over (fwd: A, bwd: A^T)
+    const int32_t* g_row_ptr;   // pattern gathered over (fwd: A, bwd: A^T): CSR, only read for rows with > 7 entries
     const int32_t* g_col_idx;
-    const int32_t* d_row_ptr;   // pattern whose row length gives deg (always A)
+    const int32_t* g_ell;       // its ELL head: [8r] = entries of row r, [8r+1..8r+7] = first columns
+    const int32_t* d_ell;       // ELL head whose [8r] gives deg (always the forward pattern A)
     void* out;              // [N,NOUT]; NULL = only the side outputs below are wanted
     void* frag_out;         // NULL or fragment image (include/gcnpt.h) of the tile: fwd S = (A+I)h, bwd dZ
     float* zero_a;          // NULL or accumulators to clear for the kernel that follows (bwd: dW, db)
@@ -118,11 +119,9 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
     CT* Z = reinterpret_cast<CT*>(smem_raw + s_bytes);          // bwd only: the tile's own dZ rows (before aggregation)
     OT* O = reinterpret_cast<OT*>(smem_raw + (BWD ? 2 : 1) * s_bytes);
     int* meta = reinterpret_cast<int*>(smem_raw + (BWD ? 2 : 1) * s_bytes + (size_t)ROWS * ostride * sizeof(OT));
-    int* rbeg = meta;                         // [ROWS]
-    int* rend = meta + ROWS;                  // [ROWS]
-    float* rinv = reinterpret_cast<float*>(meta + 2 * ROWS);   // [ROWS] fwd: 1/(deg+1)   bwd: scale/(deg+1)
-    float* rden = reinterpret_cast<float*>(meta + 3 * ROWS);   // [ROWS] deg+1
-    int* rnbr = meta + 4 * ROWS;              // [ROWS][NB_INLINE] absolute neighbour rows
+    int* rell = meta;                         // [ROWS][8] ELL heads of the tile's rows (count, 7 sentence-local columns)
+    float* rinv = reinterpret_cast<float*>(meta + 8 * ROWS);   // [ROWS] fwd: 1/(deg+1)   bwd: scale/(deg+1)
+    float* rden = reinterpret_cast<float*>(meta + 9 * ROWS);   // [ROWS] deg+1
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = blockIdx.x * ROWS;
@@ -134,22 +133,20 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
     GCNPT_STAMP_REAL(p.stamps);
     GCNPT_STAMP(p.stamps, 0);
 
-    // (1) row metadata -> LDS (32 lanes of wave 0).  Loads return in issue order per wave, so this
-    //     latency-critical chain (extents -> first neighbours) goes out before the bulk loads.
-    if (tid < ROWS) {
-        const int r = min(r0 + tid, p.N - 1);
-        const int b = r / p.T, i = r - b * p.T;
-        const size_t q = (size_t)b * (p.T + 1) + i;
-        int beg = p.g_row_ptr[q], end = p.g_row_ptr[q + 1];
-        const float dn = (float)(p.d_row_ptr[q + 1] - p.d_row_ptr[q] + 1);          // gcn.py:261
-        if (r0 + tid >= p.N) end = beg;
-        const int safe = end > beg ? end - 1 : 0;                 // some valid entry for the lanes past the row's end
-#pragma unroll
-        for (int e = 0; e < NB_INLINE; ++e)
-            rnbr[tid * NB_INLINE + e] = b * p.T + p.g_col_idx[beg + e < end ? beg + e : safe];
-        rbeg[tid] = beg; rend[tid] = end;
-        rinv[tid] = (BWD ? p.scale : 1.0f) / dn;
-        rden[tid] = dn;
+    // (1) the tile's adjacency: ONE coalesced 1-KiB load of the 32 ELL heads (lanes 0..63 of wave 0, 16 bytes each)
+    //     plus the degrees for the denominators.  No dependent load: a pruned-tree row has <= 3-4 entries.
+    if (tid < 2 * ROWS) {
+        const int row = tid >> 1, half = tid & 1;
+        const size_t r = (size_t)min(r0 + row, p.N - 1);
+        const int4 e = reinterpret_cast<const int4*>(p.g_ell)[r * 2 + half];
+        const float dn = (float)(p.d_ell[r * 8] + 1);                                // gcn.py:261
+        const bool first = half == 0;
+        const int e0 = (first && r0 + row >= p.N) ? 0 : e.x;                         // rows past the end aggregate nothing
+        reinterpret_cast<int4*>(rell)[row * 2 + half] = make_int4(e0, e.y, e.z, e.w);
+        if (first) {
+            rinv[row] = (BWD ? p.scale : 1.0f) / dn;
+            rden[row] = dn;
+        }
     }
 
     // own rows of the first batch (everyone), then (0): this wave's weight fragments, all of them
@@ -183,16 +180,21 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
                 wreg[ks][j] = wfrag[((size_t)tl * ksteps + kk) * 64 + lane];
             }
     };
-    float bias2[NTW];                                          // fwd epilogue operand, fetched now, used last
+    // fwd epilogue operand, fetched now, used last.  The MFMAs run with swapped operands (weights as A), so a lane
+    // ends up with 4 CONSECUTIVE output columns of one row: columns 16 tile + 4 (lane>>4) + g.
+    float bias2[NTW][4];
+    auto load_bias = [&](int pass) {
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) bias2[j] = 0.0f;
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = (pass * RT_WAVES * NTW + j * RT_WAVES + wave) * 16 + (lane >> 4) * 4 + g;
+                bias2[j][g] = BWD ? 0.0f : 2.0f * p.bias[min(col, p.NOUT - 1)];        // enters twice, gcn.py:270-271
+            }
+    };
     if (p.out) {
         load_w(0, 0);                                          // 156 KB per workgroup at Din=360, H=200
-        if constexpr (!BWD) {
-#pragma unroll
-            for (int j = 0; j < NTW; ++j)
-                bias2[j] = 2.0f * p.bias[min((j * RT_WAVES + wave) * 16 + (lane & 15), p.NOUT - 1)];   // enters twice, gcn.py:270-271
-        }
+        if constexpr (!BWD) load_bias(0);
     }
     GCNPT_STAMP(p.stamps, 1);
     __syncthreads();
@@ -220,32 +222,34 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
                 for (int j = 0; j < 8; ++j) acc[j] = (y[j] > 0.0f) ? acc[j] * inv : 0.0f;
                 if (p.frag_out) tile<CT>::put8(Z + (size_t)row * stride + k0, acc);
             }
-            const int beg = rbeg[row];
-            const int n = (live && p.out) ? rend[row] - beg : 0;
+            const int n = (live && p.out) ? rell[row * 8] : 0;
             const size_t rc = (size_t)min(r, p.N - 1);
-            // gcn.py:269: <= 3 neighbours per kept token of a pruned tree.  The first NB_INLINE come from LDS, the
-            // (rare) rest from col_idx; lanes without an e-th neighbour load their own row and drop it.
-            auto round = [&](int e0, auto from_lds) {
+            const int sbase = (int)(rc / p.T) * p.T;                    // first row of this row's sentence
+            // gcn.py:269: <= 3-4 neighbours per kept token of a pruned tree.  The first 7 come from the ELL head in LDS,
+            // the (rare) rest from col_idx; lanes without an e-th neighbour load their own row and drop it.
+            auto round = [&](int e0, int lim, auto from_lds) {
                 raw8<IT> nb[NBU], nby[NBU];
                 float ninv[NBU];
 #pragma unroll
                 for (int e = 0; e < NBU; ++e) {
-                    const bool on = e0 + e < n;
+                    const bool on = e0 + e < lim;
                     size_t c;
-                    if constexpr (decltype(from_lds)::value) c = (size_t)rnbr[row * NB_INLINE + min(e0 + e, NB_INLINE - 1)];
-                    else c = (size_t)((r / p.T) * p.T + p.g_col_idx[on ? beg + e0 + e : beg]);
+                    if constexpr (decltype(from_lds)::value) {
+                        c = (size_t)(sbase + rell[row * 8 + 1 + min(e0 + e, NB_INLINE - 1)]);
+                    } else {                                            // > 7 entries (dense adjacency input): continue in the CSR
+                        const int beg = p.g_row_ptr[(size_t)(sbase / p.T) * (p.T + 1) + (rc - sbase)];
+                        c = (size_t)(sbase + p.g_col_idx[on ? beg + e0 + e : beg]);
+                    }
                     c = on ? c : rc;
                     issue8<IT, VEC>(src, c, p.K, k0c, nb[e]);
                     if (BWD) {
                         issue8<IT, VEC>(yref, c, p.K, k0c, nby[e]);
-                        const int cb = (int)(c / p.T);
-                        const size_t q = (size_t)cb * (p.T + 1) + (c - (size_t)cb * p.T);
-                        ninv[e] = p.scale / (float)(p.d_row_ptr[q + 1] - p.d_row_ptr[q] + 1);
+                        ninv[e] = p.scale / (float)(p.d_ell[c * 8] + 1);
                     }
                 }
 #pragma unroll
                 for (int e = 0; e < NBU; ++e) {
-                    const bool on = e0 + e < n;
+                    const bool on = e0 + e < lim;
                     float v[8];
                     unpack8<IT>(nb[e], on, v);
                     if (BWD) {
@@ -259,8 +263,9 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
                     }
                 }
             };
-            for (int e0 = 0; e0 < min(n, NB_INLINE); e0 += NBU) round(e0, std::true_type{});
-            for (int e0 = NB_INLINE; e0 < n; e0 += NBU) round(e0, std::false_type{});
+            const int n_ell = min(n, NB_INLINE);
+            for (int e0 = 0; e0 < n_ell; e0 += NBU) round(e0, n_ell, std::true_type{});
+            for (int e0 = NB_INLINE; e0 < n; e0 += NBU) round(e0, n, std::false_type{});
             tile<CT>::put8(S + (size_t)row * stride + k0, acc);
         }
     }
@@ -339,15 +344,15 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
                     for (int j = 0; j < NTW; ++j) {
                         if constexpr (sizeof(CT) == 2) {
                             const bf16x8_t bq = __builtin_bit_cast(bf16x8_t, wreg[ks][j]);
-                            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a_cur[0]), bq, acc[0][j], 0, 0, 0);
-                            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a_cur[1]), bq, acc[1][j], 0, 0, 0);
+                            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq, __builtin_bit_cast(bf16x8_t, a_cur[0]), acc[0][j], 0, 0, 0);
+                            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq, __builtin_bit_cast(bf16x8_t, a_cur[1]), acc[1][j], 0, 0, 0);
                         } else {
                             const f32x4_t bq = __builtin_bit_cast(f32x4_t, wreg[ks][j]);
                             const f32x4_t a0 = __builtin_bit_cast(f32x4_t, a_cur[0]), a1 = __builtin_bit_cast(f32x4_t, a_cur[1]);
 #pragma unroll
                             for (int s = 0; s < 4; ++s) {
-                                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], bq[s], acc[0][j], 0, 0, 0);
-                                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], bq[s], acc[1][j], 0, 0, 0);
+                                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[s], a0[s], acc[0][j], 0, 0, 0);
+                                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[s], a1[s], acc[1][j], 0, 0, 0);
                             }
                         }
                     }
@@ -357,32 +362,50 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
         }
 
         GCNPT_STAMP(p.stamps, 6);
-        // epilogue on the accumulators -> LDS out tile (tiles past the last real one hold duplicates: not stored)
-        if (pass > 0) __syncthreads();                                   // previous pass's rows have left O
+        // epilogue on the accumulators -> LDS out tile (tiles past the last real one hold duplicates: not stored).
+        // Lane (i = lane & 15, q = lane >> 4) holds, per 16x16 tile, row i and the 4 consecutive columns 4q..4q+3.
+        if (pass > 0) {
+            __syncthreads();                                             // previous pass's rows have left O
+            if constexpr (!BWD) load_bias(pass);
+        }
+        float den[2], inv[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) { den[mt] = rden[mt * 16 + (lane & 15)]; inv[mt] = rinv[mt * 16 + (lane & 15)]; }
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
             const int tl = tile0 + j * RT_WAVES;
             if (tl >= n_tiles) continue;
-            const int col = tl * 16 + (lane & 15);
-            const int lcol = col - pass * ncols_pass;
-            float b2 = 0.0f;
-            if constexpr (!BWD) b2 = pass == 0 ? bias2[j] : 2.0f * p.bias[min(col, p.NOUT - 1)];
+            const int col0 = tl * 16 + (lane >> 4) * 4;
+            const int lcol0 = col0 - pass * ncols_pass;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
-                unsigned dh = 0;
+                const int row = mt * 16 + (lane & 15);
+                float v[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int row = mt * 16 + (lane >> 4) * 4 + g;      // rows 4k..4k+3: (g, g+1) are a hash pair
-                    float v = acc[mt][j][g];
+                    float x = acc[mt][j][g];
                     if (!BWD) {
-                        v = div_by(v + b2, rden[row], rinv[row]);        // gcn.py:390
-                        v = v > 0.0f ? v : 0.0f;                         // gcn.py:392
-                        if (p.drop_p > 0.0f) {                            // gcn.py:393
-                            if ((g & 1) == 0) dh = drop_hash(p.seed, (unsigned)(r0 + row) >> 1, (unsigned)col);
-                            v = drop_keep(dh, (unsigned)(r0 + row), p.drop_thresh16) ? v * p.scale : 0.0f;
-                        }
+                        x = div_by(x + bias2[j][g], den[mt], inv[mt]);   // gcn.py:390
+                        x = x > 0.0f ? x : 0.0f;                         // gcn.py:392
                     }
-                    io<OT>::store1(O + (size_t)row * ostride + lcol, v);
+                    v[g] = x;
+                }
+                if (!BWD && p.drop_p > 0.0f) {                            // gcn.py:393: one hash per column pair
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const unsigned dh = drop_hash(p.seed, (unsigned)(r0 + row), (unsigned)(col0 >> 1) + h2);
+                        v[2 * h2] = drop_keep(dh, 0u, p.drop_thresh16) ? v[2 * h2] * p.scale : 0.0f;
+                        v[2 * h2 + 1] = drop_keep(dh, 1u, p.drop_thresh16) ? v[2 * h2 + 1] * p.scale : 0.0f;
+                    }
+                }
+                OT* dst = O + (size_t)row * ostride + lcol0;
+                if constexpr (sizeof(OT) == 2) {
+                    uint2 pk;
+                    pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                    pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                    *reinterpret_cast<uint2*>(dst) = pk;
+                } else {
+                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
         }
@@ -426,7 +449,7 @@ static int launch_rowtile_cfg(hipStream_t s, const RowTileParams& p) {
     const int ncols_pass = RT_WAVES * NTW * 16;
     const int ostride = out_stride_dw(std::min(round_up(p.NOUT, 16), ncols_pass) * (int)sizeof(OT) / 4) * 4 / (int)sizeof(OT);
     const size_t lds = (size_t)(BWD ? 2 : 1) * ROWS * stride * sizeof(CT) + (size_t)ROWS * ostride * sizeof(OT) +
-                       (size_t)ROWS * (4 + NB_INLINE) * sizeof(int);
+                       (size_t)ROWS * 10 * sizeof(int);
     if (lds > 160 * 1024) return fail(GCNPT_E_UNSUPPORTED, "layer: K=%d needs %zu B of LDS per workgroup", p.K, lds);
     auto kern = rowtile_kernel<CT, IT, OT, BWD, VEC, NTW, KSMAX>;
     if (lds > 64 * 1024)
@@ -462,10 +485,10 @@ static int dispatch_rowtile(hipStream_t s, const RowTileParams& p, int in_dtype,
 }
 
 extern "C" int gcnpt_layer_fwd(void* stream, const void* h, int h_dtype, const void* w_fwd, const float* bias,
-                               const int32_t* row_ptr, const int32_t* col_idx, const int32_t* deg_row_ptr, int B, int T,
-                               int Din, int H, void* out, int out_dtype, int compute_dtype, float drop_p, uint64_t seed,
-                               void* s_frag) {
-    GCNPT_REQUIRE(h && w_fwd && bias && row_ptr && col_idx && out, "layer_fwd: null pointer");
+                               const int32_t* row_ptr, const int32_t* col_idx, const int32_t* ell, const int32_t* deg_ell,
+                               int B, int T, int Din, int H, void* out, int out_dtype, int compute_dtype, float drop_p,
+                               uint64_t seed, void* s_frag) {
+    GCNPT_REQUIRE(h && w_fwd && bias && row_ptr && col_idx && ell && out, "layer_fwd: null pointer");
     GCNPT_REQUIRE(B > 0 && T > 0 && Din > 0 && H > 0, "layer_fwd: sizes must be positive");
     GCNPT_REQUIRE(dtype_ok(h_dtype) && dtype_ok(out_dtype) && dtype_ok(compute_dtype), "layer_fwd: bad dtype");
     GCNPT_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "layer_fwd: drop_p=%f outside [0,1)", (double)drop_p);
@@ -473,7 +496,7 @@ extern "C" int gcnpt_layer_fwd(void* stream, const void* h, int h_dtype, const v
     RowTileParams p{};
     p.stamps = static_cast<unsigned long long*>(g_debug_stamps); p.knob = g_debug_knob;
     p.src = h; p.yref = nullptr; p.wfrag = w_fwd; p.bias = bias;
-    p.g_row_ptr = row_ptr; p.g_col_idx = col_idx; p.d_row_ptr = deg_row_ptr ? deg_row_ptr : row_ptr; p.out = out;
+    p.g_row_ptr = row_ptr; p.g_col_idx = col_idx; p.g_ell = ell; p.d_ell = deg_ell ? deg_ell : ell; p.out = out;
     p.frag_out = s_frag;
     p.N = B * T; p.T = T; p.K = Din; p.NOUT = H; p.Kpad = round_up(Din, kstep_of(compute_dtype));
     p.vec_in = (Din % 8 == 0) && aligned16(h);
@@ -485,10 +508,10 @@ extern "C" int gcnpt_layer_fwd(void* stream, const void* h, int h_dtype, const v
 }
 
 extern "C" int gcnpt_layer_bwd_data(void* stream, const void* dY, const void* Y, int g_dtype, const void* w_bwd,
-                                    const int32_t* row_ptr, const int32_t* rowT_ptr, const int32_t* colT_idx, int B,
-                                    int T, int Din, int H, void* dh, int dh_dtype, int compute_dtype, float scale,
-                                    void* z_frag, float* zero_dW, float* zero_db) {
-    GCNPT_REQUIRE(dY && Y && w_bwd && row_ptr && rowT_ptr && colT_idx, "layer_bwd_data: null pointer");
+                                    const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
+                                    const int32_t* ellT, int B, int T, int Din, int H, void* dh, int dh_dtype,
+                                    int compute_dtype, float scale, void* z_frag, float* zero_dW, float* zero_db) {
+    GCNPT_REQUIRE(dY && Y && w_bwd && ell && rowT_ptr && colT_idx && ellT, "layer_bwd_data: null pointer");
     GCNPT_REQUIRE(dh || z_frag, "layer_bwd_data: nothing to produce (dh and z_frag both NULL)");
     GCNPT_REQUIRE(B > 0 && T > 0 && Din > 0 && H > 0, "layer_bwd_data: sizes must be positive");
     GCNPT_REQUIRE(dtype_ok(g_dtype) && dtype_ok(dh_dtype) && dtype_ok(compute_dtype), "layer_bwd_data: bad dtype");
@@ -496,7 +519,7 @@ extern "C" int gcnpt_layer_bwd_data(void* stream, const void* dY, const void* Y,
     RowTileParams p{};
     p.stamps = static_cast<unsigned long long*>(g_debug_stamps); p.knob = g_debug_knob;
     p.src = dY; p.yref = Y; p.wfrag = w_bwd; p.bias = nullptr;
-    p.g_row_ptr = rowT_ptr; p.g_col_idx = colT_idx; p.d_row_ptr = row_ptr; p.out = dh;
+    p.g_row_ptr = rowT_ptr; p.g_col_idx = colT_idx; p.g_ell = ellT; p.d_ell = ell; p.out = dh;
     p.frag_out = z_frag;
     p.zero_a = zero_dW; p.zero_a_n = H * Din; p.zero_b = zero_db; p.zero_b_n = H;
     p.N = B * T; p.T = T; p.K = H; p.NOUT = Din; p.Kpad = round_up(H, kstep_of(compute_dtype));

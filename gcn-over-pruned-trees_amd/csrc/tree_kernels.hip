@@ -49,7 +49,8 @@ __global__ __launch_bounds__(PRUNE_THREADS) void prune_to_csr_kernel(
     const int64_t* __restrict__ deprel, const uint8_t* __restrict__ pad_mask, const int32_t* __restrict__ len_in,
     int B, int T, int prune_k, int cap, int32_t* __restrict__ row_ptr, int32_t* __restrict__ col_idx,
     int32_t* __restrict__ label, int32_t* __restrict__ rowT_ptr, int32_t* __restrict__ colT_idx,
-    uint8_t* __restrict__ pool_mask, int32_t* __restrict__ status) {
+    int32_t* __restrict__ ell, int32_t* __restrict__ ellT, uint8_t* __restrict__ pool_mask,
+    int32_t* __restrict__ status) {
     extern __shared__ int smem[];
     int* par = smem;               // [T]   parent token (-1 root / none, -2 head points past the sentence)
     int* cnt = par + T;            // [T]   #entity chains through the token; later K_KEEP/K_CHILD bits
@@ -184,6 +185,10 @@ __global__ __launch_bounds__(PRUNE_THREADS) void prune_to_csr_kernel(
         }
         if (pool_mask)
             for (int i = t; i < T; i += NT) pool_mask[base + i] = 1;
+        for (int i = t; i < T * 8; i += NT) {
+            ell[base * 8 + i] = 0;
+            if (ellT) ellT[base * 8 + i] = 0;
+        }
         if (t == 0) status[b] = err;
         return;
     }
@@ -193,25 +198,47 @@ __global__ __launch_bounds__(PRUNE_THREADS) void prune_to_csr_kernel(
         row_ptr[(size_t)b * (T + 1) + i] = b * cap + deg[i];
         if (rowT_ptr) rowT_ptr[(size_t)b * (T + 1) + i] = b * cap + degT[i];
     }
-    for (int r = t; r < len; r += NT) {
-        const int rf = flg[r];
-        if (!(rf & F_HASEDGE)) continue;
-        const bool rchild = cnt[r] & K_CHILD;
-        const int rp = par[r];
-        int o = b * cap + deg[r], oT = b * cap + degT[r];
-        for (int j = 0; j < len; ++j) {
-            const bool child = (cnt[j] & K_CHILD) && par[j] == r;
-            const int fj = flg[j];
-            if (child) {
-                if (fj & F_FWD_NZ) { col_idx[o] = j; if (label) label[o] = (int)deprel[base + j]; ++o; }
-                if ((fj & F_REV_NZ) && colT_idx) colT_idx[oT++] = j;
-            } else if (j == r) {
-                col_idx[o] = r; if (label) label[o] = SELF_LOOP_ID; ++o;
-                if (colT_idx) colT_idx[oT++] = r;
-            } else if (rchild && j == rp) {
-                if (rf & F_REV_NZ) { col_idx[o] = j; if (label) label[o] = (int)deprel[base + r] + FWD_BOUND; ++o; }
-                if ((rf & F_FWD_NZ) && colT_idx) colT_idx[oT++] = j;
+    for (int r = t; r < T; r += NT) {
+        int hd[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hdT[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ELL heads: count, first 7 columns
+        const int rf = r < len ? flg[r] : 0;
+        if (rf & F_HASEDGE) {
+            const bool rchild = cnt[r] & K_CHILD;
+            const int rp = par[r];
+            const int o0 = b * cap + deg[r], oT0 = b * cap + degT[r];
+            int o = o0, oT = oT0;
+            auto put = [&](int j, int lab) {
+                col_idx[o] = j; if (label) label[o] = lab;
+                if (o - o0 < 7) hd[1 + o - o0] = j;
+                ++o;
+            };
+            auto putT = [&](int j) {
+                if (colT_idx) colT_idx[oT] = j;
+                if (oT - oT0 < 7) hdT[1 + oT - oT0] = j;
+                ++oT;
+            };
+            for (int j = 0; j < len; ++j) {
+                const bool child = (cnt[j] & K_CHILD) && par[j] == r;
+                const int fj = flg[j];
+                if (child) {
+                    if (fj & F_FWD_NZ) put(j, (int)deprel[base + j]);
+                    if (fj & F_REV_NZ) putT(j);
+                } else if (j == r) {
+                    put(r, SELF_LOOP_ID);
+                    putT(r);
+                } else if (rchild && j == rp) {
+                    if (rf & F_REV_NZ) put(j, (int)deprel[base + r] + FWD_BOUND);
+                    if (rf & F_FWD_NZ) putT(j);
+                }
             }
+            hd[0] = o - o0; hdT[0] = oT - oT0;
+        }
+        int4* e = reinterpret_cast<int4*>(ell + (base + r) * 8);
+        e[0] = make_int4(hd[0], hd[1], hd[2], hd[3]);
+        e[1] = make_int4(hd[4], hd[5], hd[6], hd[7]);
+        if (ellT) {
+            int4* eT = reinterpret_cast<int4*>(ellT + (base + r) * 8);
+            eT[0] = make_int4(hdT[0], hdT[1], hdT[2], hdT[3]);
+            eT[1] = make_int4(hdT[4], hdT[5], hdT[6], hdT[7]);
         }
     }
     if (t == 0) status[b] = 0;
@@ -221,7 +248,8 @@ __global__ __launch_bounds__(PRUNE_THREADS) void prune_to_csr_kernel(
 __global__ __launch_bounds__(ADJ_THREADS) void adj_to_csr_kernel(
     const float* __restrict__ adj, int B, int T, int cap, int32_t* __restrict__ row_ptr, int32_t* __restrict__ col_idx,
     int32_t* __restrict__ label, int32_t* __restrict__ rowT_ptr, int32_t* __restrict__ colT_idx,
-    uint8_t* __restrict__ pool_mask, int32_t* __restrict__ status) {
+    int32_t* __restrict__ ell, int32_t* __restrict__ ellT, uint8_t* __restrict__ pool_mask,
+    int32_t* __restrict__ status) {
     extern __shared__ int smem[];
     int* deg = smem;              // [T+1]
     int* degT = deg + T + 1;      // [T+1]
@@ -256,21 +284,39 @@ __global__ __launch_bounds__(ADJ_THREADS) void adj_to_csr_kernel(
         status[b] = over ? GCNPT_E_CAPACITY : 0;
         atomicMax(&status[B], T);
     }
+    // ELL heads start as "count = 0"; the fill below overwrites the rows that have entries
+    for (int i = t; i < T * 8; i += ADJ_THREADS) {
+        ell[(size_t)b * T * 8 + i] = 0;
+        if (ellT) ellT[(size_t)b * T * 8 + i] = 0;
+    }
+    __syncthreads();
     if (over) return;
     const unsigned long long lt = (1ull << lane) - 1ull;
     for (int r = wave; r < T; r += NW) {
-        int o = b * cap + deg[r], oT = b * cap + degT[r];
+        const int o0 = b * cap + deg[r], oT0 = b * cap + degT[r];
+        int o = o0, oT = oT0;
+        int32_t* e = ell + ((size_t)b * T + r) * 8;
+        int32_t* eT = ellT ? ellT + ((size_t)b * T + r) * 8 : nullptr;
         for (int c0 = 0; c0 < T; c0 += WAVE) {
             const int c = c0 + lane;
             const float v = c < T ? A[(size_t)r * T + c] : 0.0f;
             const float vT = c < T ? A[(size_t)c * T + r] : 0.0f;
             const bool nz = c < T && v != 0.0f, nzT = c < T && vT != 0.0f;
             const unsigned long long m = __ballot(nz), mT = __ballot(nzT);
-            if (nz) { const int k = o + __popcll(m & lt); col_idx[k] = c; if (label) label[k] = (int)v; }
-            if (nzT && colT_idx) colT_idx[oT + __popcll(mT & lt)] = c;
+            if (nz) {
+                const int k = o + __popcll(m & lt);
+                col_idx[k] = c; if (label) label[k] = (int)v;
+                if (k - o0 < 7) e[1 + k - o0] = c;
+            }
+            if (nzT) {
+                const int k = oT + __popcll(mT & lt);
+                if (colT_idx) colT_idx[k] = c;
+                if (eT && k - oT0 < 7) eT[1 + k - oT0] = c;
+            }
             o += __popcll(m);
             oT += __popcll(mT);
         }
+        if (lane == 0) { e[0] = o - o0; if (eT) eT[0] = oT - oT0; }
     }
 }
 
@@ -291,9 +337,11 @@ using namespace gcnpt;
 extern "C" int gcnpt_prune_to_csr(void* stream, const int64_t* head, const int64_t* subj_pos, const int64_t* obj_pos,
                                   const int64_t* deprel, const uint8_t* pad_mask, const int32_t* len, int B, int T,
                                   int prune_k, int cap, int32_t* row_ptr, int32_t* col_idx, int32_t* label,
-                                  int32_t* rowT_ptr, int32_t* colT_idx, uint8_t* pool_mask, int32_t* status) {
+                                  int32_t* rowT_ptr, int32_t* colT_idx, int32_t* ell, int32_t* ellT, uint8_t* pool_mask,
+                                  int32_t* status) {
     GCNPT_REQUIRE(head && subj_pos && obj_pos && deprel && (pad_mask || len), "prune_to_csr: null input pointer");
-    GCNPT_REQUIRE(row_ptr && col_idx && status, "prune_to_csr: null output pointer");
+    GCNPT_REQUIRE(row_ptr && col_idx && ell && status, "prune_to_csr: null output pointer");
+    GCNPT_REQUIRE((rowT_ptr == nullptr) == (ellT == nullptr), "prune_to_csr: rowT_ptr, colT_idx and ellT go together");
     GCNPT_REQUIRE(B > 0 && T > 0 && cap > 0, "prune_to_csr: B, T, cap must be positive (B=%d T=%d cap=%d)", B, T, cap);
     GCNPT_REQUIRE((rowT_ptr == nullptr) == (colT_idx == nullptr), "prune_to_csr: rowT_ptr and colT_idx go together");
     if (prune_k < 0)
@@ -305,15 +353,16 @@ extern "C" int gcnpt_prune_to_csr(void* stream, const int64_t* head, const int64
     hipStream_t s = (hipStream_t)stream;
     GCNPT_HIP_CHECK(hipMemsetAsync(status + B, 0, sizeof(int32_t), s));
     hipLaunchKernelGGL(prune_to_csr_kernel, dim3(B), dim3(PRUNE_THREADS), lds, s, head, subj_pos, obj_pos, deprel,
-                       pad_mask, len, B, T, prune_k, cap, row_ptr, col_idx, label, rowT_ptr, colT_idx, pool_mask, status);
+                       pad_mask, len, B, T, prune_k, cap, row_ptr, col_idx, label, rowT_ptr, colT_idx, ell, ellT, pool_mask, status);
     GCNPT_HIP_CHECK(hipGetLastError());
     return GCNPT_OK;
 }
 
 extern "C" int gcnpt_adj_to_csr(void* stream, const float* adj, int B, int T, int cap, int32_t* row_ptr,
-                                int32_t* col_idx, int32_t* label, int32_t* rowT_ptr, int32_t* colT_idx,
-                                uint8_t* pool_mask, int32_t* status) {
-    GCNPT_REQUIRE(adj && row_ptr && col_idx && status, "adj_to_csr: null pointer");
+                                int32_t* col_idx, int32_t* label, int32_t* rowT_ptr, int32_t* colT_idx, int32_t* ell,
+                                int32_t* ellT, uint8_t* pool_mask, int32_t* status) {
+    GCNPT_REQUIRE(adj && row_ptr && col_idx && ell && status, "adj_to_csr: null pointer");
+    GCNPT_REQUIRE((rowT_ptr == nullptr) == (ellT == nullptr), "adj_to_csr: rowT_ptr, colT_idx and ellT go together");
     GCNPT_REQUIRE(B > 0 && T > 0 && cap > 0, "adj_to_csr: B, T, cap must be positive");
     GCNPT_REQUIRE((rowT_ptr == nullptr) == (colT_idx == nullptr), "adj_to_csr: rowT_ptr and colT_idx go together");
     if ((long long)B * cap > 0x7fffffffLL) return fail(GCNPT_E_UNSUPPORTED, "adj_to_csr: B*cap overflows int32");
@@ -322,7 +371,7 @@ extern "C" int gcnpt_adj_to_csr(void* stream, const float* adj, int B, int T, in
     hipStream_t s = (hipStream_t)stream;
     GCNPT_HIP_CHECK(hipMemsetAsync(status + B, 0, sizeof(int32_t), s));
     hipLaunchKernelGGL(adj_to_csr_kernel, dim3(B), dim3(ADJ_THREADS), lds, s, adj, B, T, cap, row_ptr, col_idx, label,
-                       rowT_ptr, colT_idx, pool_mask, status);
+                       rowT_ptr, colT_idx, ell, ellT, pool_mask, status);
     GCNPT_HIP_CHECK(hipGetLastError());
     return GCNPT_OK;
 }

@@ -51,12 +51,12 @@ class _GCNLayerFn(torch.autograd.Function):
         st = _lib.stream()
         _lib.check(L.gcnpt_pack_weights(st, _lib.ptr(w32), H, Din, compute, _lib.ptr(w_fwd), _lib.ptr(w_bwd)))
         out = torch.empty((B, T, H), dtype=out_dtype, device=h.device)
-        g_row_ptr = trees.empty_row_ptr() if no_adj else trees.row_ptr
+        g_ell = trees.empty_ell() if no_adj else trees.ell
         # the gathered tile S = (A+I)h is saved in MFMA fragment order for the weight gradient (include/gcnpt.h)
         want_wgrad = weight.requires_grad or bias.requires_grad
         s_frag = torch.empty((L.gcnpt_frag_bytes(B * T, Din, compute),), dtype=torch.uint8, device=h.device) if want_wgrad else None
         _lib.check(L.gcnpt_layer_fwd(st, _lib.ptr(h), _lib.dtype_code(h.dtype), _lib.ptr(w_fwd), _lib.ptr(b32),
-                                     _lib.ptr(g_row_ptr), _lib.ptr(trees.col_idx), _lib.ptr(trees.row_ptr), B, T, Din, H,
+                                     _lib.ptr(trees.row_ptr), _lib.ptr(trees.col_idx), _lib.ptr(g_ell), _lib.ptr(trees.ell), B, T, Din, H,
                                      _lib.ptr(out), _lib.dtype_code(out_dtype), compute, float(drop_p), int(seed), _lib.ptr(s_frag)))
         ctx.save_for_backward(out, w_bwd, s_frag)
         ctx.h_dtype = h.dtype
@@ -75,7 +75,7 @@ class _GCNLayerFn(torch.autograd.Function):
         gout = gout.to(out.dtype).contiguous()
         gd = _lib.dtype_code(out.dtype)
         dh = dW = db = z_frag = None
-        g_rowT = trees.empty_row_ptr() if ctx.no_adj else trees.rowT_ptr
+        g_ellT = trees.empty_ell() if ctx.no_adj else trees.ellT
         want_w = (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and s_frag is not None
         if ctx.needs_input_grad[0]:
             dh = torch.empty((B, T, Din), dtype=ctx.h_dtype, device=dev)
@@ -84,8 +84,8 @@ class _GCNLayerFn(torch.autograd.Function):
             dW = torch.empty((H, Din), dtype=torch.float32, device=dev)     # cleared by bwd_data, filled by bwd_weight
             db = torch.empty((H,), dtype=torch.float32, device=dev)
         if dh is not None or want_w:
-            _lib.check(L.gcnpt_layer_bwd_data(st, _lib.ptr(gout), _lib.ptr(out), gd, _lib.ptr(w_bwd), _lib.ptr(trees.row_ptr),
-                                              _lib.ptr(g_rowT), _lib.ptr(trees.colT_idx), B, T, Din, H, _lib.ptr(dh),
+            _lib.check(L.gcnpt_layer_bwd_data(st, _lib.ptr(gout), _lib.ptr(out), gd, _lib.ptr(w_bwd), _lib.ptr(trees.ell),
+                                              _lib.ptr(trees.rowT_ptr), _lib.ptr(trees.colT_idx), _lib.ptr(g_ellT), B, T, Din, H, _lib.ptr(dh),
                                               _lib.dtype_code(ctx.h_dtype), ctx.compute, ctx.scale, _lib.ptr(z_frag),
                                               _lib.ptr(dW), _lib.ptr(db)))
         if want_w:

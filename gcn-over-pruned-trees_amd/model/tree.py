@@ -41,14 +41,16 @@ class PrunedTrees(object):
     CSR pattern of the batch adjacency in HBM (layout: include/gcnpt.h).
 
     row_ptr  int32 [B*(T+1)]   col_idx / label  int32 [B*cap]   rowT_ptr / colT_idx: transposed pattern
+    ell / ellT int32 [B*T*8]   ELL heads: entry count + first 7 columns of every row (what the layer kernels read first)
     pool_mask bool [B,T,1]     the `mask` GCN.forward returns (model/gcn.py:262)
     status   int32 [B+1]       per-sentence code, [B] = longest sentence seen
     """
 
-    def __init__(self, B, T, cap, row_ptr, col_idx, label, rowT_ptr, colT_idx, pool_mask, status):
+    def __init__(self, B, T, cap, row_ptr, col_idx, label, rowT_ptr, colT_idx, ell, ellT, pool_mask, status):
         self.B, self.T, self.cap = B, T, cap
         self.row_ptr, self.col_idx, self.label = row_ptr, col_idx, label
         self.rowT_ptr, self.colT_idx = rowT_ptr, colT_idx
+        self.ell, self.ellT = ell, ellT
         self.pool_mask, self.status = pool_mask, status
         self._empty = None
 
@@ -56,10 +58,10 @@ class PrunedTrees(object):
     def device(self):
         return self.row_ptr.device
 
-    def empty_row_ptr(self):
-        """row_ptr of an adjacency with no entries (the `no_adj` ablation, model/gcn.py:264-265)."""
+    def empty_ell(self):
+        """ELL head of an adjacency with no entries (the `no_adj` ablation, model/gcn.py:264-265)."""
         if self._empty is None:
-            self._empty = torch.zeros_like(self.row_ptr)
+            self._empty = torch.zeros_like(self.ell)
         return self._empty
 
     def check(self, expect_maxlen=None):
@@ -97,9 +99,11 @@ def _alloc(B, T, cap, device, want_label, want_transpose):
     label = torch.empty((B * cap,), **i32) if want_label else None
     rowT_ptr = torch.empty((B * (T + 1),), **i32) if want_transpose else None
     colT_idx = torch.empty((B * cap,), **i32) if want_transpose else None
+    ell = torch.empty((B * T * 8,), **i32)
+    ellT = torch.empty((B * T * 8,), **i32) if want_transpose else None
     pool_mask = torch.empty((B, T, 1), dtype=torch.bool, device=device)
     status = torch.empty((B + 1,), **i32)
-    return row_ptr, col_idx, label, rowT_ptr, colT_idx, pool_mask, status
+    return row_ptr, col_idx, label, rowT_ptr, colT_idx, ell, ellT, pool_mask, status
 
 
 def _i64(t, name):
@@ -130,12 +134,12 @@ def prune_to_csr(head, subj_pos, obj_pos, deprel, prune_k, masks=None, lens=None
         lens = lens.to(device=head.device, dtype=torch.int32).contiguous()
     cap = 3 * T
     bufs = _alloc(B, T, cap, head.device, want_label, True)
-    row_ptr, col_idx, label, rowT_ptr, colT_idx, pool_mask, status = bufs
+    row_ptr, col_idx, label, rowT_ptr, colT_idx, ell, ellT, pool_mask, status = bufs
     _lib.check(_lib.lib().gcnpt_prune_to_csr(
         _lib.stream(), _lib.ptr(head), _lib.ptr(subj_pos), _lib.ptr(obj_pos), _lib.ptr(deprel),
         _lib.ptr(masks) if masks is not None else None, _lib.ptr(lens) if masks is None else None,
         B, T, int(prune_k), cap, _lib.ptr(row_ptr), _lib.ptr(col_idx), _lib.ptr(label), _lib.ptr(rowT_ptr),
-        _lib.ptr(colT_idx), _lib.ptr(pool_mask), _lib.ptr(status)))
+        _lib.ptr(colT_idx), _lib.ptr(ell), _lib.ptr(ellT), _lib.ptr(pool_mask), _lib.ptr(status)))
     return PrunedTrees(B, T, cap, *bufs)
 
 
@@ -147,10 +151,10 @@ def adj_to_csr(adj, want_label=True):
     B, T, _ = adj.shape
     cap = T * T
     bufs = _alloc(B, T, cap, adj.device, want_label, True)
-    row_ptr, col_idx, label, rowT_ptr, colT_idx, pool_mask, status = bufs
+    row_ptr, col_idx, label, rowT_ptr, colT_idx, ell, ellT, pool_mask, status = bufs
     _lib.check(_lib.lib().gcnpt_adj_to_csr(_lib.stream(), _lib.ptr(adj), B, T, cap, _lib.ptr(row_ptr), _lib.ptr(col_idx),
-                                           _lib.ptr(label), _lib.ptr(rowT_ptr), _lib.ptr(colT_idx), _lib.ptr(pool_mask),
-                                           _lib.ptr(status)))
+                                           _lib.ptr(label), _lib.ptr(rowT_ptr), _lib.ptr(colT_idx), _lib.ptr(ell), _lib.ptr(ellT),
+                                           _lib.ptr(pool_mask), _lib.ptr(status)))
     return PrunedTrees(B, T, cap, *bufs)
 
 

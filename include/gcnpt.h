@@ -24,6 +24,10 @@
  *   label    int32 [B*cap]     the value tree_to_adj writes (deprel id / +42 / 84), optional
  *   rowT_ptr/colT_idx          the same for the transposed pattern (needed by backward)
  *   cap >= 3*T for pruned trees (nnz = 3n-2), cap = T*T for an arbitrary dense adjacency.
+ *   ell      int32 [B*T*8]     "ELL head" of every row: ell[8r] = number of entries of row r (its degree incl. the
+ *                              diagonal), ell[8r+1 .. 8r+7] = its first 7 columns (unused slots 0).  A kept token of a
+ *                              pruned tree has <= 3-4 entries, so a 32-row tile's whole adjacency is one coalesced
+ *                              1-KiB load; rows with more entries continue in row_ptr/col_idx.   ellT: transposed.
  */
 #ifndef GCNPT_H
 #define GCNPT_H
@@ -65,7 +69,7 @@ const char* gcnpt_last_error(void);
  *   head, subj_pos, obj_pos, deprel  [dev] int64 [B,T]   exactly the loader tensors (data/loader.py:111-121)
  *   pad_mask  [dev] uint8/bool [B,T], non-zero = pad (model/gcn.py:96); may be NULL if `len` is given
  *   len       [dev] int32 [B], used when pad_mask is NULL
- *   label, rowT_ptr, colT_idx may be NULL (not produced)
+ *   label, rowT_ptr + colT_idx + ellT may be NULL (not produced); ell is required
  *   pool_mask [dev] uint8 [B*T]: 1 where (row sum + column sum == 0), the mask GCN.forward returns (gcn.py:262)
  *   status    [dev] int32 [B+1]: status[b] = 0 or GCNPT_E_* for sentence b (its rows are then empty);
  *             status[B] = max sentence length seen (the reference needs it to equal T, gcn.py:97,269)
@@ -73,13 +77,15 @@ const char* gcnpt_last_error(void);
 int gcnpt_prune_to_csr(void* stream, const int64_t* head, const int64_t* subj_pos, const int64_t* obj_pos,
                        const int64_t* deprel, const uint8_t* pad_mask, const int32_t* len, int B, int T,
                        int prune_k, int cap, int32_t* row_ptr, int32_t* col_idx, int32_t* label,
-                       int32_t* rowT_ptr, int32_t* colT_idx, uint8_t* pool_mask, int32_t* status);
+                       int32_t* rowT_ptr, int32_t* colT_idx, int32_t* ell, int32_t* ellT, uint8_t* pool_mask,
+                       int32_t* status);
 
 /* ---- A5: model/gcn.py:260-262 on an explicit dense adjacency (GCN.forward(adj, inputs)) ----------------
  * adj [dev] float32 [B,T,T] -> CSR of (adj != 0) and of its transpose, pool_mask as above.  cap >= max nnz
  * per sentence (T*T always suffices); status[b] = GCNPT_E_CAPACITY when exceeded. */
 int gcnpt_adj_to_csr(void* stream, const float* adj, int B, int T, int cap, int32_t* row_ptr, int32_t* col_idx,
-                     int32_t* label, int32_t* rowT_ptr, int32_t* colT_idx, uint8_t* pool_mask, int32_t* status);
+                     int32_t* label, int32_t* rowT_ptr, int32_t* colT_idx, int32_t* ell, int32_t* ellT,
+                     uint8_t* pool_mask, int32_t* status);
 
 /* inverse of the above for callers that want the reference's dense float32 [B,T,T] adjacency
  * (model/gcn.py:106-108); adj is fully overwritten. */
@@ -111,13 +117,14 @@ size_t gcnpt_frag_bytes(int rows, int width, int dtype);
  *                 GCNPT_F32 (exact fp32 MFMA; h/out must be f32).
  * drop_p in [0,1): 0 disables dropout (eval mode / last layer, gcn.py:393); otherwise element e of the
  * output is kept iff hash(seed, e) >= drop_p and scaled by 1/(1-drop_p).
- * deg_row_ptr: NULL, or the row_ptr whose row lengths give deg when the aggregated pattern differs from it
- * (the `no_adj` ablation, gcn.py:264-265: denominators from the real adjacency, aggregation over an empty one).
+ * row_ptr/col_idx/ell describe the aggregated pattern.  deg_ell: NULL, or the ELL head whose degrees are used when
+ * they differ from the aggregated pattern's (the `no_adj` ablation, gcn.py:264-265: denominators from the real
+ * adjacency, aggregation over an empty one = an all-zero ell).
  * s_frag: NULL (inference), or gcnpt_frag_bytes(B*T, Din, compute_dtype) bytes that receive the fragment image
  * of S = (A+I) h for gcnpt_layer_bwd_weight. */
 int gcnpt_layer_fwd(void* stream, const void* h, int h_dtype, const void* w_fwd, const float* bias,
-                    const int32_t* row_ptr, const int32_t* col_idx, const int32_t* deg_row_ptr, int B, int T,
-                    int Din, int H, void* out, int out_dtype, int compute_dtype, float drop_p, uint64_t seed,
+                    const int32_t* row_ptr, const int32_t* col_idx, const int32_t* ell, const int32_t* deg_ell, int B,
+                    int T, int Din, int H, void* out, int out_dtype, int compute_dtype, float drop_p, uint64_t seed,
                     void* s_frag);
 
 /* ---- A7: autograd of A6 -----------------------------------------------------------------------------------
@@ -125,16 +132,16 @@ int gcnpt_layer_fwd(void* stream, const void* h, int h_dtype, const void* w_fwd,
  * already carries the dropout zeros; scale = 1/(1-drop_p)):
  *   data   : dh[r,:]  = (sum_{c in rowT r} dZ[c,:] + dZ[r,:]) . W                  -> [B*T, Din] of dh_dtype
  *   weight : dW       = dZ^T ((A+I) h)   [H,Din] float32,   db = 2 * sum_r dZ[r,:]  [H] float32
- * gcnpt_layer_bwd_data: dY and Y share g_dtype; row_ptr is the forward pattern (degrees), rowT_* the transposed
- * one.  dh may be NULL (input needs no gradient).  z_frag: NULL or gcnpt_frag_bytes(B*T, H, compute_dtype) bytes
+ * gcnpt_layer_bwd_data: dY and Y share g_dtype; ell is the forward pattern's ELL head (degrees), rowT_ptr /
+ * colT_idx / ellT the transposed pattern that is aggregated over.  dh may be NULL (input needs no gradient).  z_frag: NULL or gcnpt_frag_bytes(B*T, H, compute_dtype) bytes
  * receiving the fragment image of dZ; zero_dW [H*Din] / zero_db [H]: NULL or the accumulators the FOLLOWING
  * gcnpt_layer_bwd_weight adds into, cleared here so that no separate memset is needed.
  * gcnpt_layer_bwd_weight: streams the two fragment images (z_frag from bwd_data, s_frag from fwd) and adds the
  * K-slices into dW/db with float atomics; dW/db must be zero on entry (see zero_dW/zero_db above). */
 int gcnpt_layer_bwd_data(void* stream, const void* dY, const void* Y, int g_dtype, const void* w_bwd,
-                         const int32_t* row_ptr, const int32_t* rowT_ptr, const int32_t* colT_idx, int B, int T,
-                         int Din, int H, void* dh, int dh_dtype, int compute_dtype, float scale, void* z_frag,
-                         float* zero_dW, float* zero_db);
+                         const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx, const int32_t* ellT,
+                         int B, int T, int Din, int H, void* dh, int dh_dtype, int compute_dtype, float scale,
+                         void* z_frag, float* zero_dW, float* zero_db);
 int gcnpt_layer_bwd_weight(void* stream, const void* z_frag, const void* s_frag, int B, int T, int Din, int H,
                            float* dW, float* db, int compute_dtype);
 

@@ -93,6 +93,17 @@ def _oracle_mask(adj):
     return ((A.sum(2) + A.sum(1)) == 0)[..., None]
 
 
+def _check_ell(trees, dense):
+    """ELL heads (include/gcnpt.h): [8r] = entries of row r, [8r+1..8r+7] = its first 7 columns; same for the transpose."""
+    B, T = trees.B, trees.T
+    for ell, A in ((trees.ell, dense != 0), (trees.ellT, dense.transpose(0, 2, 1) != 0)):
+        e = ell.view(B, T, 8).cpu().numpy()
+        np.testing.assert_array_equal(e[:, :, 0], A.sum(2))
+        order = np.argsort(~A, axis=2, kind="stable")[:, :, :7]            # columns of the non-zeros first, ascending
+        have = np.arange(7)[None, None, :] < A.sum(2)[:, :, None]
+        np.testing.assert_array_equal(np.where(have, e[:, :, 1:], 0), np.where(have, order, 0))
+
+
 # ---------------------------------------------------------------------------------------------------
 # pruner (A1-A4): exact
 # ---------------------------------------------------------------------------------------------------
@@ -108,6 +119,7 @@ def test_pruner_golden(api, dev, name, Ks):
         np.testing.assert_array_equal(got, want)
         assert (trees.status.cpu().numpy()[:B] == 0).all()
         np.testing.assert_array_equal(trees.pool_mask.cpu().numpy(), _oracle_mask(want))
+        _check_ell(trees, want)
         # transposed pattern == pattern of the transposed matrix
         tr = tree.adj_to_csr(_t(np.ascontiguousarray(want.transpose(0, 2, 1)), dev))
         a = trees.rowT_ptr.view(B, T + 1).cpu().numpy() - (np.arange(B) * trees.cap)[:, None]
@@ -172,6 +184,7 @@ def test_pruner_vs_oracle_full_size(api, dev, B, T, K, lengths):
     trees = _prune(tree, g, K, dev)
     np.testing.assert_array_equal(trees.to_dense().cpu().numpy(), want["adj"])
     np.testing.assert_array_equal(trees.pool_mask.cpu().numpy(), _oracle_mask(want["adj"]))
+    _check_ell(trees, want["adj"])
     # nnz = 3n - 2 for an n-node tree with at least one edge
     n = want["kept"].sum(1).astype(np.int64)
     nnz = trees.nnz().cpu().numpy()
@@ -190,6 +203,7 @@ def test_dense_adjacency_roundtrip(api, dev):
     trees = tree.adj_to_csr(_t(adj, dev))
     np.testing.assert_array_equal(trees.to_dense().cpu().numpy(), adj)
     np.testing.assert_array_equal(trees.pool_mask.cpu().numpy(), _oracle_mask(adj))
+    _check_ell(trees, adj)                                            # rows with > 7 entries: count is the full degree
     assert (trees.status.cpu().numpy()[:5] == 0).all()
 
 

@@ -7,7 +7,7 @@ bench.py -- BASELINE.json metric: GCN-layer fwd+bwd sentences/sec at batch=50 se
 One "step" = the hot path over one synthetic TACRED-shaped batch of 50 sentences x 100 tokens
 (BASELINE.json configs[1]: 2-layer GCN, no LSTM, Din 360 -> 200 -> 200, prune_k 1, bf16 storage,
 fp32 accumulation, dropout 0.5 between the layers), entirely through the C-ABI of include/gcnpt.h:
-    pack W0,W1 -> layer0 fwd -> layer1 fwd -> layer1 bwd (data, weight) -> layer0 bwd (data, weight)
+    pack W0+W1 (one launch) -> layer0 fwd -> layer1 fwd -> layer1 bwd-data -> [layer1 bwd-weight || layer0 bwd-data] -> layer0 bwd-weight
 Inputs (x, gy, weights, the loader's integer tensors) are resident in HBM before the timed region.
 `value` is the layer stack alone, as the metric says; `with_prune` repeats the measurement with the
 pruned-tree adjacency build (gcnpt_prune_to_csr) inside every step.
@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--lengths", choices=["full", "tacred"], default="full")
     ap.add_argument("--drop", type=float, default=0.5)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
+                    help="2 = run layer-1 bwd-weight beside layer-0 bwd-data (and the tree build beside the pack) on a side stream; "
+                         "measured slower than 1 on MI355X: the cross-stream graph edges cost more than the overlap gains")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-kernel-breakdown", action="store_true")
@@ -94,6 +97,7 @@ class Stack(object):
         self.trees.check(expect_maxlen=T)
         self.nnz = int(self.trees.nnz().sum())
         self.scale = 1.0 / (1.0 - args.drop) if args.drop > 0 else 1.0
+        self.side = torch.cuda.Stream(device=dev)
 
     def grads(self, k):
         H, Din = self.H, self.Din
@@ -112,6 +116,16 @@ class Stack(object):
         P = self._lib.ptr
         H, Din = self.W[l].shape
         self._lib.check(self.L.gcnpt_pack_weights(self._lib.stream(), P(self.W[l]), H, Din, self.compute, P(self.wf[l]), P(self.wb[l])))
+
+    def pack_all(self):
+        """Both layers' weights -> MFMA fragment order in ONE launch."""
+        n = len(self.W)
+        arr = lambda vals, ty: (ty * n)(*vals)  # noqa: E731
+        vp = ctypes.c_void_p
+        self._lib.check(self.L.gcnpt_pack_weights_multi(
+            self._lib.stream(), n, arr([w.data_ptr() for w in self.W], vp), arr([w.shape[0] for w in self.W], ctypes.c_int),
+            arr([w.shape[1] for w in self.W], ctypes.c_int), self.compute, arr([t.data_ptr() for t in self.wf], vp),
+            arr([t.data_ptr() for t in self.wb], vp)))
 
     def fwd(self, l):
         P, tr = self._lib.ptr, self.trees
@@ -144,12 +158,35 @@ class Stack(object):
                                                       P(dW), P(db), self.compute))
 
     def step(self, k=0, with_prune=False):
+        """
+        One step.  With --streams 2: the weight gradient of layer 1 only needs layer 1's dZ image, so it runs beside the
+        backward-data kernel of layer 0; the tree build only needs the loader tensors, so it runs beside the weight pack.
+        Every kernel of the step is still launched and finished inside the step (fork and join are inside it).
+        """
+        if self.args.streams == 1:
+            if with_prune:
+                self.prune()
+            self.pack_all()
+            self.fwd(0); self.fwd(1)
+            self.bwd_data(1, k); self.bwd_weight(1, k)
+            self.bwd_data(0, k); self.bwd_weight(0, k)
+            return
+        main = torch.cuda.current_stream()
+        side = self.side
         if with_prune:
-            self.prune()
-        self.pack(0); self.pack(1)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self.prune()
+        self.pack_all()
+        if with_prune:
+            main.wait_stream(side)
         self.fwd(0); self.fwd(1)
-        self.bwd_data(1, k); self.bwd_weight(1, k)
+        self.bwd_data(1, k)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self.bwd_weight(1, k)
         self.bwd_data(0, k); self.bwd_weight(0, k)
+        main.wait_stream(side)
 
     # ---- algorithmic bytes per launch (DESIGN.md "Measurement"; SURVEY.md 8d) ----
     def algorithmic_bytes(self):
@@ -162,7 +199,7 @@ class Stack(object):
             out["fwd%d" % l] = e * N * (Din + H) + wp + 4 * H + csr + self.sf[l].numel()
             out["bwd_data%d" % l] = e * N * (2 * H + Din) + self.wb[l].numel() + 2 * csr + self.zf[l].numel() + 4 * (H * Din + H)
             out["bwd_weight%d" % l] = self.zf[l].numel() + self.sf[l].numel() + 4 * (H * Din + H)
-            out["pack%d" % l] = 4 * H * Din + self.wf[l].numel() + self.wb[l].numel()
+            out["pack"] = out.get("pack", 0) + 4 * H * Din + self.wf[l].numel() + self.wb[l].numel()
         out["prune"] = 4 * 8 * N + N + 2 * (csr + 4 * B * (T + 1) + 4 * self.nnz) + N + 4 * (B + 1)
         return out
 
@@ -205,7 +242,7 @@ def timed(run, steps, warmup, barrier):
 
 def kernel_breakdown(stack, use_graph, reps=50, rounds=20):
     """Average duration of each kernel of the step: `reps` back-to-back launches replayed as one hipGraph, HIP events around it."""
-    calls = [("pack0", lambda: stack.pack(0)), ("pack1", lambda: stack.pack(1)), ("fwd0", lambda: stack.fwd(0)),
+    calls = [("pack", stack.pack_all), ("fwd0", lambda: stack.fwd(0)),
              ("fwd1", lambda: stack.fwd(1)), ("bwd_data1", lambda: stack.bwd_data(1)), ("bwd_weight1", lambda: stack.bwd_weight(1)),
              ("bwd_data0", lambda: stack.bwd_data(0)), ("bwd_weight0", lambda: stack.bwd_weight(0)), ("prune", stack.prune)]
     stack.step()

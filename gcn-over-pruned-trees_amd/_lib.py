@@ -22,6 +22,7 @@ SIGNATURES = {
     "gcnpt_csr_to_adj": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "gcnpt_packed_bytes": (_sz, [_i, _i, _i]),
     "gcnpt_pack_weights": (_i, [_p, _p, _i, _i, _i, _p, _p]),
+    "gcnpt_pack_weights_multi": (_i, [_p, _i, _p, _p, _p, _i, _p, _p]),
     "gcnpt_frag_bytes": (_sz, [_i, _i, _i]),
     "gcnpt_layer_fwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _f, _u64, _p]),
     "gcnpt_layer_bwd_data": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _f, _p, _p, _p]),

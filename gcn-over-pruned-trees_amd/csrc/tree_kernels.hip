@@ -15,7 +15,7 @@
 
 namespace gcnpt {
 
-constexpr int PRUNE_THREADS = 128;
+constexpr int PRUNE_THREADS = 64;    // ONE wave per sentence: phases are separated by wave-local LDS ordering only
 constexpr int ADJ_THREADS = 256;
 
 enum : int {
@@ -24,7 +24,7 @@ enum : int {
 enum : int { K_KEEP = 1, K_CHILD = 2 };
 enum : int { ERR_CHAIN_BADHEAD = 1, ERR_CHAIN_CYCLE = 2, ERR_BADHEAD = 4, ERR_CYCLE = 8, ERR_ASSERT = 16 };
 
-// exclusive scan of a[0..n) in place, a[n] = total; `scratch` holds blockDim.x ints
+// exclusive scan of a[0..n) in place, a[n] = total; `scratch` holds blockDim.x ints (any block size)
 __device__ void block_exclusive_scan(int* a, int n, int* scratch) {
     const int t = threadIdx.x, nt = blockDim.x;
     const int seg = (n + nt - 1) / nt;
@@ -44,6 +44,34 @@ __device__ void block_exclusive_scan(int* a, int n, int* scratch) {
     __syncthreads();
 }
 
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+}
+// exclusive scan of a[0..n) in place by ONE wave (lane l owns the contiguous segment l); returns the total
+__device__ __forceinline__ int wave_exclusive_scan(int* a, int n, int lane) {
+    const int seg = (n + WAVE - 1) / WAVE;
+    const int lo = min(n, lane * seg), hi = min(n, lo + seg);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += a[i];
+    int inc = s;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const int u = __shfl_up(inc, o);
+        if (lane >= o) inc += u;
+    }
+    const int total = __shfl(inc, WAVE - 1);
+    int run = inc - s;
+    for (int i = lo; i < hi; ++i) { const int v = a[i]; a[i] = run; run += v; }
+    return total;
+}
+
 __global__ __launch_bounds__(PRUNE_THREADS) void prune_to_csr_kernel(
     const int64_t* __restrict__ head, const int64_t* __restrict__ subj_pos, const int64_t* __restrict__ obj_pos,
     const int64_t* __restrict__ deprel, const uint8_t* __restrict__ pad_mask, const int32_t* __restrict__ len_in,
@@ -57,45 +85,48 @@ __global__ __launch_bounds__(PRUNE_THREADS) void prune_to_csr_kernel(
     int* flg = cnt + T;            // [T]   F_* bits
     int* deg = flg + T;            // [T+1] row degree -> row offsets
     int* degT = deg + T + 1;       // [T+1] column degree -> transposed row offsets
-    int* scratch = degT + T + 1;   // [PRUNE_THREADS]
-    __shared__ int s_len, s_nent, s_nsubj, s_err, s_lca;
+    int* klist = degT + T + 1;     // [T+1] tokens that carry an edge, ascending (compacted)
+    int* lab = klist + T + 1;      // [T]   deprel id of the token
+    __shared__ int s_err;
 
-    const int b = blockIdx.x, t = threadIdx.x, NT = PRUNE_THREADS;
+    const int b = blockIdx.x, lane = threadIdx.x;
     const size_t base = (size_t)b * T;
-    if (t == 0) { s_len = 0; s_nent = 0; s_nsubj = 0; s_err = 0; s_lca = 0x7fffffff; }
-    __syncthreads();
+    if (lane == 0) s_err = 0;
 
-    // ---- sentence length = number of non-pad slots (gcn.py:96)
-    if (pad_mask) {
-        int c = 0;
-        for (int i = t; i < T; i += NT) c += pad_mask[base + i] == 0;
-        if (c) atomicAdd(&s_len, c);
-    } else if (t == 0) {
-        s_len = min(max(len_in[b], 0), T);
+    // ---- stage the parse (tree.py:60-63, 82-83): every load is unconditional and issued before the first use
+    //      (a load behind `if (i < len)` would be a dependent round trip per token)
+    int npad = 0;
+    for (int i = lane; i < T; i += WAVE) {
+        const int64_t h = head[base + i];
+        const int64_t sp = subj_pos[base + i], op = obj_pos[base + i], d = deprel[base + i];
+        const bool pad = pad_mask ? pad_mask[base + i] != 0 : false;
+        npad += pad ? 1 : 0;
+        int f = 0;
+        if (sp == 0) f |= F_SUBJ;
+        if (op == 0) f |= F_OBJ;
+        if (d != 0) f |= F_FWD_NZ;                     // adj[p,c] = deprel[c]        survives `adj != 0`
+        if (d + FWD_BOUND != 0) f |= F_REV_NZ;         // adj[c,p] = deprel[c] + 42
+        par[i] = h > 0 ? (int)min(h - 1, (int64_t)0x3fffffff) : -1;   // range-checked against len below
+        flg[i] = f; lab[i] = (int)d; cnt[i] = 0; deg[i] = 0; degT[i] = 0;
     }
-    __syncthreads();
-    const int len = s_len;
-    if (t == 0) atomicMax(&status[B], len);
-
-    // ---- stage the parse in LDS (tree.py:60-63, 82-83)
-    for (int i = t; i < T; i += NT) {
-        int f = 0, p = -1;
-        if (i < len) {
-            const int64_t h = head[base + i];
-            if (h > 0) p = (h - 1 < len) ? (int)(h - 1) : -2;
-            if (subj_pos[base + i] == 0) { f |= F_SUBJ; atomicAdd(&s_nsubj, 1); atomicAdd(&s_nent, 1); }
-            if (obj_pos[base + i] == 0) { f |= F_OBJ; atomicAdd(&s_nent, 1); }
-            const int64_t d = deprel[base + i];
-            if (d != 0) f |= F_FWD_NZ;                 // adj[p,c] = deprel[c]        survives `adj != 0`
-            if (d + FWD_BOUND != 0) f |= F_REV_NZ;     // adj[c,p] = deprel[c] + 42
-        }
-        par[i] = p; cnt[i] = 0; flg[i] = f; deg[i] = 0; degT[i] = 0;
+    // sentence length = number of non-pad slots (gcn.py:96)
+    const int len = pad_mask ? T - wave_sum(npad) : min(max(len_in[b], 0), T);
+    if (lane == 0) atomicMax(&status[B], len);
+    int nsubj = 0, nent = 0;
+    for (int i = lane; i < T; i += WAVE) {
+        int f = flg[i], p = par[i];
+        if (i >= len) { f = 0; p = -1; }
+        else if (p >= len) p = -2;
+        nsubj += (f & F_SUBJ) ? 1 : 0;
+        nent += ((f & F_SUBJ) ? 1 : 0) + ((f & F_OBJ) ? 1 : 0);
+        flg[i] = f; par[i] = p;
     }
+    nsubj = wave_sum(nsubj);
+    nent = wave_sum(nent);
     __syncthreads();
-    const int nent = s_nent;
 
     // ---- every entity token walks to the root, counting visits (tree.py:86-109)
-    for (int i = t; i < len; i += NT) {
+    for (int i = lane; i < len; i += WAVE) {
         const int f = flg[i];
         const int w = ((f & F_SUBJ) ? 1 : 0) + ((f & F_OBJ) ? 1 : 0);
         if (!w) continue;
@@ -111,31 +142,31 @@ __global__ __launch_bounds__(PRUNE_THREADS) void prune_to_csr_kernel(
     int err = 0;
     if (s_err & ERR_CHAIN_BADHEAD) err = GCNPT_E_BAD_HEAD;
     else if (s_err & ERR_CHAIN_CYCLE) err = GCNPT_E_CYCLE;
-    else if (s_nsubj == 0) err = GCNPT_E_NO_SUBJECT;
+    else if (nsubj == 0) err = GCNPT_E_NO_SUBJECT;
 
     // ---- common ancestors and the lowest of them (tree.py:112-124)
+    int lca = 0x7fffffff;
     if (!err) {
-        for (int i = t; i < len; i += NT)
+        for (int i = lane; i < len; i += WAVE)
             if (cnt[i] == nent) flg[i] |= F_CA;
         __syncthreads();
-        for (int i = t; i < len; i += NT) {
+        for (int i = lane; i < len; i += WAVE) {
             const int p = par[i];
             if ((flg[i] & F_CA) && p >= 0 && (flg[p] & F_CA)) atomicOr(&flg[p], F_CA_HASCHILD);
         }
         __syncthreads();
-        for (int i = t; i < len; i += NT)
-            if ((flg[i] & (F_CA | F_CA_HASCHILD)) == F_CA) atomicMin(&s_lca, i);
-        __syncthreads();
-        if (s_lca == 0x7fffffff) err = GCNPT_E_NO_LCA;
+        for (int i = lane; i < len; i += WAVE)
+            if ((flg[i] & (F_CA | F_CA_HASCHILD)) == F_CA) lca = min(lca, i);
+        lca = wave_min(lca);
+        if (lca == 0x7fffffff) err = GCNPT_E_NO_LCA;
     }
-    const int lca = s_lca;
 
     // ---- path nodes, distance to the path, kept tokens (tree.py:126-147)
     if (!err) {
-        for (int i = t; i < len; i += NT)
+        for (int i = lane; i < len; i += WAVE)
             if ((cnt[i] > 0 && !(flg[i] & F_CA)) || i == lca) flg[i] |= F_PATH;
         __syncthreads();
-        for (int i = t; i < len; i += NT) {
+        for (int i = lane; i < len; i += WAVE) {
             int a = i, d = 0;
             while (a >= 0 && !(flg[a] & F_PATH)) {
                 a = par[a];
@@ -153,7 +184,7 @@ __global__ __launch_bounds__(PRUNE_THREADS) void prune_to_csr_kernel(
 
     // ---- degrees of the labelled adjacency tree_to_adj would write (tree.py:182-192)
     if (!err) {
-        for (int i = t; i < len; i += NT) {
+        for (int i = lane; i < len; i += WAVE) {
             if (!(cnt[i] & K_CHILD)) continue;
             const int p = par[i], f = flg[i];
             if (!(cnt[p] & K_KEEP)) atomicOr(&s_err, ERR_ASSERT);   // tree.py:159
@@ -165,40 +196,51 @@ __global__ __launch_bounds__(PRUNE_THREADS) void prune_to_csr_kernel(
         __syncthreads();
         if (s_err & ERR_ASSERT) err = GCNPT_E_ASSERT;
     }
+    int n_edge_rows = 0;
     if (!err) {
-        for (int i = t; i < T; i += NT) {
-            if (i < len && (flg[i] & F_HASEDGE)) { deg[i] += 1; degT[i] += 1; }   // the 84 on the diagonal
+        for (int i = lane; i < T; i += WAVE) {
+            const int he = (i < len && (flg[i] & F_HASEDGE)) ? 1 : 0;
+            deg[i] += he; degT[i] += he;                             // the 84 on the diagonal
+            klist[i] = he;
+            if (pool_mask) pool_mask[base + i] = (deg[i] + degT[i]) == 0;   // gcn.py:262
         }
         __syncthreads();
-        if (pool_mask)
-            for (int i = t; i < T; i += NT) pool_mask[base + i] = (deg[i] + degT[i]) == 0;   // gcn.py:262
+        const int tot = wave_exclusive_scan(deg, T, lane);
+        const int totT = wave_exclusive_scan(degT, T, lane);
+        n_edge_rows = wave_exclusive_scan(klist, T, lane);           // klist[i] = rank of token i among the edge rows
+        if (lane == 0) { deg[T] = tot; degT[T] = totT; }
         __syncthreads();
-        block_exclusive_scan(deg, T, scratch);
-        block_exclusive_scan(degT, T, scratch);
-        if (deg[T] > cap || degT[T] > cap) err = GCNPT_E_CAPACITY;
+        if (tot > cap || totT > cap) err = GCNPT_E_CAPACITY;
     }
 
     if (err) {   // the sentence contributes no edges; every row is empty and masked
-        for (int i = t; i <= T; i += NT) {
+        for (int i = lane; i <= T; i += WAVE) {
             row_ptr[(size_t)b * (T + 1) + i] = b * cap;
             if (rowT_ptr) rowT_ptr[(size_t)b * (T + 1) + i] = b * cap;
         }
-        if (pool_mask)
-            for (int i = t; i < T; i += NT) pool_mask[base + i] = 1;
-        for (int i = t; i < T * 8; i += NT) {
+        for (int i = lane; i < T; i += WAVE)
+            if (pool_mask) pool_mask[base + i] = 1;
+        for (int i = lane; i < T * 8; i += WAVE) {
             ell[base * 8 + i] = 0;
             if (ellT) ellT[base * 8 + i] = 0;
         }
-        if (t == 0) status[b] = err;
+        if (lane == 0) status[b] = err;
         return;
     }
 
     // ---- emit both patterns, columns ascending (same order a dense -> CSR conversion gives)
-    for (int i = t; i <= T; i += NT) {
+    for (int i = lane; i <= T; i += WAVE) {
         row_ptr[(size_t)b * (T + 1) + i] = b * cap + deg[i];
         if (rowT_ptr) rowT_ptr[(size_t)b * (T + 1) + i] = b * cap + degT[i];
     }
-    for (int r = t; r < T; r += NT) {
+    // compact the rows that carry an edge (ascending): only they, and only columns among them, have entries.
+    // klist[i] is the rank of token i among them; every such token writes itself at its rank.
+    int* elist = lab + T;          // [T]
+    for (int i = lane; i < len; i += WAVE)
+        if (flg[i] & F_HASEDGE) elist[klist[i]] = i;
+    __syncthreads();
+
+    for (int r = lane; r < T; r += WAVE) {
         int hd[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hdT[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ELL heads: count, first 7 columns
         const int rf = r < len ? flg[r] : 0;
         if (rf & F_HASEDGE) {
@@ -206,8 +248,8 @@ __global__ __launch_bounds__(PRUNE_THREADS) void prune_to_csr_kernel(
             const int rp = par[r];
             const int o0 = b * cap + deg[r], oT0 = b * cap + degT[r];
             int o = o0, oT = oT0;
-            auto put = [&](int j, int lab) {
-                col_idx[o] = j; if (label) label[o] = lab;
+            auto put = [&](int j, int lb) {
+                col_idx[o] = j; if (label) label[o] = lb;
                 if (o - o0 < 7) hd[1 + o - o0] = j;
                 ++o;
             };
@@ -216,17 +258,18 @@ __global__ __launch_bounds__(PRUNE_THREADS) void prune_to_csr_kernel(
                 if (oT - oT0 < 7) hdT[1 + oT - oT0] = j;
                 ++oT;
             };
-            for (int j = 0; j < len; ++j) {
+            for (int q = 0; q < n_edge_rows; ++q) {
+                const int j = elist[q];
                 const bool child = (cnt[j] & K_CHILD) && par[j] == r;
                 const int fj = flg[j];
                 if (child) {
-                    if (fj & F_FWD_NZ) put(j, (int)deprel[base + j]);
+                    if (fj & F_FWD_NZ) put(j, lab[j]);
                     if (fj & F_REV_NZ) putT(j);
                 } else if (j == r) {
                     put(r, SELF_LOOP_ID);
                     putT(r);
                 } else if (rchild && j == rp) {
-                    if (rf & F_REV_NZ) put(j, (int)deprel[base + r] + FWD_BOUND);
+                    if (rf & F_REV_NZ) put(j, lab[r] + FWD_BOUND);
                     if (rf & F_FWD_NZ) putT(j);
                 }
             }
@@ -241,7 +284,7 @@ __global__ __launch_bounds__(PRUNE_THREADS) void prune_to_csr_kernel(
             eT[1] = make_int4(hdT[4], hdT[5], hdT[6], hdT[7]);
         }
     }
-    if (t == 0) status[b] = 0;
+    if (lane == 0) status[b] = 0;
 }
 
 // ---- dense float adjacency -> CSR of (adj != 0) and of its transpose (gcn.py:260-262) -----------------
@@ -348,7 +391,7 @@ extern "C" int gcnpt_prune_to_csr(void* stream, const int64_t* head, const int64
         return fail(GCNPT_E_PRUNE_NEGATIVE, "prune_k=%d: the reference fork only works with prune_k >= 0 "
                     "(model/tree.py:194 reads Tree.head, which the unpruned branch never sets)", prune_k);
     if ((long long)B * cap > 0x7fffffffLL) return fail(GCNPT_E_UNSUPPORTED, "prune_to_csr: B*cap overflows int32");
-    const size_t lds = sizeof(int) * ((size_t)5 * T + 2 + PRUNE_THREADS);
+    const size_t lds = sizeof(int) * ((size_t)8 * T + 4);
     if (lds > 150 * 1024) return fail(GCNPT_E_UNSUPPORTED, "prune_to_csr: T=%d needs %zu B of LDS", T, lds);
     hipStream_t s = (hipStream_t)stream;
     GCNPT_HIP_CHECK(hipMemsetAsync(status + B, 0, sizeof(int32_t), s));

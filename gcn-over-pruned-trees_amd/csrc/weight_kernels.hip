@@ -14,17 +14,32 @@ constexpr int LAYER_THREADS = 256;
 //   forward image : B[k][n] = W[n][k]  (n over H,   k over Din)
 //   backward image: B[k][n] = W[k][n]  (n over Din, k over H)
 // ---------------------------------------------------------------------------------------------------
+constexpr int PACK_MAX_LAYERS = 8;
+struct PackParams {
+    const float* W[PACK_MAX_LAYERS];
+    uint4* wf[PACK_MAX_LAYERS];
+    uint4* wb[PACK_MAX_LAYERS];
+    int H[PACK_MAX_LAYERS], Din[PACK_MAX_LAYERS];
+    long long first[PACK_MAX_LAYERS + 1];      // fragment index range of each layer in the launch
+    int n_layers;
+};
+
+// one launch packs every layer of the stack (weights change once per optimizer step)
 template <typename CT>
-__global__ void pack_weights_kernel(const float* __restrict__ W, int H, int Din, uint4* __restrict__ wf,
-                                    uint4* __restrict__ wb) {
+__global__ void pack_weights_kernel(const PackParams p) {
     constexpr int KSTEP = sizeof(CT) == 2 ? 32 : 16;
     constexpr int PER = sizeof(CT) == 2 ? 8 : 4;
-    const int ksf = round_up(Din, KSTEP) / KSTEP, ntf = ceil_div(H, 16);
-    const int ksb = round_up(H, KSTEP) / KSTEP, ntb = ceil_div(Din, 16);
-    const long long nf = wf ? (long long)ntf * ksf * 64 : 0;
-    const long long nb = wb ? (long long)ntb * ksb * 64 : 0;
-    for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < nf + nb;
-         id += (long long)gridDim.x * blockDim.x) {
+    for (long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x; gid < p.first[p.n_layers];
+         gid += (long long)gridDim.x * blockDim.x) {
+        int l = 0;
+#pragma unroll
+        for (int i = 1; i < PACK_MAX_LAYERS; ++i) l += (i < p.n_layers && gid >= p.first[i]) ? 1 : 0;
+        const float* W = p.W[l];
+        const int H = p.H[l], Din = p.Din[l];
+        const int ksf = round_up(Din, KSTEP) / KSTEP, ntf = ceil_div(H, 16);
+        const int ksb = round_up(H, KSTEP) / KSTEP;
+        const long long nf = p.wf[l] ? (long long)ntf * ksf * 64 : 0;
+        const long long id = gid - p.first[l];
         const bool bwd = id >= nf;
         const long long f = bwd ? id - nf : id;
         const int ks_n = bwd ? ksb : ksf;
@@ -50,7 +65,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ W, int H, int Din,
         } else {
             u.x = __float_as_uint(v[0]); u.y = __float_as_uint(v[1]); u.z = __float_as_uint(v[2]); u.w = __float_as_uint(v[3]);
         }
-        (bwd ? wb : wf)[f] = u;
+        (bwd ? p.wb[l] : p.wf[l])[f] = u;
     }
 }
 
@@ -205,19 +220,33 @@ extern "C" size_t gcnpt_packed_bytes(int n_out, int k_in, int dtype) {
     return (size_t)ceil_div(n_out, 16) * ks * 64 * 16;
 }
 
-extern "C" int gcnpt_pack_weights(void* stream, const float* W, int H, int Din, int dtype, void* w_fwd, void* w_bwd) {
-    GCNPT_REQUIRE(W && (w_fwd || w_bwd), "pack_weights: null pointer");
-    GCNPT_REQUIRE(H > 0 && Din > 0, "pack_weights: H and Din must be positive");
+extern "C" int gcnpt_pack_weights_multi(void* stream, int n_layers, const float* const* W, const int* H, const int* Din,
+                                        int dtype, void* const* w_fwd, void* const* w_bwd) {
+    GCNPT_REQUIRE(n_layers >= 1 && n_layers <= PACK_MAX_LAYERS, "pack_weights: 1..%d layers per call", PACK_MAX_LAYERS);
+    GCNPT_REQUIRE(W && H && Din && w_fwd && w_bwd, "pack_weights: null pointer");
     GCNPT_REQUIRE(dtype == GCNPT_F32 || dtype == GCNPT_BF16, "pack_weights: dtype %d", dtype);
-    const size_t frags = (w_fwd ? gcnpt_packed_bytes(H, Din, dtype) : 0) / 16 + (w_bwd ? gcnpt_packed_bytes(Din, H, dtype) : 0) / 16;
-    const int grid = (int)((frags + 255) / 256);
+    PackParams p{};
+    p.n_layers = n_layers;
+    p.first[0] = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        GCNPT_REQUIRE(W[l] && (w_fwd[l] || w_bwd[l]), "pack_weights: null pointer (layer %d)", l);
+        GCNPT_REQUIRE(H[l] > 0 && Din[l] > 0, "pack_weights: H and Din must be positive (layer %d)", l);
+        p.W[l] = W[l]; p.H[l] = H[l]; p.Din[l] = Din[l];
+        p.wf[l] = static_cast<uint4*>(w_fwd[l]); p.wb[l] = static_cast<uint4*>(w_bwd[l]);
+        const size_t frags = (w_fwd[l] ? gcnpt_packed_bytes(H[l], Din[l], dtype) : 0) / 16 +
+                             (w_bwd[l] ? gcnpt_packed_bytes(Din[l], H[l], dtype) : 0) / 16;
+        p.first[l + 1] = p.first[l] + (long long)frags;
+    }
+    const int grid = (int)((p.first[n_layers] + 255) / 256);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == GCNPT_BF16)
-        hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, W, H, Din, (uint4*)w_fwd, (uint4*)w_bwd);
-    else
-        hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(grid), dim3(256), 0, s, W, H, Din, (uint4*)w_fwd, (uint4*)w_bwd);
+    if (dtype == GCNPT_BF16) hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(grid), dim3(256), 0, s, p);
     GCNPT_HIP_CHECK(hipGetLastError());
     return GCNPT_OK;
+}
+
+extern "C" int gcnpt_pack_weights(void* stream, const float* W, int H, int Din, int dtype, void* w_fwd, void* w_bwd) {
+    return gcnpt_pack_weights_multi(stream, 1, &W, &H, &Din, dtype, &w_fwd, &w_bwd);
 }
 
 extern "C" size_t gcnpt_frag_bytes(int rows, int width, int dtype) {
@@ -240,8 +269,9 @@ extern "C" int gcnpt_layer_bwd_weight(void* stream, const void* z_frag, const vo
     const int mb = ceil_div(p.m_tiles, WG_MT), nb = ceil_div(p.n_tiles, WG_NT);
     // one workgroup per CU: split the contraction so that blocks x slices ~ 256 with at least one k-step per
     // wave; slices is 1, 2, 4 or a multiple of 8 so that each slice maps onto whole XCD groups
-    int want = std::max(1, std::min(ceil_div(p.nks, 4), ceil_div(256, mb * nb)));
-    int slices = want >= 8 ? (want + 4) / 8 * 8 : (want >= 4 ? 4 : (want >= 2 ? 2 : 1));
+    // (rounded DOWN: one more workgroup than CUs costs a whole second round)
+    int want = std::max(1, std::min(ceil_div(p.nks, 4), 256 / (mb * nb)));
+    int slices = want >= 8 ? want / 8 * 8 : (want >= 4 ? 4 : (want >= 2 ? 2 : 1));
     p.ks_per_wg = ceil_div(p.nks, slices);
     p.mb = mb; p.nb = nb; p.slices = slices;
     const int per_group = (slices & 7) == 0 ? mb * nb * (slices / 8) : ceil_div(mb * nb, 8 / slices);

@@ -99,6 +99,9 @@ int gcnpt_csr_to_adj(void* stream, const int32_t* row_ptr, const int32_t* col_id
  * Must be re-run whenever the optimizer changed W. */
 size_t gcnpt_packed_bytes(int n_out, int k_in, int dtype);
 int gcnpt_pack_weights(void* stream, const float* W, int H, int Din, int dtype, void* w_fwd, void* w_bwd);
+/* the same for up to 8 layers in ONE launch (host arrays of n_layers device pointers / sizes) */
+int gcnpt_pack_weights_multi(void* stream, int n_layers, const float* const* W, const int* H, const int* Din, int dtype,
+                             void* const* w_fwd, void* const* w_bwd);
 
 /* ---- saved operands in MFMA fragment order ------------------------------------------------------------
  * The weight gradient contracts over the ROW index, so its MFMA operands need 8 consecutive rows per lane.

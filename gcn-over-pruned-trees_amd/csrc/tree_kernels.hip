@@ -15,7 +15,7 @@
 
 namespace gcnpt {
 
-constexpr int PRUNE_THREADS = 64;    // ONE wave per sentence: phases are separated by wave-local LDS ordering only
+constexpr int PRUNE_THREADS = 256;   // wave 0 prunes the sentence (wave-local phases); all 4 waves then emit the rows
 constexpr int ADJ_THREADS = 256;
 
 enum : int {
@@ -72,29 +72,38 @@ __device__ __forceinline__ int wave_exclusive_scan(int* a, int n, int lane) {
     return total;
 }
 
-__global__ __launch_bounds__(PRUNE_THREADS) void prune_to_csr_kernel(
-    const int64_t* __restrict__ head, const int64_t* __restrict__ subj_pos, const int64_t* __restrict__ obj_pos,
-    const int64_t* __restrict__ deprel, const uint8_t* __restrict__ pad_mask, const int32_t* __restrict__ len_in,
-    int B, int T, int prune_k, int cap, int32_t* __restrict__ row_ptr, int32_t* __restrict__ col_idx,
-    int32_t* __restrict__ label, int32_t* __restrict__ rowT_ptr, int32_t* __restrict__ colT_idx,
-    int32_t* __restrict__ ell, int32_t* __restrict__ ellT, uint8_t* __restrict__ pool_mask,
-    int32_t* __restrict__ status) {
-    extern __shared__ int smem[];
-    int* par = smem;               // [T]   parent token (-1 root / none, -2 head points past the sentence)
-    int* cnt = par + T;            // [T]   #entity chains through the token; later K_KEEP/K_CHILD bits
-    int* flg = cnt + T;            // [T]   F_* bits
-    int* deg = flg + T;            // [T+1] row degree -> row offsets
-    int* degT = deg + T + 1;       // [T+1] column degree -> transposed row offsets
-    int* klist = degT + T + 1;     // [T+1] tokens that carry an edge, ascending (compacted)
-    int* lab = klist + T + 1;      // [T]   deprel id of the token
-    __shared__ int s_err;
+// One 32-bit word per token keeps its parent and its flags together, so that every step of a walk up the tree is
+// ONE LDS read:  bits 0..11 = parent + 2 (0 = head points past the sentence, 1 = root / none), bits 12.. = F_* flags.
+constexpr int PW_SHIFT = 12, PW_MASK = (1 << PW_SHIFT) - 1, PRUNE_MAX_T = PW_MASK - 3;
+__device__ __forceinline__ int pw_par(int w) { return (w & PW_MASK) - 2; }
 
-    const int b = blockIdx.x, lane = threadIdx.x;
+// wave 0 runs the pruning phases alone: LDS operations of one wave complete in issue order, so a phase boundary only
+// has to stop the compiler from moving LDS accesses across it and wait for the wave's own outstanding LDS operations
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Phases of wave 0: lengths, LCA, path, distances, kept tokens, degrees, row offsets, compacted edge rows.
+__device__ void prune_sentence(const int64_t* __restrict__ head, const int64_t* __restrict__ subj_pos,
+                               const int64_t* __restrict__ obj_pos, const int64_t* __restrict__ deprel,
+                               const uint8_t* __restrict__ pad_mask, const int32_t* __restrict__ len_in, int b, int B, int T,
+                               int prune_k, int cap, int* smem, int* s_err, int* s_status, int* s_nrows,
+                               int32_t* __restrict__ row_ptr, int32_t* __restrict__ rowT_ptr, int32_t* __restrict__ ell,
+                               int32_t* __restrict__ ellT, uint8_t* __restrict__ pool_mask, int32_t* __restrict__ status,
+                               unsigned long long* stamps) {
+    int* pw = smem;                // [T]   parent + flags (see above)
+    int* cnt = pw + T;             // [T]   #entity chains through the token; later K_KEEP/K_CHILD bits
+    int* deg = cnt + T;            // [T+1] row degree -> row offsets
+    int* degT = deg + T + 1;       // [T+1] column degree -> transposed row offsets
+    int* rank = degT + T + 1;      // [T+1] rank of the token among the rows that carry an edge
+    int* lab = rank + T + 1;       // [T]   deprel id of the token
+    int* einfo = lab + T;          // [T]   compacted edge rows: token | (parent+2) << 12 | child/label bits << 24
+    const int lane = threadIdx.x & 63;
     const size_t base = (size_t)b * T;
-    if (lane == 0) s_err = 0;
 
     // ---- stage the parse (tree.py:60-63, 82-83): every load is unconditional and issued before the first use
-    //      (a load behind `if (i < len)` would be a dependent round trip per token)
     int npad = 0;
     for (int i = lane; i < T; i += WAVE) {
         const int64_t h = head[base + i];
@@ -106,112 +115,120 @@ __global__ __launch_bounds__(PRUNE_THREADS) void prune_to_csr_kernel(
         if (op == 0) f |= F_OBJ;
         if (d != 0) f |= F_FWD_NZ;                     // adj[p,c] = deprel[c]        survives `adj != 0`
         if (d + FWD_BOUND != 0) f |= F_REV_NZ;         // adj[c,p] = deprel[c] + 42
-        par[i] = h > 0 ? (int)min(h - 1, (int64_t)0x3fffffff) : -1;   // range-checked against len below
-        flg[i] = f; lab[i] = (int)d; cnt[i] = 0; deg[i] = 0; degT[i] = 0;
+        const int p = h > 0 ? (int)min(h - 1, (int64_t)(PW_MASK - 2)) : -1;      // range-checked against len below
+        pw[i] = (p + 2) | (f << PW_SHIFT);
+        lab[i] = (int)d; cnt[i] = 0; deg[i] = 0; degT[i] = 0;
     }
     // sentence length = number of non-pad slots (gcn.py:96)
     const int len = pad_mask ? T - wave_sum(npad) : min(max(len_in[b], 0), T);
     if (lane == 0) atomicMax(&status[B], len);
     int nsubj = 0, nent = 0;
     for (int i = lane; i < T; i += WAVE) {
-        int f = flg[i], p = par[i];
+        const int w = pw[i];
+        int f = w >> PW_SHIFT, p = pw_par(w);
         if (i >= len) { f = 0; p = -1; }
         else if (p >= len) p = -2;
         nsubj += (f & F_SUBJ) ? 1 : 0;
         nent += ((f & F_SUBJ) ? 1 : 0) + ((f & F_OBJ) ? 1 : 0);
-        flg[i] = f; par[i] = p;
+        pw[i] = (p + 2) | (f << PW_SHIFT);
     }
     nsubj = wave_sum(nsubj);
     nent = wave_sum(nent);
-    __syncthreads();
+    wave_lds_fence();
+    GCNPT_STAMP(stamps, 1);
 
     // ---- every entity token walks to the root, counting visits (tree.py:86-109)
     for (int i = lane; i < len; i += WAVE) {
-        const int f = flg[i];
+        const int f = pw[i] >> PW_SHIFT;
         const int w = ((f & F_SUBJ) ? 1 : 0) + ((f & F_OBJ) ? 1 : 0);
         if (!w) continue;
         int a = i, steps = 0;
         while (a >= 0) {
-            atomicAdd(&cnt[a], w);
-            a = par[a];
-            if (++steps > len) { atomicOr(&s_err, ERR_CHAIN_CYCLE); a = -1; }
+            atomicAdd(&cnt[a], w);                     // result unused: no-return LDS add, nothing to wait for
+            a = pw_par(pw[a]);
+            if (++steps > len) { atomicOr(s_err, ERR_CHAIN_CYCLE); a = -1; }
         }
-        if (a == -2) atomicOr(&s_err, ERR_CHAIN_BADHEAD);
+        if (a == -2) atomicOr(s_err, ERR_CHAIN_BADHEAD);
     }
-    __syncthreads();
+    wave_lds_fence();
     int err = 0;
-    if (s_err & ERR_CHAIN_BADHEAD) err = GCNPT_E_BAD_HEAD;
-    else if (s_err & ERR_CHAIN_CYCLE) err = GCNPT_E_CYCLE;
+    if (*s_err & ERR_CHAIN_BADHEAD) err = GCNPT_E_BAD_HEAD;
+    else if (*s_err & ERR_CHAIN_CYCLE) err = GCNPT_E_CYCLE;
     else if (nsubj == 0) err = GCNPT_E_NO_SUBJECT;
+    GCNPT_STAMP(stamps, 2);
 
     // ---- common ancestors and the lowest of them (tree.py:112-124)
     int lca = 0x7fffffff;
     if (!err) {
         for (int i = lane; i < len; i += WAVE)
-            if (cnt[i] == nent) flg[i] |= F_CA;
-        __syncthreads();
+            if (cnt[i] == nent) pw[i] |= F_CA << PW_SHIFT;
+        wave_lds_fence();
         for (int i = lane; i < len; i += WAVE) {
-            const int p = par[i];
-            if ((flg[i] & F_CA) && p >= 0 && (flg[p] & F_CA)) atomicOr(&flg[p], F_CA_HASCHILD);
+            const int w = pw[i], p = pw_par(w);
+            if ((w & (F_CA << PW_SHIFT)) && p >= 0 && (pw[p] & (F_CA << PW_SHIFT))) atomicOr(&pw[p], F_CA_HASCHILD << PW_SHIFT);
         }
-        __syncthreads();
+        wave_lds_fence();
         for (int i = lane; i < len; i += WAVE)
-            if ((flg[i] & (F_CA | F_CA_HASCHILD)) == F_CA) lca = min(lca, i);
+            if (((pw[i] >> PW_SHIFT) & (F_CA | F_CA_HASCHILD)) == F_CA) lca = min(lca, i);
         lca = wave_min(lca);
         if (lca == 0x7fffffff) err = GCNPT_E_NO_LCA;
     }
+    GCNPT_STAMP(stamps, 3);
 
     // ---- path nodes, distance to the path, kept tokens (tree.py:126-147)
     if (!err) {
         for (int i = lane; i < len; i += WAVE)
-            if ((cnt[i] > 0 && !(flg[i] & F_CA)) || i == lca) flg[i] |= F_PATH;
-        __syncthreads();
+            if ((cnt[i] > 0 && !(pw[i] & (F_CA << PW_SHIFT))) || i == lca) pw[i] |= F_PATH << PW_SHIFT;
+        wave_lds_fence();
         for (int i = lane; i < len; i += WAVE) {
-            int a = i, d = 0;
-            while (a >= 0 && !(flg[a] & F_PATH)) {
-                a = par[a];
-                if (++d > len) { atomicOr(&s_err, ERR_CYCLE); a = -1; }
+            int a = i, d = 0, w = pw[i];
+            while (a >= 0 && !(w & (F_PATH << PW_SHIFT))) {          // one LDS read per step
+                a = pw_par(w);
+                if (a >= 0) w = pw[a];
+                if (++d > len) { atomicOr(s_err, ERR_CYCLE); a = -1; }
             }
-            if (a == -2) atomicOr(&s_err, ERR_BADHEAD);
+            if (a == -2) atomicOr(s_err, ERR_BADHEAD);
             const bool keep = a >= 0 && d <= prune_k;
-            const bool child = keep && i != lca && par[i] >= 0;
+            const bool child = keep && i != lca && pw_par(pw[i]) >= 0;
             cnt[i] = (keep ? K_KEEP : 0) | (child ? K_CHILD : 0);   // cnt is free from here on
         }
-        __syncthreads();
-        if (s_err & ERR_BADHEAD) err = GCNPT_E_BAD_HEAD;
-        else if (s_err & ERR_CYCLE) err = GCNPT_E_CYCLE;
+        wave_lds_fence();
+        if (*s_err & ERR_BADHEAD) err = GCNPT_E_BAD_HEAD;
+        else if (*s_err & ERR_CYCLE) err = GCNPT_E_CYCLE;
     }
+    GCNPT_STAMP(stamps, 4);
 
     // ---- degrees of the labelled adjacency tree_to_adj would write (tree.py:182-192)
     if (!err) {
         for (int i = lane; i < len; i += WAVE) {
             if (!(cnt[i] & K_CHILD)) continue;
-            const int p = par[i], f = flg[i];
-            if (!(cnt[p] & K_KEEP)) atomicOr(&s_err, ERR_ASSERT);   // tree.py:159
+            const int w = pw[i], p = pw_par(w), f = w >> PW_SHIFT;
+            if (!(cnt[p] & K_KEEP)) atomicOr(s_err, ERR_ASSERT);   // tree.py:159
             if (f & F_FWD_NZ) { atomicAdd(&deg[p], 1); atomicAdd(&degT[i], 1); }
             if (f & F_REV_NZ) { atomicAdd(&deg[i], 1); atomicAdd(&degT[p], 1); }
-            atomicOr(&flg[p], F_HASEDGE);
-            atomicOr(&flg[i], F_HASEDGE);
+            atomicOr(&pw[p], F_HASEDGE << PW_SHIFT);
+            atomicOr(&pw[i], F_HASEDGE << PW_SHIFT);
         }
-        __syncthreads();
-        if (s_err & ERR_ASSERT) err = GCNPT_E_ASSERT;
+        wave_lds_fence();
+        if (*s_err & ERR_ASSERT) err = GCNPT_E_ASSERT;
     }
     int n_edge_rows = 0;
     if (!err) {
         for (int i = lane; i < T; i += WAVE) {
-            const int he = (i < len && (flg[i] & F_HASEDGE)) ? 1 : 0;
+            const int he = (i < len && (pw[i] & (F_HASEDGE << PW_SHIFT))) ? 1 : 0;
             deg[i] += he; degT[i] += he;                             // the 84 on the diagonal
-            klist[i] = he;
+            rank[i] = he;
             if (pool_mask) pool_mask[base + i] = (deg[i] + degT[i]) == 0;   // gcn.py:262
         }
-        __syncthreads();
+        wave_lds_fence();
         const int tot = wave_exclusive_scan(deg, T, lane);
         const int totT = wave_exclusive_scan(degT, T, lane);
-        n_edge_rows = wave_exclusive_scan(klist, T, lane);           // klist[i] = rank of token i among the edge rows
+        n_edge_rows = wave_exclusive_scan(rank, T, lane);
         if (lane == 0) { deg[T] = tot; degT[T] = totT; }
-        __syncthreads();
+        wave_lds_fence();
         if (tot > cap || totT > cap) err = GCNPT_E_CAPACITY;
     }
+    GCNPT_STAMP(stamps, 5);
 
     if (err) {   // the sentence contributes no edges; every row is empty and masked
         for (int i = lane; i <= T; i += WAVE) {
@@ -224,67 +241,116 @@ __global__ __launch_bounds__(PRUNE_THREADS) void prune_to_csr_kernel(
             ell[base * 8 + i] = 0;
             if (ellT) ellT[base * 8 + i] = 0;
         }
-        if (lane == 0) status[b] = err;
+        if (lane == 0) { status[b] = err; *s_status = err; }
         return;
     }
 
-    // ---- emit both patterns, columns ascending (same order a dense -> CSR conversion gives)
+    // ---- emit both patterns, columns ascending (same order a dense -> CSR conversion gives).
+    // Only rows that carry an edge have entries, and only such rows appear as columns: compact them (ascending)
+    // with everything the inner loop needs in ONE word, so that loop is a stream of broadcast LDS reads.
     for (int i = lane; i <= T; i += WAVE) {
         row_ptr[(size_t)b * (T + 1) + i] = b * cap + deg[i];
         if (rowT_ptr) rowT_ptr[(size_t)b * (T + 1) + i] = b * cap + degT[i];
     }
-    // compact the rows that carry an edge (ascending): only they, and only columns among them, have entries.
-    // klist[i] is the rank of token i among them; every such token writes itself at its rank.
-    int* elist = lab + T;          // [T]
-    for (int i = lane; i < len; i += WAVE)
-        if (flg[i] & F_HASEDGE) elist[klist[i]] = i;
-    __syncthreads();
-
-    for (int r = lane; r < T; r += WAVE) {
-        int hd[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hdT[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ELL heads: count, first 7 columns
-        const int rf = r < len ? flg[r] : 0;
-        if (rf & F_HASEDGE) {
-            const bool rchild = cnt[r] & K_CHILD;
-            const int rp = par[r];
-            const int o0 = b * cap + deg[r], oT0 = b * cap + degT[r];
-            int o = o0, oT = oT0;
-            auto put = [&](int j, int lb) {
-                col_idx[o] = j; if (label) label[o] = lb;
-                if (o - o0 < 7) hd[1 + o - o0] = j;
-                ++o;
-            };
-            auto putT = [&](int j) {
-                if (colT_idx) colT_idx[oT] = j;
-                if (oT - oT0 < 7) hdT[1 + oT - oT0] = j;
-                ++oT;
-            };
-            for (int q = 0; q < n_edge_rows; ++q) {
-                const int j = elist[q];
-                const bool child = (cnt[j] & K_CHILD) && par[j] == r;
-                const int fj = flg[j];
-                if (child) {
-                    if (fj & F_FWD_NZ) put(j, lab[j]);
-                    if (fj & F_REV_NZ) putT(j);
-                } else if (j == r) {
-                    put(r, SELF_LOOP_ID);
-                    putT(r);
-                } else if (rchild && j == rp) {
-                    if (rf & F_REV_NZ) put(j, lab[r] + FWD_BOUND);
-                    if (rf & F_FWD_NZ) putT(j);
-                }
+    for (int i = lane; i < T; i += WAVE) {
+        const int w = i < len ? pw[i] : 0;
+        if (w & (F_HASEDGE << PW_SHIFT)) {
+            const int f = w >> PW_SHIFT;
+            einfo[rank[i]] = i | ((w & PW_MASK) << 12) | ((cnt[i] & K_CHILD) ? 1 << 24 : 0) |
+                             ((f & F_FWD_NZ) ? 1 << 25 : 0) | ((f & F_REV_NZ) ? 1 << 26 : 0);
+        } else {                                                     // no entries: an all-zero ELL head
+            int4* e = reinterpret_cast<int4*>(ell + (base + i) * 8);
+            e[0] = make_int4(0, 0, 0, 0); e[1] = make_int4(0, 0, 0, 0);
+            if (ellT) {
+                int4* eT = reinterpret_cast<int4*>(ellT + (base + i) * 8);
+                eT[0] = make_int4(0, 0, 0, 0); eT[1] = make_int4(0, 0, 0, 0);
             }
-            hd[0] = o - o0; hdT[0] = oT - oT0;
-        }
-        int4* e = reinterpret_cast<int4*>(ell + (base + r) * 8);
-        e[0] = make_int4(hd[0], hd[1], hd[2], hd[3]);
-        e[1] = make_int4(hd[4], hd[5], hd[6], hd[7]);
-        if (ellT) {
-            int4* eT = reinterpret_cast<int4*>(ellT + (base + r) * 8);
-            eT[0] = make_int4(hdT[0], hdT[1], hdT[2], hdT[3]);
-            eT[1] = make_int4(hdT[4], hdT[5], hdT[6], hdT[7]);
         }
     }
-    if (lane == 0) status[b] = 0;
+    wave_lds_fence();
+    GCNPT_STAMP(stamps, 6);
+    if (lane == 0) { *s_nrows = n_edge_rows; status[b] = 0; }
+}
+
+// All 4 waves: the CSR entries and ELL heads of the rows that carry an edge.  One row at a time per wave, one
+// candidate column per lane: ballot + prefix popcount give every entry its slot, no inner loop, no LDS traffic
+// (row info comes from the other lanes' registers with v_readlane).
+__device__ void emit_rows(int b, int T, int cap, int* smem, int err, int n_edge_rows, int lane, int wave,
+                          int32_t* __restrict__ col_idx, int32_t* __restrict__ label, int32_t* __restrict__ colT_idx,
+                          int32_t* __restrict__ ell, int32_t* __restrict__ ellT, unsigned long long* stamps) {
+    if (err) return;
+    int* deg = smem + 2 * T;
+    int* degT = deg + T + 1;
+    int* lab = degT + 2 * (T + 1);
+    int* einfo = lab + T;
+    const size_t base = (size_t)b * T;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int q0 = 0; q0 < n_edge_rows; q0 += WAVE) {                  // rows, a chunk of 64 at a time (registers)
+        const int rw = q0 + lane < n_edge_rows ? einfo[q0 + lane] : 0;
+        const int rdeg = deg[rw & 0xfff], rdegT = degT[rw & 0xfff], rlab = lab[rw & 0xfff];
+        const int nq = min(WAVE, n_edge_rows - q0);
+        for (int qq = wave; qq < nq; qq += PRUNE_THREADS / WAVE) {    // this wave's rows of the chunk
+            const int me = __builtin_amdgcn_readlane(rw, qq);
+            const int r = me & 0xfff, rp = ((me >> 12) & 0xfff) - 2;
+            const bool rchild = me & (1 << 24), rfwd = me & (1 << 25), rrev = me & (1 << 26);
+            const int labr = __builtin_amdgcn_readlane(rlab, qq) + FWD_BOUND;
+            int o = b * cap + __builtin_amdgcn_readlane(rdeg, qq), oT = b * cap + __builtin_amdgcn_readlane(rdegT, qq);
+            int32_t* hd = ell + (base + r) * 8;                       // ELL head: [0] = count, [1..7] = first 7 columns
+            int32_t* hdT = ellT ? ellT + (base + r) * 8 : nullptr;
+            int n_e = 0, n_eT = 0;
+            for (int k0 = 0; k0 < n_edge_rows; k0 += WAVE) {          // candidate columns: the edge rows, ascending
+                const bool valid = k0 + lane < n_edge_rows;
+                const int w = valid ? einfo[k0 + lane] : 0;
+                const int j = w & 0xfff, jp = ((w >> 12) & 0xfff) - 2;
+                const bool is_child = valid && (w & (1 << 24)) && jp == r;      // j is a kept child of r
+                const bool is_self = valid && j == r;
+                const bool is_par = valid && rchild && j == rp;
+                const bool e = (is_child && (w & (1 << 25))) || is_self || (is_par && rrev);      // adj[r,j] != 0
+                const bool eT = (is_child && (w & (1 << 26))) || is_self || (is_par && rfwd);     // adj[j,r] != 0
+                const unsigned long long m = __ballot(e), mT = __ballot(eT);
+                if (e) {
+                    const int pos = n_e + __popcll(m & lt);
+                    col_idx[o + pos] = j;
+                    if (label) label[o + pos] = is_self ? SELF_LOOP_ID : (is_child ? lab[j] : labr);
+                    if (pos < 7) hd[1 + pos] = j;
+                }
+                if (eT) {
+                    const int pos = n_eT + __popcll(mT & lt);
+                    if (colT_idx) colT_idx[oT + pos] = j;
+                    if (hdT && pos < 7) hdT[1 + pos] = j;
+                }
+                n_e += __popcll(m);
+                n_eT += __popcll(mT);
+            }
+            if (lane < 8) {                                           // count, and zeros in the unused slots
+                if (lane == 0) hd[0] = n_e; else if (lane > n_e) hd[lane] = 0;
+                if (hdT) { if (lane == 0) hdT[0] = n_eT; else if (lane > n_eT) hdT[lane] = 0; }
+            }
+        }
+    }
+    GCNPT_STAMP(stamps, 7);
+}
+
+__global__ __launch_bounds__(PRUNE_THREADS) void prune_to_csr_kernel(
+    const int64_t* __restrict__ head, const int64_t* __restrict__ subj_pos, const int64_t* __restrict__ obj_pos,
+    const int64_t* __restrict__ deprel, const uint8_t* __restrict__ pad_mask, const int32_t* __restrict__ len_in,
+    int B, int T, int prune_k, int cap, int32_t* __restrict__ row_ptr, int32_t* __restrict__ col_idx,
+    int32_t* __restrict__ label, int32_t* __restrict__ rowT_ptr, int32_t* __restrict__ colT_idx,
+    int32_t* __restrict__ ell, int32_t* __restrict__ ellT, uint8_t* __restrict__ pool_mask,
+    int32_t* __restrict__ status, unsigned long long* stamps) {
+    extern __shared__ int smem[];  // carved in prune_sentence()
+    __shared__ int s_err;
+
+    __shared__ int s_status, s_nrows;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { s_err = 0; s_status = 0; s_nrows = 0; }
+    GCNPT_STAMP_REAL(stamps);
+    GCNPT_STAMP(stamps, 0);
+    __syncthreads();
+    if (wave == 0) prune_sentence(head, subj_pos, obj_pos, deprel, pad_mask, len_in, b, B, T, prune_k, cap, smem, &s_err, &s_status,
+                                  &s_nrows, row_ptr, rowT_ptr, ell, ellT, pool_mask, status, stamps);
+    __syncthreads();
+    emit_rows(b, T, cap, smem, s_status, s_nrows, lane, wave, col_idx, label, colT_idx, ell, ellT, stamps);
 }
 
 // ---- dense float adjacency -> CSR of (adj != 0) and of its transpose (gcn.py:260-262) -----------------
@@ -391,12 +457,13 @@ extern "C" int gcnpt_prune_to_csr(void* stream, const int64_t* head, const int64
         return fail(GCNPT_E_PRUNE_NEGATIVE, "prune_k=%d: the reference fork only works with prune_k >= 0 "
                     "(model/tree.py:194 reads Tree.head, which the unpruned branch never sets)", prune_k);
     if ((long long)B * cap > 0x7fffffffLL) return fail(GCNPT_E_UNSUPPORTED, "prune_to_csr: B*cap overflows int32");
-    const size_t lds = sizeof(int) * ((size_t)8 * T + 4);
-    if (lds > 150 * 1024) return fail(GCNPT_E_UNSUPPORTED, "prune_to_csr: T=%d needs %zu B of LDS", T, lds);
+    const size_t lds = sizeof(int) * ((size_t)7 * T + 4);
+    if (T > PRUNE_MAX_T) return fail(GCNPT_E_UNSUPPORTED, "prune_to_csr: T=%d exceeds the %d tokens a sentence may have", T, PRUNE_MAX_T);
     hipStream_t s = (hipStream_t)stream;
     GCNPT_HIP_CHECK(hipMemsetAsync(status + B, 0, sizeof(int32_t), s));
     hipLaunchKernelGGL(prune_to_csr_kernel, dim3(B), dim3(PRUNE_THREADS), lds, s, head, subj_pos, obj_pos, deprel,
-                       pad_mask, len, B, T, prune_k, cap, row_ptr, col_idx, label, rowT_ptr, colT_idx, ell, ellT, pool_mask, status);
+                       pad_mask, len, B, T, prune_k, cap, row_ptr, col_idx, label, rowT_ptr, colT_idx, ell, ellT, pool_mask, status,
+                       static_cast<unsigned long long*>(g_debug_stamps));
     GCNPT_HIP_CHECK(hipGetLastError());
     return GCNPT_OK;
 }

@@ -240,27 +240,41 @@ def timed(run, steps, warmup, barrier):
     return wall, e0.elapsed_time(e1) * 1e-3
 
 
-def kernel_breakdown(stack, use_graph, reps=50, rounds=20):
-    """Average duration of each kernel of the step: `reps` back-to-back launches replayed as one hipGraph, HIP events around it."""
-    calls = [("pack", stack.pack_all), ("fwd0", lambda: stack.fwd(0)),
-             ("fwd1", lambda: stack.fwd(1)), ("bwd_data1", lambda: stack.bwd_data(1)), ("bwd_weight1", lambda: stack.bwd_weight(1)),
-             ("bwd_data0", lambda: stack.bwd_data(0)), ("bwd_weight0", lambda: stack.bwd_weight(0)), ("prune", stack.prune)]
+def kernel_breakdown(stack, use_graph, rounds=300):
+    """
+    Duration of each kernel IN the step: the step is replayed truncated after its first k launches (one hipGraph per k),
+    HIP events around `rounds` replays, and kernel k is charged t(k) - t(k-1).  Unlike timing a kernel alone back to back,
+    this keeps the producer -> consumer cache state of the real step (each kernel reads what the previous one wrote from
+    other XCDs) and includes its launch boundary.  `prune` is timed as the step with the tree build minus the step without.
+    """
+    calls = [("pack", stack.pack_all), ("fwd0", lambda: stack.fwd(0)), ("fwd1", lambda: stack.fwd(1)),
+             ("bwd_data1", lambda: stack.bwd_data(1)), ("bwd_weight1", lambda: stack.bwd_weight(1)),
+             ("bwd_data0", lambda: stack.bwd_data(0)), ("bwd_weight0", lambda: stack.bwd_weight(0))]
     stack.step()
     torch.cuda.synchronize()
-    out = {}
-    for name, call in calls:
-        def many(call=call):
-            for _ in range(reps):
-                call()
-        run, _ = capture(many, use_graph)
-        run(); torch.cuda.synchronize()
+
+    def timed_replay(fn):
+        run, _ = capture(fn, use_graph)
+        for _ in range(20):
+            run()
+        torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(rounds):
             run()
         e1.record()
         torch.cuda.synchronize()
-        out[name] = e0.elapsed_time(e1) * 1e-3 / (reps * rounds)
+        return e0.elapsed_time(e1) * 1e-3 / rounds
+
+    out, prev = {}, 0.0
+    for k in range(1, len(calls) + 1):
+        def prefix(k=k):
+            for _, c in calls[:k]:
+                c()
+        t = timed_replay(prefix)
+        out[calls[k - 1][0]] = max(t - prev, 1e-9)
+        prev = t
+    out["prune"] = max(timed_replay(lambda: stack.step(0, with_prune=True)) - prev, 1e-9)
     stack.step()          # leave consistent buffers behind
     torch.cuda.synchronize()
     return out
@@ -375,7 +389,7 @@ def main():
             gbs = alg[dom] / kt[dom] / 1e9
             result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                   "traffic": traffic, "algorithmic_bytes": alg[dom], "avg_launch_us": kt[dom] * 1e6,
-                                  "note": "avg duration from HIP events around 50 back-to-back launches replayed as one hipGraph (includes dispatch gaps)"}
+                                  "note": "in-step duration: HIP events around hipGraph replays of the step truncated after k launches, t(k)-t(k-1); includes the launch boundary"}
             result["kernels"] = {k: {"avg_us": kt[k] * 1e6, "algorithmic_bytes": alg[k], "GBps": alg[k] / kt[k] / 1e9} for k in kt}
             tot_b = sum(alg[k] for k in step_keys)
             result["step_roofline"] = {"algorithmic_bytes": tot_b, "sum_kernel_us": sum(kt[k] for k in step_keys) * 1e6,

@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--lengths", choices=["full", "tacred"], default="full")
     ap.add_argument("--drop", type=float, default=0.5)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--fused", action="store_true",
+                    help="sentence-resident stack kernels (all layers in one launch per direction) instead of one launch per layer; "
+                         "measured slower on MI355X at this size (109 vs 76 us/step): 50 workgroups carry every elementwise phase")
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="2 = run layer-1 bwd-weight beside layer-0 bwd-data (and the tree build beside the pack) on a side stream; "
                          "measured slower than 1 on MI355X: the cross-stream graph edges cost more than the overlap gains")
@@ -98,6 +101,11 @@ class Stack(object):
         self.nnz = int(self.trees.nnz().sum())
         self.scale = 1.0 / (1.0 - args.drop) if args.drop > 0 else 1.0
         self.side = torch.cuda.Stream(device=dev)
+        self.fused = args.fused and args.dtype == "bf16" and bool(self.L.gcnpt_stack_supported(T, Din, H, 2, self.compute))
+        if self.fused:       # fragment images with per-sentence k-steps: layer inputs h_l (fwd) and G_l = (A+I)^T dZ_l (bwd)
+            fb = self.L.gcnpt_stack_frag_bytes
+            self.hf = [torch.empty((fb(B, T, d),), dtype=torch.uint8, device=dev) for h, d in dims]
+            self.gf = [torch.empty((fb(B, T, h),), dtype=torch.uint8, device=dev) for h, d in dims]
 
     def grads(self, k):
         H, Din = self.H, self.Din
@@ -157,19 +165,49 @@ class Stack(object):
         self._lib.check(self.L.gcnpt_layer_bwd_weight(self._lib.stream(), P(self.zf[l]), P(self.sf[l]), self.B, self.T, Din, H,
                                                       P(dW), P(db), self.compute))
 
+    # ---- sentence-resident stack: every layer in one launch per direction ----
+    def stack_fwd(self, k=0):
+        P, A, tr, L = self._lib.ptr, self._lib.ptr_array, self.trees, 2
+        g = self.grads(k)
+        self._lib.check(self.L.gcnpt_stack_fwd(
+            self._lib.stream(), L, P(self.x), self.act, A(self.wf), A(self.b), P(tr.row_ptr), P(tr.col_idx), P(tr.ell), None,
+            self.B, self.T, self.Din, self.H, A([self.h1, self.h2]), self.act, (ctypes.c_float * L)(self.args.drop, 0.0),
+            (ctypes.c_uint64 * L)(0x5eed, 0), A(self.hf), A([g[0], g[2]]), A([g[1], g[3]])))
+
+    def stack_bwd(self, k=0):
+        P, A, tr, L = self._lib.ptr, self._lib.ptr_array, self.trees, 2
+        g = self.grads(k)
+        self._lib.check(self.L.gcnpt_stack_bwd(
+            self._lib.stream(), L, P(self.gy), A([self.h1, self.h2]), self.act, A(self.wb), P(tr.ell), P(tr.rowT_ptr), P(tr.colT_idx),
+            P(tr.ellT), self.B, self.T, self.Din, self.H, P(self.dx), self.act, (ctypes.c_float * L)(self.scale, 1.0), A(self.gf),
+            A([g[1], g[3]])))
+
+    def stack_bwd_weight(self, k=0):
+        A, L = self._lib.ptr_array, 2
+        g = self.grads(k)
+        self._lib.check(self.L.gcnpt_stack_bwd_weight(self._lib.stream(), L, A(self.gf), A(self.hf), self.B, self.T, self.Din, self.H,
+                                                      A([g[0], g[2]])))
+
+    def calls(self, k=0):
+        """The launches of one step, in order (name, callable)."""
+        if self.fused:
+            return [("pack", self.pack_all), ("stack_fwd", lambda: self.stack_fwd(k)), ("stack_bwd", lambda: self.stack_bwd(k)),
+                    ("stack_bwd_weight", lambda: self.stack_bwd_weight(k))]
+        return [("pack", self.pack_all), ("fwd0", lambda: self.fwd(0)), ("fwd1", lambda: self.fwd(1)),
+                ("bwd_data1", lambda: self.bwd_data(1, k)), ("bwd_weight1", lambda: self.bwd_weight(1, k)),
+                ("bwd_data0", lambda: self.bwd_data(0, k)), ("bwd_weight0", lambda: self.bwd_weight(0, k))]
+
     def step(self, k=0, with_prune=False):
         """
         One step.  With --streams 2: the weight gradient of layer 1 only needs layer 1's dZ image, so it runs beside the
         backward-data kernel of layer 0; the tree build only needs the loader tensors, so it runs beside the weight pack.
         Every kernel of the step is still launched and finished inside the step (fork and join are inside it).
         """
-        if self.args.streams == 1:
+        if self.args.streams == 1 or self.fused:
             if with_prune:
                 self.prune()
-            self.pack_all()
-            self.fwd(0); self.fwd(1)
-            self.bwd_data(1, k); self.bwd_weight(1, k)
-            self.bwd_data(0, k); self.bwd_weight(0, k)
+            for _, call in self.calls(k):
+                call()
             return
         main = torch.cuda.current_stream()
         side = self.side
@@ -201,6 +239,14 @@ class Stack(object):
             out["bwd_weight%d" % l] = self.zf[l].numel() + self.sf[l].numel() + 4 * (H * Din + H)
             out["pack"] = out.get("pack", 0) + 4 * H * Din + self.wf[l].numel() + self.wb[l].numel()
         out["prune"] = 4 * 8 * N + N + 2 * (csr + 4 * B * (T + 1) + 4 * self.nnz) + N + 4 * (B + 1)
+        if self.fused:
+            (H, Din), grads = tuple(self.W[0].shape), 4 * self.n_grad
+            hf, gf = sum(t.numel() for t in self.hf), sum(t.numel() for t in self.gf)
+            # x in, h1 + h2 out, weights, bias, ELL, fragment images of the layer inputs, cleared accumulators
+            out["stack_fwd"] = e * N * (Din + 2 * H) + sum(t.numel() for t in self.wf) + 8 * H + csr + hf + grads
+            # gy, h2, h1 in, dx out, weights, ELL (both patterns), fragment images of G, bias gradients
+            out["stack_bwd"] = e * N * (3 * H + Din) + sum(t.numel() for t in self.wb) + 2 * csr + gf + 8 * H
+            out["stack_bwd_weight"] = hf + gf + 4 * (H * Din + H * H)
         return out
 
 
@@ -247,9 +293,7 @@ def kernel_breakdown(stack, use_graph, rounds=300):
     this keeps the producer -> consumer cache state of the real step (each kernel reads what the previous one wrote from
     other XCDs) and includes its launch boundary.  `prune` is timed as the step with the tree build minus the step without.
     """
-    calls = [("pack", stack.pack_all), ("fwd0", lambda: stack.fwd(0)), ("fwd1", lambda: stack.fwd(1)),
-             ("bwd_data1", lambda: stack.bwd_data(1)), ("bwd_weight1", lambda: stack.bwd_weight(1)),
-             ("bwd_data0", lambda: stack.bwd_data(0)), ("bwd_weight0", lambda: stack.bwd_weight(0))]
+    calls = stack.calls(0)
     stack.step()
     torch.cuda.synchronize()
 
@@ -380,6 +424,8 @@ def main():
         if not args.no_kernel_breakdown:
             kt = kernel_breakdown(stack, use_graph)
             step_keys = [k for k in kt if k != "prune"]
+            result["config"]["kernels_per_step"] = "sentence-resident stack: pack, stack_fwd, stack_bwd, stack_bwd_weight" if stack.fused \
+                else "per layer: pack, fwd0, fwd1, bwd_data1, bwd_weight1, bwd_data0, bwd_weight0"
             dom = max(step_keys, key=lambda k: kt[k])
             traffic = None
             tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # per-launch HBM bytes from rocprofv3 --pmc passes, if recorded

@@ -27,6 +27,11 @@ SIGNATURES = {
     "gcnpt_layer_fwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _f, _u64, _p]),
     "gcnpt_layer_bwd_data": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _f, _p, _p, _p]),
     "gcnpt_layer_bwd_weight": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _i]),
+    "gcnpt_stack_supported": (_i, [_i, _i, _i, _i, _i]),
+    "gcnpt_stack_frag_bytes": (_sz, [_i, _i, _i]),
+    "gcnpt_stack_fwd": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p]),
+    "gcnpt_stack_bwd": (_i, [_p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p]),
+    "gcnpt_stack_bwd_weight": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _p]),
 }
 
 
@@ -85,6 +90,11 @@ def ptr(t):
     if not t.is_contiguous():
         raise RuntimeError("gcnpt ops need contiguous tensors")
     return t.data_ptr()
+
+
+def ptr_array(tensors):
+    """Host array of device pointers (None -> NULL) for the entry points that take one pointer per layer."""
+    return (ctypes.c_void_p * len(tensors))(*[ptr(t) for t in tensors])
 
 
 def stream():

@@ -48,62 +48,6 @@ struct RowTileParams {
     int knob;
 };
 
-template <typename IT> struct raw8 { uint4 a, b; };      // 8 elements as loaded (bf16: a only)
-
-// 8 elements of row `row` from column k0.  NO load here is behind a condition: hipcc puts every conditional
-// load in its own basic block with an s_waitcnt vmcnt(0) in front, which turns a batch of loads into a chain
-// of round trips.  Callers pass a (row, k0) that is valid memory (clamped) and zero the result if it was not wanted.
-template <typename IT, bool VEC>
-__device__ __forceinline__ void issue8(const IT* base, size_t row, int K, int k0, raw8<IT>& r) {
-    if constexpr (VEC) {                                    // K % 8 == 0, 16-byte aligned base, k0 + 8 <= K
-        const IT* p = base + row * (size_t)K + k0;
-        r.a = *reinterpret_cast<const uint4*>(p);
-        if constexpr (sizeof(IT) == 4) r.b = *reinterpret_cast<const uint4*>(p + 4);
-    } else {                                                // any K / alignment: 8 clamped element loads
-        const IT* p = base + row * (size_t)K;
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float x = io<IT>::load1(p + min(k0 + j, K - 1));
-            v[j] = (k0 + j < K) ? x : 0.0f;
-        }
-        if constexpr (sizeof(IT) == 4) {
-            r.a = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
-            r.b = make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7]));
-        } else {
-            r.a.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-            r.a.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-            r.a.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
-            r.a.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
-        }
-    }
-}
-
-// the 8 floats of a raw8, all zero when !live
-template <typename IT>
-__device__ __forceinline__ void unpack8(const raw8<IT>& r, bool live, float (&v)[8]) {
-    const uint4 z = make_uint4(0, 0, 0, 0);
-    const uint4 a = live ? r.a : z;
-    if constexpr (sizeof(IT) == 4) {
-        const uint4 b = live ? r.b : z;
-        v[0] = __uint_as_float(a.x); v[1] = __uint_as_float(a.y); v[2] = __uint_as_float(a.z); v[3] = __uint_as_float(a.w);
-        v[4] = __uint_as_float(b.x); v[5] = __uint_as_float(b.y); v[6] = __uint_as_float(b.z); v[7] = __uint_as_float(b.w);
-    } else {
-        v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
-        v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
-        v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
-        v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
-    }
-}
-
-// out-tile row stride in dwords: 16-byte aligned rows, == 4 (mod 8) to spread the 4 row groups of an
-// accumulator store over the banks
-__host__ __device__ inline int out_stride_dw(int payload_dw) {
-    int s = round_up(payload_dw, 4);
-    while ((s & 7) != 4) s += 4;
-    return s;
-}
-
 template <typename CT, typename IT, typename OT, bool BWD, bool VEC, int NTW, int KSMAX>
 __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTileParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];

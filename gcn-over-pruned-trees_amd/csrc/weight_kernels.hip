@@ -117,7 +117,7 @@ __global__ __launch_bounds__(LAYER_THREADS) void weight_grad_kernel(const Weight
     const int bm = blk % p.mb, bn = blk / p.mb;
     const int m0 = bm * WG_MT, n0 = bn * WG_NT;
     const int ks_lo = slice * p.ks_per_wg, ks_hi = min(p.nks, ks_lo + p.ks_per_wg);
-    const bool want_db = bn == 0;
+    const bool want_db = bn == 0 && p.db != nullptr;
     GCNPT_STAMP_REAL(p.stamps);
     GCNPT_STAMP(p.stamps, 0);
 
@@ -255,17 +255,14 @@ extern "C" size_t gcnpt_frag_bytes(int rows, int width, int dtype) {
     return (size_t)ceil_div(width, 16) * ksteps * 64 * 16;
 }
 
-extern "C" int gcnpt_layer_bwd_weight(void* stream, const void* z_frag, const void* s_frag, int B, int T, int Din, int H,
-                                      float* dW, float* db, int compute_dtype) {
-    GCNPT_REQUIRE(z_frag && s_frag && dW && db, "layer_bwd_weight: null pointer");
-    GCNPT_REQUIRE(B > 0 && T > 0 && Din > 0 && H > 0, "layer_bwd_weight: sizes must be positive");
-    GCNPT_REQUIRE(dtype_ok(compute_dtype), "layer_bwd_weight: bad dtype");
+static int launch_weight_grad(hipStream_t s, const void* z_frag, const void* s_frag, int nks, int Din, int H, float* dW, float* db,
+                              int compute_dtype) {
     WeightGradParams p{};
     p.stamps = static_cast<unsigned long long*>(g_debug_stamps); p.knob = g_debug_knob;
     p.zf = static_cast<const uint4*>(z_frag); p.sf = static_cast<const uint4*>(s_frag);
     p.dW = dW; p.db = db; p.H = H; p.Din = Din;
     p.m_tiles = ceil_div(H, 16); p.n_tiles = ceil_div(Din, 16);
-    p.nks = ceil_div(B * T, 32) * (compute_dtype == GCNPT_BF16 ? 1 : 2);
+    p.nks = nks;
     const int mb = ceil_div(p.m_tiles, WG_MT), nb = ceil_div(p.n_tiles, WG_NT);
     // one workgroup per CU: split the contraction so that blocks x slices ~ 256 with at least one k-step per
     // wave; slices is 1, 2, 4 or a multiple of 8 so that each slice maps onto whole XCD groups
@@ -276,11 +273,33 @@ extern "C" int gcnpt_layer_bwd_weight(void* stream, const void* z_frag, const vo
     p.mb = mb; p.nb = nb; p.slices = slices;
     const int per_group = (slices & 7) == 0 ? mb * nb * (slices / 8) : ceil_div(mb * nb, 8 / slices);
     const dim3 grid(8 * per_group);
-    hipStream_t s = (hipStream_t)stream;
     if (compute_dtype == GCNPT_BF16)
         hipLaunchKernelGGL(weight_grad_kernel<bf16_t>, grid, dim3(LAYER_THREADS), 0, s, p);
     else
         hipLaunchKernelGGL(weight_grad_kernel<float>, grid, dim3(LAYER_THREADS), 0, s, p);
     GCNPT_HIP_CHECK(hipGetLastError());
+    return GCNPT_OK;
+}
+
+extern "C" int gcnpt_layer_bwd_weight(void* stream, const void* z_frag, const void* s_frag, int B, int T, int Din, int H,
+                                      float* dW, float* db, int compute_dtype) {
+    GCNPT_REQUIRE(z_frag && s_frag && dW && db, "layer_bwd_weight: null pointer");
+    GCNPT_REQUIRE(B > 0 && T > 0 && Din > 0 && H > 0, "layer_bwd_weight: sizes must be positive");
+    GCNPT_REQUIRE(dtype_ok(compute_dtype), "layer_bwd_weight: bad dtype");
+    const int nks = ceil_div(B * T, 32) * (compute_dtype == GCNPT_BF16 ? 1 : 2);
+    return launch_weight_grad((hipStream_t)stream, z_frag, s_frag, nks, Din, H, dW, db, compute_dtype);
+}
+
+// weight gradients of the sentence-resident stack: dW_l += G_l^T h_l from the two per-sentence fragment images
+// (db_l is added by gcnpt_stack_bwd itself)
+extern "C" int gcnpt_stack_bwd_weight(void* stream, int n_layers, const void* const* g_frag, const void* const* h_frag, int B, int T,
+                                      int Din, int H, float* const* dW) {
+    GCNPT_REQUIRE(g_frag && h_frag && dW && n_layers >= 1 && n_layers <= 8, "stack_bwd_weight: bad argument");
+    GCNPT_REQUIRE(B > 0 && T > 0 && Din > 0 && H > 0, "stack_bwd_weight: sizes must be positive");
+    const int nks = B * ceil_div(T, 32);
+    for (int l = n_layers - 1; l >= 0; --l) {
+        GCNPT_REQUIRE(g_frag[l] && h_frag[l] && dW[l], "stack_bwd_weight: null pointer (layer %d)", l);
+        if (int rc = launch_weight_grad((hipStream_t)stream, g_frag[l], h_frag[l], nks, l == 0 ? Din : H, H, dW[l], nullptr, GCNPT_BF16)) return rc;
+    }
     return GCNPT_OK;
 }

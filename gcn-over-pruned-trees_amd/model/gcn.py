@@ -16,9 +16,12 @@ direction, reached through the C-ABI of include/gcnpt.h.  Embeddings, the option
 the output MLP stay ordinary PyTorch-ROCm modules, as in the reference.
 
 New optional `opt` keys (defaults reproduce the reference): `gcn_dtype` = 'fp32' | 'bf16' (MFMA operand /
-activation storage type inside the layer stack), `gcn_check_trees` = True (synchronise once per forward to
+activation storage type inside the layer stack), `gcn_fused` = False (bf16 only: run the whole stack with the
+sentence-resident one-launch-per-direction kernels when the shape fits; slower than one launch per layer at B=50), `gcn_check_trees` = True (synchronise once per forward to
 raise on malformed trees the way the reference does; False keeps the step free of host syncs).
 """
+import ctypes
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -111,6 +114,96 @@ def gcn_layer(h, weight, bias, trees, drop_p=0.0, seed=0, compute_dtype=torch.fl
     if compute == _lib.F32:
         out_dtype = torch.float32
     return _GCNLayerFn.apply(h, weight, bias, trees, float(drop_p), int(seed), compute, out_dtype, bool(no_adj))
+
+
+class _GCNStackFn(torch.autograd.Function):
+    """The whole L-layer stack as ONE op: sentence-resident kernels (csrc/stack_kernels.hip), one launch per direction."""
+
+    @staticmethod
+    def forward(ctx, x, trees, cfg, *params):
+        Ws, bs = params[0::2], params[1::2]
+        L = len(Ws)
+        B, T, Din = x.shape
+        H = Ws[0].shape[0]
+        lib, st, dev = _lib.lib(), _lib.stream(), x.device
+        x = x.contiguous()
+        dims = [(H, Din if l == 0 else H) for l in range(L)]
+        w32 = [w.detach().to(torch.float32).contiguous() for w in Ws]
+        b32 = [b.detach().to(torch.float32).contiguous() for b in bs]
+        u8 = dict(dtype=torch.uint8, device=dev)
+        wf = [torch.empty((lib.gcnpt_packed_bytes(h, k, _lib.BF16),), **u8) for h, k in dims]
+        wb = [torch.empty((lib.gcnpt_packed_bytes(k, h, _lib.BF16),), **u8) for h, k in dims]
+        ints = lambda v: (ctypes.c_int * L)(*v)  # noqa: E731
+        _lib.check(lib.gcnpt_pack_weights_multi(st, L, _lib.ptr_array(w32), ints([h for h, _ in dims]), ints([k for _, k in dims]),
+                                                _lib.BF16, _lib.ptr_array(wf), _lib.ptr_array(wb)))
+        need_w = any(p.requires_grad for p in params)
+        h_out = [torch.empty((B, T, H), dtype=torch.bfloat16 if l < L - 1 else cfg["out_dtype"], device=dev) for l in range(L)]
+        h_frag = [torch.empty((lib.gcnpt_stack_frag_bytes(B, T, k),), **u8) for _, k in dims] if need_w else [None] * L
+        g_ell = trees.empty_ell() if cfg["no_adj"] else trees.ell
+        _lib.check(lib.gcnpt_stack_fwd(
+            st, L, _lib.ptr(x), _lib.dtype_code(x.dtype), _lib.ptr_array(wf), _lib.ptr_array(b32), _lib.ptr(trees.row_ptr),
+            _lib.ptr(trees.col_idx), _lib.ptr(g_ell), _lib.ptr(trees.ell), B, T, Din, H, _lib.ptr_array(h_out),
+            _lib.dtype_code(cfg["out_dtype"]), (ctypes.c_float * L)(*cfg["drop_p"]), (ctypes.c_uint64 * L)(*cfg["seed"]),
+            _lib.ptr_array(h_frag), None, None))
+        ctx.save_for_backward(*h_out, *wb, *[f for f in h_frag if f is not None])
+        ctx.trees, ctx.cfg, ctx.dims, ctx.shape, ctx.need_w = trees, cfg, dims, (B, T, Din, H, L), need_w
+        ctx.x_dtype = x.dtype
+        ctx.param_dtypes = [p.dtype for p in params]
+        return h_out[-1]
+
+    @staticmethod
+    def backward(ctx, gout):
+        B, T, Din, H, L = ctx.shape
+        saved = ctx.saved_tensors
+        h_out, wb, h_frag = saved[:L], saved[L:2 * L], saved[2 * L:]
+        trees, cfg = ctx.trees, ctx.cfg
+        lib, st, dev = _lib.lib(), _lib.stream(), gout.device
+        gout = gout.to(h_out[-1].dtype).contiguous()
+        want_w = ctx.need_w and any(ctx.needs_input_grad[3:])
+        dx = torch.empty((B, T, Din), dtype=ctx.x_dtype, device=dev) if ctx.needs_input_grad[0] else None
+        g_frag, dWs, dbs = [None] * L, [None] * L, [None] * L
+        if want_w:
+            g_frag = [torch.empty((lib.gcnpt_stack_frag_bytes(B, T, H),), dtype=torch.uint8, device=dev) for _ in range(L)]
+            sizes = [h * k for h, k in ctx.dims] + [h for h, _ in ctx.dims]
+            flat = torch.zeros((sum(sizes),), dtype=torch.float32, device=dev)          # one memset for every accumulator
+            parts = torch.split(flat, sizes)
+            dWs = [parts[l].view(ctx.dims[l]) for l in range(L)]
+            dbs = list(parts[L:])
+        scale = [1.0 / (1.0 - p) if p > 0 else 1.0 for p in cfg["drop_p"]]
+        g_ellT = trees.empty_ell() if cfg["no_adj"] else trees.ellT
+        _lib.check(lib.gcnpt_stack_bwd(
+            st, L, _lib.ptr(gout), _lib.ptr_array(h_out), _lib.dtype_code(gout.dtype), _lib.ptr_array(wb), _lib.ptr(trees.ell),
+            _lib.ptr(trees.rowT_ptr), _lib.ptr(trees.colT_idx), _lib.ptr(g_ellT), B, T, Din, H, _lib.ptr(dx),
+            _lib.dtype_code(ctx.x_dtype), (ctypes.c_float * L)(*scale), _lib.ptr_array(g_frag), _lib.ptr_array(dbs)))
+        grads = [None] * (2 * L)
+        if want_w:
+            _lib.check(lib.gcnpt_stack_bwd_weight(st, L, _lib.ptr_array(g_frag), _lib.ptr_array(list(h_frag)), B, T, Din, H,
+                                                  _lib.ptr_array(dWs)))
+            for l in range(L):
+                grads[2 * l] = dWs[l].to(ctx.param_dtypes[2 * l])
+                grads[2 * l + 1] = dbs[l].to(ctx.param_dtypes[2 * l + 1])
+        return (dx, None, None) + tuple(grads)
+
+
+def gcn_stack_supported(T, Din, H, n_layers, compute_dtype=torch.bfloat16):
+    """Whether the sentence-resident one-launch-per-direction kernels handle this shape (else: one gcn_layer per layer)."""
+    return bool(_lib.lib().gcnpt_stack_supported(int(T), int(Din), int(H), int(n_layers), _lib.dtype_code(compute_dtype)))
+
+
+def gcn_stack(x, weights, biases, trees, drop_p=None, seeds=None, out_dtype=torch.float32, no_adj=False):
+    """
+    The reference's whole layer loop (model/gcn.py:266-393) as one op.  x [B,T,Din] float32/bfloat16 CUDA; weights /
+    biases: lists of the nn.Linear parameters; drop_p[l]: dropout applied to the output of layer l (0 for the last).
+    bf16 MFMA operands with fp32 accumulation; needs gcn_stack_supported(T, Din, H, L).
+    """
+    if not isinstance(trees, PrunedTrees):
+        raise TypeError("trees must be a PrunedTrees (see model.tree.prune_to_csr / adj_to_csr)")
+    _lib.require_gpu(x)
+    L = len(weights)
+    cfg = dict(drop_p=[float(p) for p in (drop_p or [0.0] * L)], seed=[int(s) for s in (seeds or [0] * L)],
+               out_dtype=out_dtype, no_adj=bool(no_adj))
+    params = [t for wb in zip(weights, biases) for t in wb]
+    return _GCNStackFn.apply(x, trees, cfg, *params)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -277,6 +370,14 @@ class GCN(nn.Module):
         trees = adj if isinstance(adj, PrunedTrees) else adj_to_csr(adj, want_label=False)   # gcn.py:260-262
         no_adj = bool(self.opt.get('no_adj', False))                                           # gcn.py:264-265
         x = gcn_inputs
+        B, T, Din = x.shape
+        if (self.compute_dtype == torch.bfloat16 and self.opt.get('gcn_fused', False)
+                and gcn_stack_supported(T, Din, self.mem_dim, self.layers)):
+            # whole stack in one launch per direction (sentence-resident kernels)
+            ps = [self.gcn_drop.p if (self.training and l < self.layers - 1) else 0.0 for l in range(self.layers)]
+            seeds = [int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0 for p in ps]
+            h = gcn_stack(x, [lin.weight for lin in self.W], [lin.bias for lin in self.W], trees, ps, seeds, torch.float32, no_adj)
+            return h, trees.pool_mask
         for l in range(self.layers):
             last = l == self.layers - 1
             p = self.gcn_drop.p if (self.training and not last) else 0.0                      # gcn.py:393

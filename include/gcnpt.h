@@ -148,6 +148,31 @@ int gcnpt_layer_bwd_data(void* stream, const void* dY, const void* Y, int g_dtyp
 int gcnpt_layer_bwd_weight(void* stream, const void* z_frag, const void* s_frag, int B, int T, int Din, int H,
                            float* dW, float* db, int compute_dtype);
 
+/* ---- optional: the whole L-layer stack in ONE launch per direction (sentence-resident kernels) ---------------
+ * A workgroup owns a whole sentence (T <= 112 rows) and runs every layer with the inter-layer activations in LDS;
+ * aggregation is done after the matrix product ((A+I)(h W^T)), LDS -> LDS, so nothing is ever gathered from HBM.
+ * bf16 MFMA operands / fp32 accumulate only; gcnpt_stack_supported() says whether a shape fits, otherwise use the
+ * per-layer entry points above (which these agree with to rounding).  Host arrays of n_layers device pointers.
+ *   gcnpt_stack_fwd : x [B*T,Din] -> h_out[l] = h_{l+1} [B*T,H] (bf16 for l < L-1, out_dtype for the last);
+ *                     h_frag[l]: NULL or gcnpt_stack_frag_bytes(B,T,width_l) bytes, the fragment image of the layer
+ *                     INPUT h_l (k-steps of 32 rows per sentence); zero_dW / zero_db: NULL or accumulators to clear.
+ *   gcnpt_stack_bwd : dY, Y[l] = h_{l+1} -> dx (NULL = not wanted), g_frag[l] = image of G_l = (A+I)^T dZ_l,
+ *                     db[l] += 2 sum dZ_l  (scale[l] = 1/(1-drop_p[l]) of the dropout applied to h_{l+1})
+ *   gcnpt_stack_bwd_weight : dW[l] += G_l^T h_l  (both images; dW cleared beforehand, e.g. by gcnpt_stack_fwd) */
+int gcnpt_stack_supported(int T, int Din, int H, int n_layers, int compute_dtype);
+size_t gcnpt_stack_frag_bytes(int B, int T, int width);
+int gcnpt_stack_fwd(void* stream, int n_layers, const void* x, int x_dtype, const void* const* w_fwd,
+                    const float* const* bias, const int32_t* row_ptr, const int32_t* col_idx, const int32_t* ell,
+                    const int32_t* deg_ell, int B, int T, int Din, int H, void* const* h_out, int out_dtype,
+                    const float* drop_p, const uint64_t* seed, void* const* h_frag, float* const* zero_dW,
+                    float* const* zero_db);
+int gcnpt_stack_bwd(void* stream, int n_layers, const void* dY, const void* const* Y, int g_dtype,
+                    const void* const* w_bwd, const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
+                    const int32_t* ellT, int B, int T, int Din, int H, void* dx, int dx_dtype, const float* scale,
+                    void* const* g_frag, float* const* db);
+int gcnpt_stack_bwd_weight(void* stream, int n_layers, const void* const* g_frag, const void* const* h_frag, int B, int T,
+                           int Din, int H, float* const* dW);
+
 #ifdef __cplusplus
 }
 #endif

@@ -369,6 +369,107 @@ def test_layers_full_size_vs_oracle(api, dev, cfg):
 
 
 # ---------------------------------------------------------------------------------------------------
+# sentence-resident stack (gcnpt_stack_fwd / bwd / bwd_weight): all layers in one launch per direction
+# ---------------------------------------------------------------------------------------------------
+def _run_fused(api, dev, g, trees=None, drop=None, no_adj=False, x_dtype=torch.float32, out_dtype=torch.float32):
+    gcn, tree = api
+    if trees is None:
+        trees = _prune(tree, g, int(g["prune_k"]), dev)
+    x = _t(g["x"], dev).to(x_dtype).requires_grad_()
+    Ws = [_t(w, dev).requires_grad_() for w in g["Ws"]]
+    bs = [_t(b, dev).requires_grad_() for b in g["bs"]]
+    L = len(Ws)
+    ps = [drop[0] if (drop and l < L - 1) else 0.0 for l in range(L)]
+    seeds = [drop[1] if (drop and l < L - 1) else 0 for l in range(L)]
+    h = gcn.gcn_stack(x, Ws, bs, trees, ps, seeds, out_dtype, no_adj)
+    inner = [t.detach().float().cpu().numpy() for t in h.grad_fn.saved_tensors[:L]]   # h_1 .. h_L as stored by the kernel
+    h.backward(_t(g["gy"], dev).to(out_dtype))
+    return dict(h=h.detach().float().cpu().numpy(), dx=x.grad.float().cpu().numpy(), dW=[w.grad.cpu().numpy() for w in Ws],
+                db=[b.grad.cpu().numpy() for b in bs], outs=inner)
+
+
+@pytest.mark.parametrize("name", LAYER_CASES[:4])        # c5s (T=300) does not fit a sentence-resident tile
+def test_fused_stack_golden(api, dev, name):
+    from oracle import gcn_ref
+    gcn, _ = api
+    g = layer_case(name)
+    assert gcn.gcn_stack_supported(int(g["T"]), int(g["din"]), int(g["hidden"]), int(g["layers"]))
+    r = _run_fused(api, dev, g)
+    assert max_rel(r["h"], g["h"]) <= 2e-2                             # vs the reference's fp32 output
+    L = int(g["layers"])
+    big = int(g["B"]) * int(g["T"]) >= 200
+    _check_bf16_grads(r, g["adj"], g, (g["dx"], [g["dW%d" % l] for l in range(L)], [g["db%d" % l] for l in range(L)]) if big else None)
+    # and against the per-layer kernels: same mathematics, different summation order ((A+I)(hW^T) vs ((A+I)h)W^T)
+    p = _run_stack(api, dev, g, torch.bfloat16)
+    assert max_rel(r["h"], p["h"]) <= BF16_TIGHT
+
+
+@pytest.mark.parametrize("cfg", [dict(B=50, T=100, din=360, hid=200, K=1, lengths="full", L=2),
+                                 dict(B=50, T=100, din=400, hid=200, K=1, lengths="tacred", L=2),
+                                 dict(B=7, T=112, din=448, hid=192, K=2, lengths="tacred", L=3),
+                                 dict(B=5, T=33, din=44, hid=24, K=1, lengths="tacred", L=1),
+                                 dict(B=3, T=17, din=37, hid=19, K=3, lengths="full", L=4)])
+def test_fused_stack_vs_oracle(api, dev, cfg):
+    """BASELINE configs 2 and 3 at full size, the largest shape the kernels take, and odd widths / depths."""
+    from gcn_over_pruned_trees_amd.utils import synthetic
+    from oracle import gcn_ref, prune_ref
+    B, T, din, hid, K, L = cfg["B"], cfg["T"], cfg["din"], cfg["hid"], cfg["K"], cfg["L"]
+    tb = synthetic.random_tree_batch(4321, B, T, cfg["lengths"])
+    adj = prune_ref.batch_adj(tb["head"], tb["subj_pos"], tb["obj_pos"], tb["deprel"], tb["lens"], K)["adj"]
+    Ws, bs = synthetic.layer_params(2, [din] + [hid] * L)
+    g = dict(tb, x=synthetic.normal(3, (B, T, din)), gy=synthetic.normal(4, (B, T, hid)), Ws=Ws, bs=bs, prune_k=K)
+    h, _ = gcn_ref.gcn_forward(adj, g["x"], Ws, bs)
+    r = _run_fused(api, dev, g)
+    assert max_rel(r["h"], h) <= 2e-2
+    fro = gcn_ref.gcn_backward(adj, g["x"], Ws, bs, g["gy"]) if B * T >= 2000 else None
+    _check_bf16_grads(r, adj, g, fro)
+    # bf16 in / bf16 out (the bench configuration) runs the other instantiations
+    r16 = _run_fused(api, dev, g, x_dtype=torch.bfloat16, out_dtype=torch.bfloat16)
+    assert max_rel(r16["h"], h) <= 3e-2
+
+
+def test_fused_stack_dropout_no_adj_and_dense_adjacency(api, dev):
+    from oracle import gcn_ref
+    gcn, tree = api
+    g = layer_case("layers_c2s.npz")
+    base = _run_fused(api, dev, g)
+    p = 0.5
+    r1 = _run_fused(api, dev, g, drop=(p, 777))
+    r2 = _run_fused(api, dev, g, drop=(p, 777))
+    y, yd = base["outs"][0], r1["outs"][0]
+    np.testing.assert_array_equal(yd, r2["outs"][0])
+    kept, pos = yd != 0, y > 0
+    assert not kept[~pos].any()
+    np.testing.assert_allclose(yd[kept], gcn_ref.round_bf16(y[kept] * 2.0), rtol=2 ** -7)
+    assert abs(kept[pos].mean() - (1 - p)) < 0.01
+    # the per-layer kernels draw the same mask from (seed, row, column)
+    pl = _run_stack(api, dev, g, torch.bfloat16, drop=(p, 777))
+    agree = ((pl["outs"][0] != 0) == kept)[pos & (np.abs(y) > 1e-2)]
+    assert agree.mean() > 0.999
+    mask = np.where(pos, kept, True).astype(np.float32)
+    dx, dWs, dbs = gcn_ref.gcn_backward(g["adj"], g["x"], g["Ws"], g["bs"], g["gy"], drop_masks=[mask], drop_p=p, acts=r1["outs"])
+    assert max_rel(r1["dx"], dx) <= BF16_GRAD
+    for l in range(2):
+        assert max_rel(r1["dW"][l], dWs[l]) <= BF16_GRAD and max_rel(r1["db"][l], dbs[l]) <= BF16_GRAD
+    # no_adj ablation (gcn.py:264-265)
+    r = _run_fused(api, dev, g, no_adj=True)
+    h, _ = gcn_ref.gcn_forward(g["adj"], g["x"], g["Ws"], g["bs"], no_adj=True)
+    dx, dWs, dbs = gcn_ref.gcn_backward(g["adj"], g["x"], g["Ws"], g["bs"], g["gy"], no_adj=True, acts=r["outs"])
+    assert max_rel(r["h"], h) <= 2e-2 and max_rel(r["dx"], dx) <= BF16_GRAD and max_rel(r["dW"][0], dWs[0]) <= BF16_GRAD
+    # arbitrary (non-symmetric, > 7 entries per row) dense adjacency: the CSR continuation and the transposed pattern
+    rng = np.random.RandomState(5)
+    B, T = 3, 40
+    adj = ((rng.random_sample((B, T, T)) < 0.3) * rng.randint(1, 40, size=(B, T, T))).astype(np.float32)
+    Ws = [rng.uniform(-.2, .2, (24, 40)).astype(np.float32), rng.uniform(-.2, .2, (24, 24)).astype(np.float32)]
+    bs = [rng.uniform(-.2, .2, (24,)).astype(np.float32) for _ in range(2)]
+    gd = dict(x=rng.standard_normal((B, T, 40)).astype(np.float32), gy=rng.standard_normal((B, T, 24)).astype(np.float32), Ws=Ws, bs=bs)
+    r = _run_fused(api, dev, gd, trees=tree.adj_to_csr(_t(adj, dev)))
+    h, _ = gcn_ref.gcn_forward(adj, gd["x"], Ws, bs)
+    assert max_rel(r["h"], h) <= 2e-2
+    _check_bf16_grads(r, adj, gd)
+
+
+# ---------------------------------------------------------------------------------------------------
 # drop-in boundary: the reference's module surface
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("tag", ["gcn", "cgcn"])
@@ -387,6 +488,18 @@ def test_classifier_end_to_end_golden(api, dev, tag):
         logits, pooled = model(inputs)
     assert max_rel(logits.cpu().numpy(), g["logits"]) <= 1e-4
     assert max_rel(pooled.cpu().numpy(), g["pooling_output"]) <= 1e-4
+    # bf16 stack (sentence-resident kernels): same logits to bf16 accuracy
+    for fused in (False, True):
+        m16 = gcn.GCNClassifier(dict(opt, gcn_dtype="bf16", gcn_fused=fused))
+        m16.load_state_dict(sd, strict=True)
+        m16.to(dev).eval()
+        with torch.no_grad():
+            l16, _ = m16(inputs)
+        assert max_rel(l16.cpu().numpy(), g["logits"]) <= 3e-2
+        m16.train()
+        l16, p16 = m16(inputs)
+        (l16.logsumexp(1).mean() + 1e-3 * m16.conv_l2()).backward()
+        assert all(torch.isfinite(lin.weight.grad).all() and lin.weight.grad.abs().sum() > 0 for lin in m16.get_gcn_parameters())
     # training mode: a full update step runs (dropout on, grads reach every parameter of the layer stack)
     model.train()
     logits, pooled = model(inputs)

@@ -33,8 +33,7 @@ def main():
     L.gcnpt_debug_set_knob(knob)
     print("knob =", knob)
     buf = torch.zeros((4096 * 16,), dtype=torch.int64, device=dev)
-    calls = [("prune", stack.prune), ("fwd0", lambda: stack.fwd(0)), ("fwd1", lambda: stack.fwd(1)), ("bwd_data1", lambda: stack.bwd_data(1)),
-             ("bwd_weight1", lambda: stack.bwd_weight(1)), ("bwd_data0", lambda: stack.bwd_data(0)), ("bwd_weight0", lambda: stack.bwd_weight(0))]
+    calls = [("prune", stack.prune)] + stack.calls(0)[1:]
     for _ in range(5):
         stack.step()
     torch.cuda.synchronize()

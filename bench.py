@@ -54,8 +54,12 @@ def parse():
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="2 = run layer-1 bwd-weight beside layer-0 bwd-data (and the tree build beside the pack) on a side stream; "
                          "measured slower than 1 on MI355X: the cross-stream graph edges cost more than the overlap gains")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-threads", type=int, default=4,
+                    help="BLAS threads of the CPU baseline (4 measured fastest on the bench box: 1169 sentences/s vs 701 at 16 and 749 at 128; "
+                         "the matrices are small)")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
     return ap.parse_args()
 
@@ -329,7 +333,8 @@ def cpu_baseline(args, seconds):
     from gcn_over_pruned_trees_amd.utils import synthetic
     from oracle import gcn_ref, prune_ref
     try:
-        from threadpoolctl import threadpool_info
+        from threadpoolctl import threadpool_info, threadpool_limits
+        threadpool_limits(limits=max(1, min(args.cpu_threads, os.cpu_count() or 1)))
         cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
         cores = os.cpu_count() or 1
@@ -361,9 +366,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ.get("GCNPT_BENCH_ONE_DEVICE"):          # rehearsal of the N > 1 code path on a 1-GPU box (with --dist-backend gloo)
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        barrier = lambda: dist.barrier(device_ids=[local])  # noqa: E731
+        dist.init_process_group(args.dist_backend)
+        barrier = dist.barrier
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -379,7 +386,8 @@ def main():
     # ---- the timed step: layer stack fwd+bwd (+ overlapped gradient all-reduce when N > 1)
     replays = [capture(lambda k=k: stack.step(k), use_graph) for k in range(2 if world > 1 else 1)]
     graphed = replays[0][1]
-    reducer = OverlappedAllReduce(stack.buckets, dist, average=True) if world > 1 else None
+    # SUM, not AVG: the 1/world factor belongs to the optimizer's learning rate, and SUM is supported by every backend
+    reducer = OverlappedAllReduce(stack.buckets, dist, average=False) if world > 1 else None
 
     def run(i):
         k = i & 1 if world > 1 else 0
@@ -440,11 +448,11 @@ def main():
             tot_b = sum(alg[k] for k in step_keys)
             result["step_roofline"] = {"algorithmic_bytes": tot_b, "sum_kernel_us": sum(kt[k] for k in step_keys) * 1e6,
                                        "frac_of_hbm_peak": tot_b / sum(kt[k] for k in step_keys) / 1e9 / HBM_PEAK_GBS}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         print(json.dumps(result))
     if world > 1:
-        dist.barrier(device_ids=[local])
+        dist.barrier()
         dist.destroy_process_group()
     return result
 

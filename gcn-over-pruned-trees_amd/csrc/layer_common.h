@@ -77,9 +77,9 @@ __host__ __device__ inline int lds_stride_dw(int payload_dw) {
 // 16 bits each, so the mask is a pure function of (seed, row, col) whatever the kernel's tiling is
 __device__ __forceinline__ unsigned drop_hash(uint64_t seed, unsigned row, unsigned col_pair) {
     unsigned x = row * 0x9E3779B1u + col_pair * 0x85EBCA77u + (unsigned)seed;
-    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-    x += (unsigned)(seed >> 32) * 0xC2B2AE3Du;
-    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12;
+    x ^= x >> 15; x *= 0x2C1B3C6Du;
+    x += (unsigned)(seed >> 32);
+    x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
     return x;
 }
 __device__ __forceinline__ bool drop_keep(unsigned hash, unsigned col, unsigned thresh16) {

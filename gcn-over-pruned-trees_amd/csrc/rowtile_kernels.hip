@@ -129,12 +129,18 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
     float bias2[NTW][4];
     auto load_bias = [&](int pass) {
 #pragma unroll
-        for (int j = 0; j < NTW; ++j)
+        for (int j = 0; j < NTW; ++j) {
+            const int col0 = (pass * RT_WAVES * NTW + j * RT_WAVES + wave) * 16 + (lane >> 4) * 4;
+            if ((p.NOUT & 3) == 0) {                                  // kernel-uniform: one 16-byte load per tile
+                const float4 bv = *reinterpret_cast<const float4*>(p.bias + min(col0, p.NOUT - 4));
+                const bool in = col0 < p.NOUT;
+                bias2[j][0] = in ? 2.0f * bv.x : 0.0f; bias2[j][1] = in ? 2.0f * bv.y : 0.0f;     // enters twice, gcn.py:270-271
+                bias2[j][2] = in ? 2.0f * bv.z : 0.0f; bias2[j][3] = in ? 2.0f * bv.w : 0.0f;
+            } else {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col = (pass * RT_WAVES * NTW + j * RT_WAVES + wave) * 16 + (lane >> 4) * 4 + g;
-                bias2[j][g] = BWD ? 0.0f : 2.0f * p.bias[min(col, p.NOUT - 1)];        // enters twice, gcn.py:270-271
+                for (int g = 0; g < 4; ++g) bias2[j][g] = 2.0f * p.bias[min(col0 + g, p.NOUT - 1)];
             }
+        }
     };
     if (p.out) {
         load_w(0, 0);                                          // 156 KB per workgroup at Din=360, H=200

@@ -288,12 +288,10 @@ class GCNRelationModel(nn.Module):
         if self.opt.get('gcn_check_trees', True):
             trees.check(expect_maxlen=head.shape[1])
         h, pool_mask = self.gcn(trees, inputs)
-        subj_mask = subj_pos.ne(0).unsqueeze(2)      # gcn.py:116 (True = not a subject token)
-        obj_mask = obj_pos.ne(0).unsqueeze(2)
-        kind = self.opt['pooling']
-        h_out = pool(h, pool_mask, type=kind)
-        outputs = torch.cat([h_out, pool(h, subj_mask, type=kind), pool(h, obj_mask, type=kind)], dim=1)
-        return self.out_mlp(outputs), h_out
+        # gcn.py:116-121: three masked poolings and the concat, one pass over h (masks straight from the position tensors)
+        pooled = pool3(h, pool_mask, subj_pos, obj_pos, type=self.opt['pooling'])
+        h_out = pooled[:, :self.opt['hidden_dim']]
+        return self.out_mlp(pooled), h_out
 
 
 class GCN(nn.Module):
@@ -385,6 +383,48 @@ class GCN(nn.Module):
             out_dtype = torch.float32 if last else self.compute_dtype
             x = gcn_layer(x, self.W[l].weight, self.W[l].bias, trees, p, seed, self.compute_dtype, out_dtype, no_adj)
         return x, trees.pool_mask
+
+
+class _Pool3Fn(torch.autograd.Function):
+    """[pool(h, pool_mask) | pool(h, subj_pos != 0) | pool(h, obj_pos != 0)] in one pass (csrc/pool_kernels.hip)."""
+
+    @staticmethod
+    def forward(ctx, h, pool_mask, subj_pos, obj_pos, kind):
+        B, T, H = h.shape
+        lib, st = _lib.lib(), _lib.stream()
+        h = h.contiguous()
+        pm = pool_mask.contiguous()
+        sp, op = subj_pos.contiguous(), obj_pos.contiguous()
+        out = torch.empty((B, 3 * H), dtype=torch.float32, device=h.device)
+        argmax = torch.empty((B, 3, H), dtype=torch.int32, device=h.device) if kind == 0 else None
+        _lib.check(lib.gcnpt_pool3_fwd(st, _lib.ptr(h), _lib.dtype_code(h.dtype), _lib.ptr(pm), _lib.ptr(sp), _lib.ptr(op), B, T, H, kind,
+                                       _lib.ptr(out), _lib.ptr(argmax)))
+        ctx.save_for_backward(pm, sp, op, argmax)
+        ctx.kind, ctx.shape, ctx.h_dtype = kind, (B, T, H), h.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pm, sp, op, argmax = ctx.saved_tensors
+        B, T, H = ctx.shape
+        dh = torch.empty((B, T, H), dtype=ctx.h_dtype, device=g.device)
+        g = g.to(torch.float32).contiguous()
+        _lib.check(_lib.lib().gcnpt_pool3_bwd(_lib.stream(), _lib.ptr(g), _lib.ptr(argmax), _lib.ptr(pm), _lib.ptr(sp), _lib.ptr(op), B, T, H,
+                                              ctx.kind, _lib.ptr(dh), _lib.dtype_code(ctx.h_dtype)))
+        return dh, None, None, None, None
+
+
+def pool3(h, pool_mask, subj_pos, obj_pos, type='max'):
+    """
+    The three poolings of GCNRelationModel.forward (model/gcn.py:116-121) fused: returns float32 [B, 3H] =
+    cat([pool(h, pool_mask), pool(h, subj_pos != 0), pool(h, obj_pos != 0)], dim=1) with pool() of model/gcn.py:473-483.
+    h [B,T,H] float32/bfloat16 CUDA, pool_mask bool [B,T,1] (True = excluded), subj_pos / obj_pos int64 [B,T].
+    """
+    _lib.require_gpu(h)
+    if pool_mask.dtype not in (torch.bool, torch.uint8) or subj_pos.dtype != torch.int64 or obj_pos.dtype != torch.int64:
+        raise TypeError("pool3: pool_mask must be bool/uint8, subj_pos / obj_pos int64")
+    kind = 0 if type == 'max' else (1 if type == 'avg' else 2)
+    return _Pool3Fn.apply(h, pool_mask, subj_pos, obj_pos, kind)
 
 
 def pool(h, mask, type='max'):

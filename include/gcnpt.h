@@ -173,6 +173,16 @@ int gcnpt_stack_bwd(void* stream, int n_layers, const void* dY, const void* cons
 int gcnpt_stack_bwd_weight(void* stream, int n_layers, const void* const* g_frag, const void* const* h_frag, int B, int T,
                            int Din, int H, float* const* dW);
 
+/* ---- N1: the consumer right after the path, model/gcn.py:116-121 + pool() 473-483 ---------------------------------
+ * One pass over h [B*T,H] (h_dtype) produces out [B, 3H] float32 = [pool(h, pool_mask) | pool(h, subj_pos != 0) |
+ * pool(h, obj_pos != 0)], the row the output MLP reads.  type: 0 = max (masked tokens count as -1e12; ties go to the
+ * first token, as torch.max(dim) does; argmax int32 [B,3,H] is recorded for backward), 1 = avg, 2 = sum.
+ * gcnpt_pool3_bwd writes dh [B*T,H] completely (masked tokens get 0, as masked_fill blocks their gradient). */
+int gcnpt_pool3_fwd(void* stream, const void* h, int h_dtype, const uint8_t* pool_mask, const int64_t* subj_pos,
+                    const int64_t* obj_pos, int B, int T, int H, int type, float* out, int32_t* argmax);
+int gcnpt_pool3_bwd(void* stream, const float* g, const int32_t* argmax, const uint8_t* pool_mask, const int64_t* subj_pos,
+                    const int64_t* obj_pos, int B, int T, int H, int type, void* dh, int dh_dtype);
+
 #ifdef __cplusplus
 }
 #endif

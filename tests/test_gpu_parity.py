@@ -510,6 +510,37 @@ def test_classifier_end_to_end_golden(api, dev, tag):
     assert model.gcn_model.emb.weight.grad.abs().sum() > 0
 
 
+@pytest.mark.parametrize("kind", ["max", "avg", "sum"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pool3_matches_three_pool_calls(api, dev, kind, dtype):
+    """N1: fused pooling == the reference's three pool() calls (gcn.py:116-121, 473-483), values and gradients.
+    The reference side is evaluated on the CPU, where torch.max(dim) returns the first maximum."""
+    gcn, _ = api
+    rng = np.random.RandomState(9)
+    B, T, H = 6, 37, 200
+    h = np.maximum(rng.standard_normal((B, T, H)), 0).astype(np.float32)       # relu output: many exact ties at 0
+    h[0, :, :5] = 0.0
+    pool_mask = rng.random_sample((B, T, 1)) < 0.6
+    pool_mask[1] = True                                                          # a fully masked sentence (one-node tree)
+    subj = rng.randint(-5, 6, size=(B, T)).astype(np.int64)
+    obj = rng.randint(-3, 4, size=(B, T)).astype(np.int64)
+    subj[:, 3] = 0; obj[:, 7] = 0
+    if kind == "avg":
+        pool_mask[1, 0] = False                                                  # avg of nothing is 0/0 in the reference too
+    hq = torch.from_numpy(h).to(dtype).float()                                   # what the kernel sees
+    hr = hq.clone().requires_grad_()
+    ref = torch.cat([gcn.pool(hr, torch.from_numpy(pool_mask), kind), gcn.pool(hr, torch.from_numpy(subj != 0)[..., None], kind),
+                     gcn.pool(hr, torch.from_numpy(obj != 0)[..., None], kind)], dim=1)
+    gy = torch.from_numpy(rng.standard_normal((B, 3 * H)).astype(np.float32))
+    ref.backward(gy)
+    hd = hq.to(dev).to(dtype).requires_grad_()
+    out = gcn.pool3(hd, _t(pool_mask, dev), _t(subj, dev), _t(obj, dev), kind)
+    out.backward(gy.to(dev))
+    tol = 1e-6 if dtype == torch.float32 else 1e-2
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=tol, atol=tol)
+    np.testing.assert_allclose(hd.grad.float().cpu().numpy(), hr.grad.numpy(), rtol=tol, atol=tol)
+
+
 def test_inputs_to_tree_reps_matches_reference_layout(api, dev):
     _, tree = api
     g = load_golden("trees_tacred_samples.npz")

@@ -29,6 +29,8 @@ SIGNATURES = {
     "gcnpt_layer_bwd_weight": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _i]),
     "gcnpt_pool3_fwd": (_i, [_p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "gcnpt_pool3_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i]),
+    "gcnpt_diag_layer_fwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p, _f, _u64]),
+    "gcnpt_diag_layer_bwd": (_i, [_p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _f]),
     "gcnpt_stack_supported": (_i, [_i, _i, _i, _i, _i]),
     "gcnpt_stack_frag_bytes": (_sz, [_i, _i, _i]),
     "gcnpt_stack_fwd": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p]),

@@ -239,14 +239,17 @@ class GCNRelationModel(nn.Module):
         super().__init__()
         self.opt = opt
         self.emb_matrix = emb_matrix
-        if opt.get('adj_type', 'regular') != 'regular':
-            raise NotImplementedError("adj_type=%r: only the 'regular' adjacency path is built so far "
-                                      "(diagonal_deprel / full_deprel are the next rows of the scope table)" % opt['adj_type'])
+        self.adj_type = opt.get('adj_type', 'regular')
+        if self.adj_type not in ('regular', 'diagonal_deprel'):
+            raise NotImplementedError("adj_type=%r: 'regular' and 'diagonal_deprel' are built; full_deprel is the next "
+                                      "row of the scope table" % opt['adj_type'])
         self.emb = nn.Embedding(opt['vocab_size'], opt['emb_dim'], padding_idx=constant.PAD_ID)
         self.pos_emb = nn.Embedding(constant.N_POS, opt['pos_dim']) if opt['pos_dim'] > 0 else None
         self.ner_emb = nn.Embedding(constant.N_NER, opt['ner_dim']) if opt['ner_dim'] > 0 else None
-        # the reference keeps a 1-wide dummy table on the regular path (gcn.py:53-56); kept for checkpoints
-        self.deprel_emb = nn.Embedding(constant.N_DEPREL, 1, padding_idx=0)
+        # gcn.py:48-56: the reference keeps a 1-wide dummy table on the regular path (kept for checkpoints);
+        # diagonal_deprel scales hidden vectors element-wise, so its table is hidden_dim wide
+        self.deprel_emb = nn.Embedding(constant.N_DEPREL, opt['hidden_dim'] if self.adj_type == 'diagonal_deprel' else 1,
+                                       padding_idx=0)
         self.init_embeddings()
         self.gcn = GCN(opt, (self.emb, self.pos_emb, self.ner_emb, self.deprel_emb), opt['hidden_dim'], opt['num_layers'])
         mlp = [nn.Linear(opt['hidden_dim'] * 3, opt['hidden_dim']), nn.ReLU()]
@@ -284,7 +287,8 @@ class GCNRelationModel(nn.Module):
         else:
             words, masks, pos, deprel, head, subj_pos, obj_pos = inputs
         # lengths, head_to_tree, tree_to_adj and the upload (gcn.py:96-112) in one launch, no host round trip
-        trees = prune_to_csr(head, subj_pos, obj_pos, deprel, self.opt['prune_k'], masks=masks, want_label=False)
+        trees = prune_to_csr(head, subj_pos, obj_pos, deprel, self.opt['prune_k'], masks=masks,
+                             want_label=self.adj_type != 'regular')
         if self.opt.get('gcn_check_trees', True):
             trees.check(expect_maxlen=head.shape[1])
         h, pool_mask = self.gcn(trees, inputs)
@@ -295,8 +299,8 @@ class GCNRelationModel(nn.Module):
 
 
 class GCN(nn.Module):
-    """Reference model/gcn.py:128-395, `regular` adjacency.  `adj` may be a dense float32 [B,T,T] tensor
-    (as the reference passes) or a PrunedTrees from model.tree."""
+    """Reference model/gcn.py:128-395, `regular` and `diagonal_deprel` adjacency types.  `adj` may be a dense
+    float32 [B,T,T] tensor (as the reference passes) or a PrunedTrees from model.tree."""
 
     def __init__(self, opt, embeddings, mem_dim, num_layers):
         super().__init__()
@@ -307,8 +311,9 @@ class GCN(nn.Module):
         tacred = opt['dataset'] == 'tacred'
         self.in_dim = opt['emb_dim'] + opt['pos_dim'] + (opt['ner_dim'] if tacred else 0)
         self.emb, self.pos_emb, self.ner_emb, self.deprel_emb = embeddings
-        if opt.get('adj_type', 'regular') != 'regular':
-            raise NotImplementedError("adj_type=%r is not built yet; only 'regular'" % opt['adj_type'])
+        self.adj_type = opt.get('adj_type', 'regular')
+        if self.adj_type not in ('regular', 'diagonal_deprel'):
+            raise NotImplementedError("adj_type=%r is not built yet; 'regular' and 'diagonal_deprel' are" % opt['adj_type'])
         if opt.get('rnn', False):
             self.rnn = nn.LSTM(self.in_dim, opt['rnn_hidden'], opt['rnn_layers'], batch_first=True,
                                dropout=opt['rnn_dropout'], bidirectional=True)
@@ -317,13 +322,19 @@ class GCN(nn.Module):
         self.in_drop = nn.Dropout(opt['input_dropout'])
         self.gcn_drop = nn.Dropout(opt['gcn_dropout'])
         self.emb_dropout = opt.get('emb_dropout', 0.0)
-        self.W = nn.ModuleList(nn.Linear(self.in_dim if l == 0 else mem_dim, mem_dim) for l in range(num_layers))
+        if self.adj_type == 'diagonal_deprel':                  # gcn.py:153-155: no per-layer weights in this variant
+            self.preprocessor = nn.Linear(self.in_dim, mem_dim)
+            self.in_dim = mem_dim
+        else:
+            self.W = nn.ModuleList(nn.Linear(self.in_dim if l == 0 else mem_dim, mem_dim) for l in range(num_layers))
         kind = opt.get('gcn_dtype', 'fp32')
         if kind not in ('fp32', 'bf16'):
             raise ValueError("gcn_dtype must be 'fp32' or 'bf16'")
         self.compute_dtype = torch.float32 if kind == 'fp32' else torch.bfloat16
 
     def conv_l2(self):
+        # the reference's diagonal_deprel model has no W list, so its conv_l2() / get_gcn_parameters() raise
+        # AttributeError (gcn.py:207-215); the same happens here
         return sum(p.pow(2).sum() for lin in self.W for p in (lin.weight, lin.bias))
 
     def get_gcn_parameters(self):
@@ -348,6 +359,21 @@ class GCN(nn.Module):
         out, _ = nn.utils.rnn.pad_packed_sequence(out, batch_first=True)
         return out
 
+    def _forward_diagonal(self, adj, gcn_inputs, deprel):
+        """gcn.py:255-257, 272-294: Linear preprocessor (host BLAS), then the element-wise relation-scaled layers.
+        no_adj has no effect on this variant in the reference either (it only zeroes the matrix the regular path uses)."""
+        trees = adj if isinstance(adj, PrunedTrees) else adj_to_csr(adj, want_label=True)
+        x = self.preprocessor(gcn_inputs).to(self.compute_dtype)
+        table = self.deprel_emb.weight            # padding_idx=0: nn.Embedding's backward would zero row 0, the hook below does
+        if table.requires_grad and not getattr(self, '_pad_hooked', False):
+            table.register_hook(_zero_pad_row)
+            self._pad_hooked = True
+        for l in range(self.layers):
+            p = self.gcn_drop.p if (self.training and l < self.layers - 1) else 0.0
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
+            x = diag_layer(x, table, deprel, trees, p, seed)
+        return x.float(), trees.pool_mask
+
     def forward(self, adj, inputs):
         if self.opt['dataset'] == 'tacred':
             words, masks, pos, ner, deprel, head, subj_pos, obj_pos = inputs
@@ -365,6 +391,8 @@ class GCN(nn.Module):
         else:
             gcn_inputs = embs
 
+        if self.adj_type == 'diagonal_deprel':
+            return self._forward_diagonal(adj, gcn_inputs, deprel)
         trees = adj if isinstance(adj, PrunedTrees) else adj_to_csr(adj, want_label=False)   # gcn.py:260-262
         no_adj = bool(self.opt.get('no_adj', False))                                           # gcn.py:264-265
         x = gcn_inputs
@@ -383,6 +411,57 @@ class GCN(nn.Module):
             out_dtype = torch.float32 if last else self.compute_dtype
             x = gcn_layer(x, self.W[l].weight, self.W[l].bias, trees, p, seed, self.compute_dtype, out_dtype, no_adj)
         return x, trees.pool_mask
+
+
+def _zero_pad_row(grad):
+    grad = grad.clone()
+    grad[0].zero_()
+    return grad
+
+
+class _DiagLayerFn(torch.autograd.Function):
+    """One diagonal_deprel layer (csrc/diag_kernels.hip): reference model/gcn.py:272-294 + 390-393."""
+
+    @staticmethod
+    def forward(ctx, h, emb, deprel, trees, drop_p, seed):
+        for t in (h, emb, deprel):
+            _lib.require_gpu(t)
+        if trees.label is None:
+            raise ValueError("diagonal_deprel needs the adjacency values: build the trees with want_label=True")
+        B, T = trees.B, trees.T
+        H = h.shape[-1]
+        if h.shape[0] * h.shape[1] != B * T or emb.shape != (constant.N_DEPREL, H) or deprel.numel() != B * T:
+            raise ValueError("diag layer: h %s, table %s, deprel %s do not fit %d x %d trees" %
+                             (tuple(h.shape), tuple(emb.shape), tuple(deprel.shape), B, T))
+        h = h.contiguous()
+        E = emb.detach().float().contiguous()
+        deprel = deprel.contiguous()
+        out = torch.empty_like(h)
+        _lib.check(_lib.lib().gcnpt_diag_layer_fwd(_lib.stream(), _lib.ptr(h), _lib.dtype_code(h.dtype), _lib.ptr(E), _lib.ptr(deprel),
+                                                   _lib.ptr(trees.row_ptr), _lib.ptr(trees.col_idx), _lib.ptr(trees.label), B, T, H,
+                                                   _lib.ptr(out), float(drop_p), int(seed)))
+        ctx.trees, ctx.scale = trees, (1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0)
+        ctx.save_for_backward(h, out, E, deprel)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        h, out, E, deprel = ctx.saved_tensors
+        trees = ctx.trees
+        B, T, H = trees.B, trees.T, h.shape[-1]
+        gout = gout.to(h.dtype).contiguous()
+        dh = torch.empty_like(h)
+        dE = torch.zeros_like(E)
+        _lib.check(_lib.lib().gcnpt_diag_layer_bwd(_lib.stream(), _lib.ptr(gout), _lib.ptr(out), _lib.ptr(h), _lib.dtype_code(h.dtype),
+                                                   _lib.ptr(E), _lib.ptr(deprel), _lib.ptr(trees.row_ptr), _lib.ptr(trees.col_idx),
+                                                   _lib.ptr(trees.label), _lib.ptr(trees.rowT_ptr), _lib.ptr(trees.colT_idx), B, T, H,
+                                                   _lib.ptr(dh), _lib.ptr(dE), ctx.scale))
+        return dh, dE, None, None, None, None
+
+
+def diag_layer(h, deprel_table, deprel, trees, drop_p=0.0, seed=0):
+    """dropout(relu(((F (E[deprel] * h)) + (R (E[deprel+42] * h)) + E[84] * h) / (deg + 1))) for h [B,T,H] (fp32 or bf16)."""
+    return _DiagLayerFn.apply(h, deprel_table, deprel, trees, drop_p, seed)
 
 
 class _Pool3Fn(torch.autograd.Function):

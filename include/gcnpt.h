@@ -183,6 +183,22 @@ int gcnpt_pool3_fwd(void* stream, const void* h, int h_dtype, const uint8_t* poo
 int gcnpt_pool3_bwd(void* stream, const float* g, const int32_t* argmax, const uint8_t* pool_mask, const int64_t* subj_pos,
                     const int64_t* obj_pos, int B, int T, int H, int type, void* dh, int dh_dtype);
 
+/* ---- N2: adj_type == 'diagonal_deprel', model/gcn.py:272-294 (+ 390-393) -------------------------------------------
+ * No weight matrix: out[r] = dropout(relu((sum_{c: 0<adj[r,c]<42} E[deprel[c]]*h[c] + sum_{c: 42<adj[r,c]<84}
+ * E[deprel[c]+42]*h[c] + E[84]*h[r]) / (deg[r]+1))), all products element-wise over the H columns.  h, out, Y, dY, dh
+ * are [B*T,H] of `dtype`; E is the float32 [85,H] relation embedding table (model/gcn.py:56-57); deprel int64 [B*T];
+ * row_ptr/col_idx/label and rowT_ptr/colT_idx as gcnpt_prune_to_csr / gcnpt_adj_to_csr write them (label = the adj value).
+ * The preprocessor Linear in front of the layers (gcn.py:257) is a plain GEMM and stays with the host's BLAS.
+ * gcnpt_diag_layer_bwd writes dh completely and ACCUMULATES into dE [85,H] float32 (the same table feeds every layer:
+ * the caller clears it once per backward pass); scale = 1/(1-drop_p) of the forward call. */
+int gcnpt_diag_layer_fwd(void* stream, const void* h, int dtype, const float* E, const int64_t* deprel,
+                         const int32_t* row_ptr, const int32_t* col_idx, const int32_t* label, int B, int T, int H,
+                         void* out, float drop_p, uint64_t seed);
+int gcnpt_diag_layer_bwd(void* stream, const void* dY, const void* Y, const void* h, int dtype, const float* E,
+                         const int64_t* deprel, const int32_t* row_ptr, const int32_t* col_idx, const int32_t* label,
+                         const int32_t* rowT_ptr, const int32_t* colT_idx, int B, int T, int H, void* dh, float* dE,
+                         float scale);
+
 #ifdef __cplusplus
 }
 #endif

@@ -148,3 +148,62 @@ def gcn_forward_bf16(adj, x, weights, biases, drop_masks=None, drop_p=0.0):
         h = round_bf16(g)
         acts.append(h)
     return h, mask, acts
+
+
+# ----------------------------------------------------------------------------------------------
+# adj_type == 'diagonal_deprel' (SURVEY.md 8f row N2): reference model/gcn.py:153-155, 255-257, 272-294.
+# No per-layer weight matrix: a Linear "preprocessor" in front, then every layer scales each neighbour
+# row ELEMENT-WISE by the embedding of a dependency relation:
+#   forward edges  (0 < adj[r,c] < 42):   E[deprel[c]]      * h[c]
+#   reverse edges  (42 < adj[r,c] < 84):  E[deprel[c] + 42] * h[c]     (the COLUMN token's relation, as the reference does)
+#   self           E[84] * h[r]           (the diagonal 84 of adj is in neither range)
+# ----------------------------------------------------------------------------------------------
+DEPREL_FORWARD_BOUND, DEPREL_REVERSE_BOUND, SELF_LOOP_INDEX = 42, 84, 84   # utils/constant.py:14-17
+
+
+def diag_forward(adj, x, deprel, Wp, bp, E, layers, drop_masks=None, drop_p=0.0, return_saved=False):
+    A, denom, mask = adjacency_prep(adj)
+    F = ((adj > 0) & (adj < DEPREL_FORWARD_BOUND)).astype(np.float32)                        # gcn.py:276-279
+    R = ((adj > DEPREL_FORWARD_BOUND) & (adj < DEPREL_REVERSE_BOUND)).astype(np.float32)     # gcn.py:281-285
+    E = np.asarray(E, dtype=np.float32)
+    fe, re, se = E[deprel], E[deprel + DEPREL_FORWARD_BOUND], E[SELF_LOOP_INDEX]             # gcn.py:274, 287, 289-292
+    h = (np.matmul(np.asarray(x, np.float32), np.asarray(Wp, np.float32).T) + np.asarray(bp, np.float32)).astype(np.float32)   # gcn.py:257
+    saved = []
+    for l in range(layers):
+        z = np.matmul(F, fe * h) + np.matmul(R, re * h) + h * se                              # gcn.py:280, 288, 293-294
+        g = np.maximum(z / denom, 0.0).astype(np.float32)                                     # gcn.py:390-392
+        if l < layers - 1 and drop_masks is not None and drop_p > 0.0:
+            g = g * drop_masks[l].astype(np.float32) * np.float32(1.0 / (1.0 - drop_p))
+        saved.append((h, g))
+        h = g
+    if return_saved:
+        return h, mask, (F, R, fe, re, se, denom, saved)
+    return h, mask
+
+
+def diag_backward(adj, x, deprel, Wp, bp, E, layers, gy, drop_masks=None, drop_p=0.0, acts=None):
+    """returns (dx, dWp, dbp, dE); dE[0] = 0 as nn.Embedding(padding_idx=0) does (gcn.py:56)."""
+    _, _, (F, R, fe, re, se, denom, saved) = diag_forward(adj, x, deprel, Wp, bp, E, layers, drop_masks, drop_p, True)
+    if acts is not None:
+        ins = [saved[0][0]] + [np.asarray(a, np.float32) for a in acts[:-1]]
+        saved = [(ins[l], np.asarray(acts[l], np.float32)) for l in range(layers)]
+    E = np.asarray(E, dtype=np.float32)
+    dE = np.zeros_like(E, dtype=np.float64)
+    g = np.asarray(gy, dtype=np.float32)
+    Ft, Rt = np.transpose(F, (0, 2, 1)), np.transpose(R, (0, 2, 1))
+    for l in reversed(range(layers)):
+        h_in, out = saved[l]
+        scale = np.float32(1.0 / (1.0 - drop_p)) if (l < layers - 1 and drop_masks is not None and drop_p > 0.0) else np.float32(1.0)
+        dZ = g * (out > 0) * scale / denom
+        uf, ur = np.matmul(Ft, dZ), np.matmul(Rt, dZ)                  # gradient wrt (fe*h) and (re*h)
+        np.add.at(dE, deprel, (uf * h_in).astype(np.float64))
+        np.add.at(dE, deprel + DEPREL_FORWARD_BOUND, (ur * h_in).astype(np.float64))
+        dE[SELF_LOOP_INDEX] += (dZ * h_in).reshape(-1, E.shape[1]).sum(0)
+        g = (uf * fe + ur * re + dZ * se).astype(np.float32)
+    dE[0] = 0.0
+    Wp = np.asarray(Wp, np.float32)
+    din = Wp.shape[1]
+    dWp = np.matmul(g.reshape(-1, Wp.shape[0]).T, np.asarray(x, np.float32).reshape(-1, din)).astype(np.float32)
+    dbp = g.reshape(-1, Wp.shape[0]).sum(0).astype(np.float32)
+    dx = np.matmul(g, Wp).astype(np.float32)
+    return dx, dWp, dbp, dE.astype(np.float32)

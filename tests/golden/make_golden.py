@@ -205,6 +205,38 @@ def gen_layers():
 
 
 # ------------------------------------------------------------------------------------------------
+def gen_diag():
+    """adj_type='diagonal_deprel' layer stack (gcn.py:272-294) isolated behind the reference's GCN.forward."""
+    seed, B, T, din, hidden, layers, K = 150, 4, 40, 56, 48, 2, 1
+    batch = synthetic.random_tree_batch(seed, B, T, "tacred")
+    adj, _, status = ref_adj(batch["head"], batch["subj_pos"], batch["obj_pos"], batch["deprel"], batch["lens"], T, K)
+    assert (status == 0).all()
+    rng = np.random.RandomState(seed + 1)
+    E = rng.uniform(-1, 1, size=(85, hidden)).astype(np.float32)
+    E[0] = 0.0
+    (Wp,), (bp,) = synthetic.layer_params(seed + 2, [din, hidden])
+    x = synthetic.normal(seed + 3, (B, T, din))
+    gy = synthetic.normal(seed + 4, (B, T, hidden))
+    opt = dict(ref_opt(din, hidden, layers, K), adj_type="diagonal_deprel", deprel_emb_dim=hidden)
+    demb = torch.nn.Embedding(85, hidden, padding_idx=0)
+    gcn = GCN(opt, (None, None, None, demb), hidden, layers)
+    with torch.no_grad():
+        demb.weight.copy_(torch.from_numpy(E))
+        gcn.preprocessor.weight.copy_(torch.from_numpy(Wp))
+        gcn.preprocessor.bias.copy_(torch.from_numpy(bp))
+    gcn.eval()
+    xt = torch.from_numpy(x).requires_grad_()
+    t = lambda a: torch.from_numpy(a)  # noqa: E731
+    inputs = (xt, t(batch["masks"]), None, None, t(batch["deprel"]), t(batch["head"]), t(batch["subj_pos"]), t(batch["obj_pos"]))
+    h, mask = gcn(torch.from_numpy(adj), inputs)
+    h.backward(torch.from_numpy(gy))
+    save("layers_diag_deprel.npz", B=np.int64(B), T=np.int64(T), din=np.int64(din), hidden=np.int64(hidden), layers=np.int64(layers),
+         prune_k=np.int64(K), lens=batch["lens"], head=batch["head"], deprel=batch["deprel"], subj_pos=batch["subj_pos"],
+         obj_pos=batch["obj_pos"], coo=coo(adj), x=x, gy=gy, E=E, Wp=Wp, bp=bp, h=h.detach().numpy(), mask=mask.numpy(),
+         dx=xt.grad.numpy(), dWp=gcn.preprocessor.weight.grad.numpy(), dbp=gcn.preprocessor.bias.grad.numpy(), dE=demb.weight.grad.numpy())
+
+
+# ------------------------------------------------------------------------------------------------
 def gen_end_to_end():
     """GCNClassifier logits for 10 sample sentences, eval mode, seeded weights (GCN and C-GCN)."""
     arr, sents = tacred_sample_arrays()
@@ -226,12 +258,14 @@ def gen_end_to_end():
         ner[r, :n] = [ref_constant.NER_TO_ID.get(p, 1) for p in s["stanford_ner"]]
     fields = {k: arr[k][sel][:, :T] for k in ("head", "deprel", "subj_pos", "obj_pos")}
     masks = words == 0
-    for tag, rnn in (("gcn", False), ("cgcn", True)):
+    for tag, rnn in (("gcn", False), ("cgcn", True), ("diag", False)):
         opt = dict(vocab_size=len(vocab) + 2, emb_dim=24, pos_dim=6, ner_dim=6, hidden_dim=32, num_layers=2,
                    input_dropout=0.5, gcn_dropout=0.5, emb_dropout=0.0, word_dropout=0.04, topn=10 ** 10,
                    deprel_emb_dim=32, adj_type="regular", prune_k=1, pooling="max", mlp_layers=2,
                    pooling_l2=0.003, conv_l2=0.0, rnn=rnn, rnn_hidden=16, rnn_layers=1, rnn_dropout=0.5,
                    cuda=False, dataset="tacred", num_class=42, no_adj=False)
+        if tag == "diag":
+            opt["adj_type"] = "diagonal_deprel"
         torch.manual_seed(4321)
         model = GCNClassifier(opt)
         model.eval()
@@ -249,6 +283,12 @@ def gen_end_to_end():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    gen_trees()
-    gen_layers()
-    gen_end_to_end()
+    which = sys.argv[1:] or ["trees", "layers", "diag", "e2e"]
+    if "trees" in which:
+        gen_trees()
+    if "layers" in which:
+        gen_layers()
+    if "diag" in which:
+        gen_diag()
+    if "e2e" in which:
+        gen_end_to_end()

@@ -470,6 +470,130 @@ def test_fused_stack_dropout_no_adj_and_dense_adjacency(api, dev):
 
 
 # ---------------------------------------------------------------------------------------------------
+# N2: adj_type == 'diagonal_deprel' (gcnpt_diag_layer_fwd / bwd)
+# ---------------------------------------------------------------------------------------------------
+def _run_diag(api, dev, g, L, dtype=torch.float32, trees=None, drop=None):
+    """preprocessor Linear (torch) + L diag layers through the C-ABI; returns outputs and all gradients as numpy."""
+    gcn, tree = api
+    B, T = g["x"].shape[:2]
+    if trees is None:
+        masks = np.arange(T)[None, :] >= g["lens"][:, None]
+        trees = tree.prune_to_csr(_t(g["head"], dev), _t(g["subj_pos"], dev), _t(g["obj_pos"], dev), _t(g["deprel"], dev),
+                                  int(g["prune_k"]), masks=_t(masks, dev), want_label=True).check()
+    x = _t(g["x"], dev).requires_grad_()
+    Wp, bp, E = (_t(g[k], dev).requires_grad_() for k in ("Wp", "bp", "E"))
+    deprel = _t(g["deprel"], dev)
+    h = torch.nn.functional.linear(x, Wp, bp).to(dtype)
+    acts = []
+    for l in range(L):
+        p, seed = drop if (drop and l < L - 1) else (0.0, 0)
+        h = gcn.diag_layer(h, E, deprel, trees, p, seed)
+        acts.append(h)
+    h.backward(_t(g["gy"], dev).to(dtype))
+    f = lambda t: t.detach().float().cpu().numpy()  # noqa: E731
+    return dict(h=f(h), acts=[f(a) for a in acts], dx=f(x.grad), dWp=f(Wp.grad), dbp=f(bp.grad), dE=f(E.grad),
+                mask=trees.pool_mask.cpu().numpy(), trees=trees)
+
+
+def test_diag_deprel_golden(api, dev):
+    """fp32 against outputs and gradients recorded from the reference's GCN(adj_type='diagonal_deprel')."""
+    gcn, tree = api
+    g = load_golden("layers_diag_deprel.npz")
+    B, T, L = int(g["B"]), int(g["T"]), int(g["layers"])
+    r = _run_diag(api, dev, g, L)
+    np.testing.assert_array_equal(r["mask"], g["mask"])
+    assert max_rel(r["h"], g["h"]) <= FWD_RTOL
+    dE = r["dE"].copy()
+    dE[0] = 0                                   # nn.Embedding(padding_idx=0): the module's hook does this (checked end to end below)
+    for got, key in ((r["dx"], "dx"), (r["dWp"], "dWp"), (r["dbp"], "dbp"), (dE, "dE")):
+        assert max_rel(got, g[key]) <= GRAD_RTOL, key
+    # the same through an explicit dense adjacency with the reference's labels (gcnpt_adj_to_csr, want_label)
+    adj = dense_from_coo(g["coo"], B, T)
+    r2 = _run_diag(api, dev, g, L, trees=tree.adj_to_csr(_t(adj, dev), want_label=True))
+    np.testing.assert_array_equal(r2["h"], r["h"])
+    np.testing.assert_array_equal(r2["dx"], r["dx"])
+    assert max_rel(r2["dE"], r["dE"]) <= 1e-5    # atomics: summation order differs run to run
+
+
+@pytest.mark.parametrize("cfg", [dict(B=50, T=100, din=360, hid=200, K=1, L=2), dict(B=7, T=61, din=33, hid=50, K=2, L=3),
+                                 dict(B=4, T=40, din=64, hid=328, K=0, L=2)])
+def test_diag_deprel_vs_oracle(api, dev, cfg):
+    """BASELINE config-2 shape and odd widths (H % 4 != 0: scalar path; H > 256: two column chunks), fp32 and bf16,
+    with dropout between the layers, against the numpy oracle."""
+    from gcn_over_pruned_trees_amd.utils import synthetic
+    from oracle import gcn_ref, prune_ref
+    B, T, din, hid, K, L = (cfg[k] for k in ("B", "T", "din", "hid", "K", "L"))
+    tb = synthetic.random_tree_batch(77, B, T, "tacred")
+    adj = prune_ref.batch_adj(tb["head"], tb["subj_pos"], tb["obj_pos"], tb["deprel"], tb["lens"], K)["adj"]
+    rng = np.random.RandomState(5)
+    E = rng.uniform(-1, 1, size=(85, hid)).astype(np.float32)
+    (Wp,), (bp,) = synthetic.layer_params(6, [din, hid])
+    g = dict(tb, x=synthetic.normal(7, (B, T, din)), gy=synthetic.normal(8, (B, T, hid)), Wp=Wp, bp=bp, E=E, prune_k=K)
+    p = 0.25
+    for dtype, ftol, gtol in ((torch.float32, FWD_RTOL, GRAD_RTOL), (torch.bfloat16, 3e-2, None)):
+        r = _run_diag(api, dev, g, L, dtype, drop=(p, 4242))
+        # dropout masks as the device drew them: a layer's pre-dropout values come from the oracle run through that
+        # layer with the masks found so far; where the oracle's value is <= 0 the mask does not matter
+        masks = []
+        for l in range(L - 1):
+            _, _, (_, _, _, _, _, _, saved) = gcn_ref.diag_forward(adj, g["x"], g["deprel"], Wp, bp, E, l + 1, masks, p, True)
+            pre = saved[l][1]
+            kept = (r["acts"][l] != 0) | (pre <= 0)
+            assert abs((r["acts"][l] != 0)[pre > 0].mean() - (1 - p)) < 0.02
+            masks.append(kept.astype(np.float32))
+        h, mask = gcn_ref.diag_forward(adj, g["x"], g["deprel"], Wp, bp, E, L, masks, p)
+        np.testing.assert_array_equal(r["mask"], mask)
+        assert max_rel(r["h"], h) <= ftol
+        # gradients: the oracle differentiated through the device's own activations (ReLU' is a step function: one
+        # pre-activation within rounding of 0 flips a whole gradient path, in fp32 as in bf16)
+        dx, dWp, dbp, dE = gcn_ref.diag_backward(adj, g["x"], g["deprel"], Wp, bp, E, L, g["gy"], masks, p, acts=r["acts"])
+        dEg = r["dE"].copy()
+        dEg[0] = 0
+        for got, want, key in ((r["dx"], dx, "dx"), (r["dWp"], dWp, "dWp"), (r["dbp"], dbp, "dbp"), (dEg, dE, "dE")):
+            if gtol is not None:
+                assert max_rel(got, want) <= gtol, key
+            else:
+                assert fro_rel(got, want) <= 3e-2, key
+        if gtol is not None:        # fp32: the activation pattern itself differs from the oracle's in at most a handful of ~0 entries
+            _, _, (_, _, _, _, _, _, saved) = gcn_ref.diag_forward(adj, g["x"], g["deprel"], Wp, bp, E, L, masks, p, True)
+            for l in range(L):
+                flips = (saved[l][1] > 0) != (r["acts"][l] > 0)
+                assert flips.mean() <= 1e-4 and (not flips.any() or np.abs(saved[l][1][flips]).max() <= 1e-5 * np.abs(saved[l][1]).max())
+
+
+def test_diag_deprel_classifier_end_to_end_golden(api, dev):
+    """GCNClassifier(adj_type='diagonal_deprel') loads the reference's state_dict and reproduces its logits."""
+    import json
+    gcn, _ = api
+    g = load_golden("e2e_diag.npz")
+    opt = json.loads(str(g["opt"]))
+    opt["cuda"] = True
+    model = gcn.GCNClassifier(opt)
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd:")}
+    model.load_state_dict(sd, strict=True)
+    model.to(dev).eval()
+    inputs = tuple(_t(g[k], dev) for k in ("words", "masks", "pos", "ner", "deprel", "head", "subj_pos", "obj_pos"))
+    with torch.no_grad():
+        logits, pooled = model(inputs)
+    assert max_rel(logits.cpu().numpy(), g["logits"]) <= 1e-4
+    assert max_rel(pooled.cpu().numpy(), g["pooling_output"]) <= 1e-4
+    m16 = gcn.GCNClassifier(dict(opt, gcn_dtype="bf16"))
+    m16.load_state_dict(sd, strict=True)
+    m16.to(dev).eval()
+    with torch.no_grad():
+        l16, _ = m16(inputs)
+    assert max_rel(l16.cpu().numpy(), g["logits"]) <= 3e-2
+    model.train()
+    logits, pooled = model(inputs)
+    (logits.logsumexp(1).mean() + 0.003 * (pooled ** 2).sum(1).mean()).backward()
+    table = model.get_deprel_emb()
+    assert torch.isfinite(table.grad).all() and table.grad.abs().sum() > 0 and (table.grad[0] == 0).all()
+    assert model.gcn_model.gcn.preprocessor.weight.grad.abs().sum() > 0
+    with pytest.raises(AttributeError):          # as in the reference: this variant has no W list (gcn.py:207-215)
+        model.conv_l2()
+
+
+# ---------------------------------------------------------------------------------------------------
 # drop-in boundary: the reference's module surface
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("tag", ["gcn", "cgcn"])

@@ -126,3 +126,17 @@ def test_dropout_mask_semantics():
     for l in range(2):
         assert max_rel(dWs[l], Ws[l].grad.numpy()) <= GRAD_RTOL
         assert max_rel(dbs[l], bs[l].grad.numpy()) <= GRAD_RTOL
+
+
+def test_diag_deprel_oracle_matches_reference_golden():
+    """N2: numpy restatement of the diagonal_deprel layers vs outputs/gradients recorded from the reference."""
+    g = load_golden("layers_diag_deprel.npz")
+    B, T, L = int(g["B"]), int(g["T"]), int(g["layers"])
+    adj = dense_from_coo(g["coo"], B, T)
+    h, mask = gcn_ref.diag_forward(adj, g["x"], g["deprel"], g["Wp"], g["bp"], g["E"], L)
+    np.testing.assert_allclose(h, g["h"], rtol=1e-5, atol=1e-6)
+    assert (mask == g["mask"]).all()
+    dx, dWp, dbp, dE = gcn_ref.diag_backward(adj, g["x"], g["deprel"], g["Wp"], g["bp"], g["E"], L, g["gy"])
+    for got, key in ((dx, "dx"), (dWp, "dWp"), (dbp, "dbp"), (dE, "dE")):
+        np.testing.assert_allclose(got, g[key], rtol=2e-4, atol=2e-5, err_msg=key)
+    assert (g["dE"][0] == 0).all() and np.abs(g["dE"]).max() > 0

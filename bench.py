@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--fused", action="store_true",
                     help="sentence-resident stack kernels (all layers in one launch per direction) instead of one launch per layer; "
                          "measured slower on MI355X at this size (109 vs 76 us/step): 50 workgroups carry every elementwise phase")
+    ap.add_argument("--split-weight-grad", action="store_true",
+                    help="one weight-gradient launch per layer (right after that layer's backward-data) instead of one launch "
+                         "for all layers at the end of the backward sweep")
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="2 = run layer-1 bwd-weight beside layer-0 bwd-data (and the tree build beside the pack) on a side stream; "
                          "measured slower than 1 on MI355X: the cross-stream graph edges cost more than the overlap gains")
@@ -169,6 +172,15 @@ class Stack(object):
         self._lib.check(self.L.gcnpt_layer_bwd_weight(self._lib.stream(), P(self.zf[l]), P(self.sf[l]), self.B, self.T, Din, H,
                                                       P(dW), P(db), self.compute))
 
+    def bwd_weight_all(self, k=0):
+        """Both layers' weight gradients in ONE launch (they only need the fragment images the sweep has left behind)."""
+        A, n = self._lib.ptr_array, len(self.W)
+        g = self.grads(k)
+        ints = lambda vals: (ctypes.c_int * n)(*vals)  # noqa: E731
+        self._lib.check(self.L.gcnpt_layer_bwd_weight_multi(
+            self._lib.stream(), n, A(self.zf), A(self.sf), self.B, self.T, ints([w.shape[1] for w in self.W]),
+            ints([w.shape[0] for w in self.W]), A([g[0], g[2]]), A([g[1], g[3]]), self.compute))
+
     # ---- sentence-resident stack: every layer in one launch per direction ----
     def stack_fwd(self, k=0):
         P, A, tr, L = self._lib.ptr, self._lib.ptr_array, self.trees, 2
@@ -197,9 +209,13 @@ class Stack(object):
         if self.fused:
             return [("pack", self.pack_all), ("stack_fwd", lambda: self.stack_fwd(k)), ("stack_bwd", lambda: self.stack_bwd(k)),
                     ("stack_bwd_weight", lambda: self.stack_bwd_weight(k))]
+        if self.args.split_weight_grad:
+            return [("pack", self.pack_all), ("fwd0", lambda: self.fwd(0)), ("fwd1", lambda: self.fwd(1)),
+                    ("bwd_data1", lambda: self.bwd_data(1, k)), ("bwd_weight1", lambda: self.bwd_weight(1, k)),
+                    ("bwd_data0", lambda: self.bwd_data(0, k)), ("bwd_weight0", lambda: self.bwd_weight(0, k))]
         return [("pack", self.pack_all), ("fwd0", lambda: self.fwd(0)), ("fwd1", lambda: self.fwd(1)),
-                ("bwd_data1", lambda: self.bwd_data(1, k)), ("bwd_weight1", lambda: self.bwd_weight(1, k)),
-                ("bwd_data0", lambda: self.bwd_data(0, k)), ("bwd_weight0", lambda: self.bwd_weight(0, k))]
+                ("bwd_data1", lambda: self.bwd_data(1, k)), ("bwd_data0", lambda: self.bwd_data(0, k)),
+                ("bwd_weight", lambda: self.bwd_weight_all(k))]
 
     def step(self, k=0, with_prune=False):
         """
@@ -241,6 +257,7 @@ class Stack(object):
             out["fwd%d" % l] = e * N * (Din + H) + wp + 4 * H + csr + self.sf[l].numel()
             out["bwd_data%d" % l] = e * N * (2 * H + Din) + self.wb[l].numel() + 2 * csr + self.zf[l].numel() + 4 * (H * Din + H)
             out["bwd_weight%d" % l] = self.zf[l].numel() + self.sf[l].numel() + 4 * (H * Din + H)
+            out["bwd_weight"] = out.get("bwd_weight", 0) + out["bwd_weight%d" % l]
             out["pack"] = out.get("pack", 0) + 4 * H * Din + self.wf[l].numel() + self.wb[l].numel()
         out["prune"] = 4 * 8 * N + N + 2 * (csr + 4 * B * (T + 1) + 4 * self.nnz) + N + 4 * (B + 1)
         if self.fused:
@@ -433,7 +450,8 @@ def main():
             kt = kernel_breakdown(stack, use_graph)
             step_keys = [k for k in kt if k != "prune"]
             result["config"]["kernels_per_step"] = "sentence-resident stack: pack, stack_fwd, stack_bwd, stack_bwd_weight" if stack.fused \
-                else "per layer: pack, fwd0, fwd1, bwd_data1, bwd_weight1, bwd_data0, bwd_weight0"
+                else ("pack, fwd0, fwd1, bwd_data1, bwd_weight1, bwd_data0, bwd_weight0" if args.split_weight_grad
+                      else "pack, fwd0, fwd1, bwd_data1, bwd_data0, bwd_weight (both layers, one launch)")
             dom = max(step_keys, key=lambda k: kt[k])
             traffic = None
             tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # per-launch HBM bytes from rocprofv3 --pmc passes, if recorded

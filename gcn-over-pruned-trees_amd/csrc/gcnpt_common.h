@@ -53,6 +53,15 @@ constexpr int WAVE = 64;
 constexpr int FWD_BOUND = 42;      // utils/constant.py:14  DEPREL_FORWARD_BOUND
 constexpr int SELF_LOOP_ID = 84;   // utils/constant.py:12,29  DEPREL_TO_ID['self_loop']
 
+// LDS operations of ONE wave complete in issue order, so data handed from lane to lane of the same wave through LDS only
+// needs the compiler kept from moving LDS accesses across the hand-over and the wave's own outstanding LDS operations
+// waited for: no workgroup barrier
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 __host__ __device__ inline int ceil_div(int x, int m) { return (x + m - 1) / m; }
 

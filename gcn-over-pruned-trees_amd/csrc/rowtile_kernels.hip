@@ -23,6 +23,9 @@ constexpr int ROWS = 32;             // token rows per workgroup (two 16-row MFM
 constexpr int RT_THREADS = 512;      // 8 waves; wave w owns output tiles w, w+8, ...
 constexpr int RT_WAVES = RT_THREADS / WAVE;
 constexpr int NB_INLINE = 7;         // neighbours per row that the ELL head carries (include/gcnpt.h)
+#ifndef GCNPT_W_EARLY_NUM
+#define GCNPT_W_EARLY_NUM 2          // quarters of a wave's weight fragments requested before the adjacency is known
+#endif
 
 struct RowTileParams {
     const void* src;        // fwd: h [N,K]      bwd: dY [N,K]
@@ -66,6 +69,8 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
     int* rell = meta;                         // [ROWS][8] ELL heads of the tile's rows (count, 7 sentence-local columns)
     float* rinv = reinterpret_cast<float*>(meta + 8 * ROWS);   // [ROWS] fwd: 1/(deg+1)   bwd: scale/(deg+1)
     float* rden = reinterpret_cast<float*>(meta + 9 * ROWS);   // [ROWS] deg+1
+    int* glist = meta + 10 * ROWS;            // [ROWS] tile rows that aggregate at least one entry, compacted
+    int* gcount = meta + 11 * ROWS;           // [1] their number
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = blockIdx.x * ROWS;
@@ -77,23 +82,15 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
     GCNPT_STAMP_REAL(p.stamps);
     GCNPT_STAMP(p.stamps, 0);
 
-    // (1) the tile's adjacency: ONE coalesced 1-KiB load of the 32 ELL heads (lanes 0..63 of wave 0, 16 bytes each)
-    //     plus the degrees for the denominators.  No dependent load: a pruned-tree row has <= 3-4 entries.
-    if (tid < 2 * ROWS) {
-        const int row = tid >> 1, half = tid & 1;
-        const size_t r = (size_t)min(r0 + row, p.N - 1);
-        const int4 e = reinterpret_cast<const int4*>(p.g_ell)[r * 2 + half];
-        const float dn = (float)(p.d_ell[r * 8] + 1);                                // gcn.py:261
-        const bool first = half == 0;
-        const int e0 = (first && r0 + row >= p.N) ? 0 : e.x;                         // rows past the end aggregate nothing
-        reinterpret_cast<int4*>(rell)[row * 2 + half] = make_int4(e0, e.y, e.z, e.w);
-        if (first) {
-            rinv[row] = (BWD ? p.scale : 1.0f) / dn;
-            rden[row] = dn;
-        }
-    }
+    // (1) the tile's adjacency: the 32 ELL heads (1 KiB) and the degrees for the denominators.  EVERY wave loads all of
+    //     them (64 lanes x 16 bytes; waves 1..7 hit wave 0's lines) and keeps its own copy of the derived tables: the load
+    //     is unconditional and first in the queue, and no wave waits for another one before it can start gathering.
+    const int erow = lane >> 1, ehalf = lane & 1;
+    const size_t er = (size_t)min(r0 + erow, p.N - 1);
+    const int4 ell_v = reinterpret_cast<const int4*>(p.g_ell)[er * 2 + ehalf];
+    const int deg_v = p.d_ell[er * 8];                                                   // gcn.py:261
 
-    // own rows of the first batch (everyone), then (0): this wave's weight fragments, all of them
+    // own rows of the first batch (everyone)
     const int nchunk = p.Kpad / 8;
     const int n_items = ROWS * nchunk;
     const int kmax8 = VEC ? p.K - 8 : p.K - 1;
@@ -110,12 +107,17 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
     };
     issue_self(0);
 
+    // (0) this wave's weight fragments.  The vector-memory counter retires IN ORDER: whatever is issued before the
+    //     neighbour loads of step (2) has to land before they can be consumed.  So only the first KS_EARLY k-steps go
+    //     out now (they drain while the ELL heads are on their way); the rest follows the neighbour loads.
+    constexpr int KS_EARLY = KSMAX * GCNPT_W_EARLY_NUM / 4;
     uint4 wreg[KSMAX][NTW];
-    auto load_w = [&](int pass, int kc0) {
+    auto load_w = [&](int pass, int kc0, int ks_lo, int ks_hi) {
 #pragma unroll
         for (int ks = 0; ks < KSMAX; ++ks)
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
+                if (ks < ks_lo || ks >= ks_hi) continue;                    // compile-time after unrolling
                 const int tl = min(pass * RT_WAVES * NTW + j * RT_WAVES + wave, n_tiles - 1);
                 const int kk = min(kc0 + ks, ksteps - 1);
 #ifdef GCNPT_STAMPS
@@ -126,42 +128,169 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
     };
     // fwd epilogue operand, fetched now, used last.  The MFMAs run with swapped operands (weights as A), so a lane
     // ends up with 4 CONSECUTIVE output columns of one row: columns 16 tile + 4 (lane>>4) + g.
-    float bias2[NTW][4];
+    // (only loaded here: any arithmetic on it now would be a wait for everything issued before it)
+    float braw[NTW][4];
     auto load_bias = [&](int pass) {
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
             const int col0 = (pass * RT_WAVES * NTW + j * RT_WAVES + wave) * 16 + (lane >> 4) * 4;
             if ((p.NOUT & 3) == 0) {                                  // kernel-uniform: one 16-byte load per tile
                 const float4 bv = *reinterpret_cast<const float4*>(p.bias + min(col0, p.NOUT - 4));
-                const bool in = col0 < p.NOUT;
-                bias2[j][0] = in ? 2.0f * bv.x : 0.0f; bias2[j][1] = in ? 2.0f * bv.y : 0.0f;     // enters twice, gcn.py:270-271
-                bias2[j][2] = in ? 2.0f * bv.z : 0.0f; bias2[j][3] = in ? 2.0f * bv.w : 0.0f;
+                braw[j][0] = bv.x; braw[j][1] = bv.y; braw[j][2] = bv.z; braw[j][3] = bv.w;
             } else {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) bias2[j][g] = 2.0f * p.bias[min(col0 + g, p.NOUT - 1)];
+                for (int g = 0; g < 4; ++g) braw[j][g] = p.bias[min(col0 + g, p.NOUT - 1)];
             }
         }
     };
-    if (p.out) {
-        load_w(0, 0);                                          // 156 KB per workgroup at Din=360, H=200
-        if constexpr (!BWD) load_bias(0);
+    load_w(0, 0, 0, KS_EARLY);              // unconditional even when only the side outputs are wanted: a branch here would
+                                            // make every later wait assume the shorter queue
+
+    // park the heads in LDS and compact the rows that aggregate anything (a pruned tree keeps ~1 token in 8).  All
+    // waves write the same values to the same places; each reads back only after its own writes (wave_lds_fence).
+    {
+        const bool first = ehalf == 0;
+        const int e0 = (first && r0 + erow >= p.N) ? 0 : ell_v.x;                    // rows past the end aggregate nothing
+        reinterpret_cast<int4*>(rell)[erow * 2 + ehalf] = make_int4(e0, ell_v.y, ell_v.z, ell_v.w);
+        const float dn = (float)(deg_v + 1);
+        rinv[erow] = (BWD ? p.scale : 1.0f) / dn;       // both lanes of a row write it: a use under `first` only would let
+        rden[erow] = dn;                                // hipcc sink the degree load into that branch, behind a full wait
+        const bool agg = first && e0 > 0 && p.out != nullptr;
+        const unsigned long long m = __ballot(agg);
+        if (agg) glist[__popcll(m & ((1ull << lane) - 1ull))] = erow;
+        if (lane == 0) *gcount = __popcll(m);
     }
     GCNPT_STAMP(p.stamps, 1);
-    __syncthreads();
+    wave_lds_fence();
     GCNPT_STAMP(p.stamps, 2);
 
-    // (2) finish the gather batch by batch: S[row,:] = x[row,:] + sum_{c in pattern row} x[c,:]
+    // (2) gcn.py:269 as a gather, S[row,:] = x[row,:] + sum_{c in pattern row} x[c,:], in two maps that share one barrier:
+    //   (2a) rows that aggregate something, compacted: item gi = (list slot, 8-column chunk), so the ~4 such rows of a
+    //        tile spread over ALL waves and their neighbour loads (<= NBU per round; a pruned-tree row has 3-4 entries)
+    //        leave in ONE round trip per item.  The first 7 neighbours come from the ELL head in LDS, the (rare) rest
+    //        from col_idx; lanes without an e-th neighbour load their own row and drop it.
+    //   (2b) every other row is a plain copy of the loads issued at the top.
+    struct GItem { raw8<IT> s, sy, nb[NBU], nby[NBU]; int dcnt[NBU]; };
+    const int n_g = *gcount * nchunk;
+    auto g_decode = [&](int gi, int& row, int& k0, int& n) {
+        const bool has = gi < n_g;
+        const int li = has ? gi / nchunk : 0;
+        row = has ? glist[li] : 0;
+        k0 = has ? (gi - li * nchunk) * 8 : 0;
+        n = (has && k0 < p.K) ? rell[row * 8] : 0;
+        return has;
+    };
+    auto g_issue = [&](int gi, GItem& g) {
+        int row, k0, n;
+        g_decode(gi, row, k0, n);
+        const size_t r = (size_t)min(r0 + row, p.N - 1);
+        const int sbase = (int)(r / p.T) * p.T;                        // first row of this row's sentence
+        const int k0c = min(k0, kmax8);
+        issue8<IT, VEC>(src, r, p.K, k0c, g.s);
+        if (BWD) issue8<IT, VEC>(yref, r, p.K, k0c, g.sy);
+#pragma unroll
+        for (int e = 0; e < NBU; ++e) {
+            // no e-th neighbour: the first 16 bytes of the tile's first row, one cache line for all such lanes.  (NOT the
+            // item's own row: hipcc would then reuse the load above, wait for it, and branch around the others.)
+            const bool on = e < min(n, NB_INLINE);
+            const size_t c = on ? (size_t)(sbase + rell[row * 8 + 1 + e]) : (size_t)r0;
+            const int kc = on ? k0c : 0;
+            issue8<IT, VEC>(src, c, p.K, kc, g.nb[e]);
+            if (BWD) {
+                issue8<IT, VEC>(yref, c, p.K, kc, g.nby[e]);
+                g.dcnt[e] = p.d_ell[c * 8];
+            }
+        }
+    };
+    auto g_finish = [&](int gi, const GItem& g) {
+        int row, k0, n;
+        const bool has = g_decode(gi, row, k0, n);
+        const bool live = has && k0 < p.K;
+        const size_t rc = (size_t)min(r0 + row, p.N - 1);
+        const int sbase = (int)(rc / p.T) * p.T;
+        const int k0c = min(k0, kmax8);
+        float acc[8];
+        unpack8<IT>(g.s, live, acc);                                    // the explicit W(h) term, gcn.py:271
+        if (BWD) {
+            float y[8];
+            unpack8<IT>(g.sy, live, y);
+            const float inv = rinv[row];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = (y[j] > 0.0f) ? acc[j] * inv : 0.0f;
+        }
+        const int n_ell = min(n, NB_INLINE);
+#pragma unroll
+        for (int e = 0; e < NBU; ++e) {
+            const bool on = e < n_ell;
+            float v[8];
+            unpack8<IT>(g.nb[e], on, v);
+            if (BWD) {
+                float y[8];
+                unpack8<IT>(g.nby[e], on, y);
+                const float ninv = p.scale / (float)(g.dcnt[e] + 1);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += (y[j] > 0.0f) ? v[j] * ninv : 0.0f;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += v[j];
+            }
+        }
+        // rows with more than NBU entries (branching tree nodes, dense adjacency input): further round trips
+        auto round = [&](int e0, int lim, auto from_lds) {
+            raw8<IT> nb[NBU], nby[NBU];
+            float ninv[NBU];
+#pragma unroll
+            for (int e = 0; e < NBU; ++e) {
+                const bool on = e0 + e < lim;
+                size_t c;
+                if constexpr (decltype(from_lds)::value) {
+                    c = (size_t)(sbase + rell[row * 8 + 1 + min(e0 + e, NB_INLINE - 1)]);
+                } else {                                            // > 7 entries: continue in the CSR
+                    const int beg = p.g_row_ptr[(size_t)(sbase / p.T) * (p.T + 1) + (rc - sbase)];
+                    c = (size_t)(sbase + p.g_col_idx[on ? beg + e0 + e : beg]);
+                }
+                c = on ? c : rc;
+                issue8<IT, VEC>(src, c, p.K, k0c, nb[e]);
+                if (BWD) {
+                    issue8<IT, VEC>(yref, c, p.K, k0c, nby[e]);
+                    ninv[e] = p.scale / (float)(p.d_ell[c * 8] + 1);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < NBU; ++e) {
+                const bool on = e0 + e < lim;
+                float v[8];
+                unpack8<IT>(nb[e], on, v);
+                if (BWD) {
+                    float y[8];
+                    unpack8<IT>(nby[e], on, y);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += (y[j] > 0.0f) ? v[j] * ninv[e] : 0.0f;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += v[j];
+                }
+            }
+        };
+        for (int e0 = NBU; e0 < n_ell; e0 += NBU) round(e0, n_ell, std::true_type{});
+        for (int e0 = NB_INLINE; e0 < n; e0 += NBU) round(e0, n, std::false_type{});
+        if (has) tile<CT>::put8(S + (size_t)row * stride + k0, acc);
+    };
+
+    GItem g0;
+    g_issue(tid, g0);
+    load_w(0, 0, KS_EARLY, KSMAX);                              // 156 KB per workgroup at Din=360, H=200
+    if constexpr (!BWD) load_bias(0);
+
+    // (2b)
     const int n_batches = ceil_div(n_items, ITEMS * RT_THREADS);
-    for (int batch = 0; batch < n_batches; ++batch) {
-        if (batch > 0) issue_self(batch);
+    auto copy_batch = [&](int batch) {
 #pragma unroll
         for (int u = 0; u < ITEMS; ++u) {
             const int it = (batch * ITEMS + u) * RT_THREADS + tid;
             if (it >= n_items) continue;
             const int row = it / nchunk, k0 = (it - row * nchunk) * 8;
-            const int r = r0 + row;
-            const bool live = r < p.N && k0 < p.K;
-            const int k0c = min(k0, kmax8);
+            const bool live = r0 + row < p.N && k0 < p.K;
             float acc[8];
             unpack8<IT>(self[u], live, acc);                            // the explicit W(h) term, gcn.py:271
             if (BWD) {
@@ -172,52 +301,20 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
                 for (int j = 0; j < 8; ++j) acc[j] = (y[j] > 0.0f) ? acc[j] * inv : 0.0f;
                 if (p.frag_out) tile<CT>::put8(Z + (size_t)row * stride + k0, acc);
             }
-            const int n = (live && p.out) ? rell[row * 8] : 0;
-            const size_t rc = (size_t)min(r, p.N - 1);
-            const int sbase = (int)(rc / p.T) * p.T;                    // first row of this row's sentence
-            // gcn.py:269: <= 3-4 neighbours per kept token of a pruned tree.  The first 7 come from the ELL head in LDS,
-            // the (rare) rest from col_idx; lanes without an e-th neighbour load their own row and drop it.
-            auto round = [&](int e0, int lim, auto from_lds) {
-                raw8<IT> nb[NBU], nby[NBU];
-                float ninv[NBU];
-#pragma unroll
-                for (int e = 0; e < NBU; ++e) {
-                    const bool on = e0 + e < lim;
-                    size_t c;
-                    if constexpr (decltype(from_lds)::value) {
-                        c = (size_t)(sbase + rell[row * 8 + 1 + min(e0 + e, NB_INLINE - 1)]);
-                    } else {                                            // > 7 entries (dense adjacency input): continue in the CSR
-                        const int beg = p.g_row_ptr[(size_t)(sbase / p.T) * (p.T + 1) + (rc - sbase)];
-                        c = (size_t)(sbase + p.g_col_idx[on ? beg + e0 + e : beg]);
-                    }
-                    c = on ? c : rc;
-                    issue8<IT, VEC>(src, c, p.K, k0c, nb[e]);
-                    if (BWD) {
-                        issue8<IT, VEC>(yref, c, p.K, k0c, nby[e]);
-                        ninv[e] = p.scale / (float)(p.d_ell[c * 8] + 1);
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < NBU; ++e) {
-                    const bool on = e0 + e < lim;
-                    float v[8];
-                    unpack8<IT>(nb[e], on, v);
-                    if (BWD) {
-                        float y[8];
-                        unpack8<IT>(nby[e], on, y);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) acc[j] += (y[j] > 0.0f) ? v[j] * ninv[e] : 0.0f;
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) acc[j] += v[j];
-                    }
-                }
-            };
-            const int n_ell = min(n, NB_INLINE);
-            for (int e0 = 0; e0 < n_ell; e0 += NBU) round(e0, n_ell, std::true_type{});
-            for (int e0 = NB_INLINE; e0 < n; e0 += NBU) round(e0, n, std::false_type{});
-            tile<CT>::put8(S + (size_t)row * stride + k0, acc);
+            if (!(p.out && rell[row * 8] > 0)) tile<CT>::put8(S + (size_t)row * stride + k0, acc);   // else: (2a) writes it
         }
+    };
+    copy_batch(0);
+    // (2a)
+    g_finish(tid, g0);
+    for (int base = RT_THREADS; base < n_g; base += RT_THREADS) {      // tiles with more than 512 / (K/8) aggregating rows
+        GItem g;
+        g_issue(base + tid, g);
+        g_finish(base + tid, g);
+    }
+    for (int batch = 1; batch < n_batches; ++batch) {                  // K > 384: the tile's own rows take several batches
+        issue_self(batch);
+        copy_batch(batch);
     }
     GCNPT_STAMP(p.stamps, 3);
     __syncthreads();
@@ -277,7 +374,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
         const int tile0 = pass * RT_WAVES * NTW + wave;
 
         for (int kc0 = 0; kc0 < ksteps; kc0 += KSMAX) {
-            if (pass > 0 || kc0 > 0) load_w(pass, kc0);
+            if (pass > 0 || kc0 > 0) load_w(pass, kc0, 0, KSMAX);
             // A fragments are read one k-step ahead of the MFMAs that use them
             constexpr int AW = sizeof(CT) == 2 ? 8 : 4;                  // CT elements per lane per k-step (16 bytes)
             uint4 a_cur[2], a_nxt[2];
@@ -335,7 +432,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
                 for (int g = 0; g < 4; ++g) {
                     float x = acc[mt][j][g];
                     if (!BWD) {
-                        x = div_by(x + bias2[j][g], den[mt], inv[mt]);   // gcn.py:390
+                        x = div_by(x + 2.0f * braw[j][g], den[mt], inv[mt]);   // gcn.py:270-271 (the bias enters twice), 390
                         x = x > 0.0f ? x : 0.0f;                         // gcn.py:392
                     }
                     v[g] = x;
@@ -399,7 +496,7 @@ static int launch_rowtile_cfg(hipStream_t s, const RowTileParams& p) {
     const int ncols_pass = RT_WAVES * NTW * 16;
     const int ostride = out_stride_dw(std::min(round_up(p.NOUT, 16), ncols_pass) * (int)sizeof(OT) / 4) * 4 / (int)sizeof(OT);
     const size_t lds = (size_t)(BWD ? 2 : 1) * ROWS * stride * sizeof(CT) + (size_t)ROWS * ostride * sizeof(OT) +
-                       (size_t)ROWS * 10 * sizeof(int);
+                       (size_t)ROWS * 12 * sizeof(int);
     if (lds > 160 * 1024) return fail(GCNPT_E_UNSUPPORTED, "layer: K=%d needs %zu B of LDS per workgroup", p.K, lds);
     auto kern = rowtile_kernel<CT, IT, OT, BWD, VEC, NTW, KSMAX>;
     if (lds > 64 * 1024)

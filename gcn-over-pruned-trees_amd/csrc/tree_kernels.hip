@@ -77,13 +77,7 @@ __device__ __forceinline__ int wave_exclusive_scan(int* a, int n, int lane) {
 constexpr int PW_SHIFT = 12, PW_MASK = (1 << PW_SHIFT) - 1, PRUNE_MAX_T = PW_MASK - 3;
 __device__ __forceinline__ int pw_par(int w) { return (w & PW_MASK) - 2; }
 
-// wave 0 runs the pruning phases alone: LDS operations of one wave complete in issue order, so a phase boundary only
-// has to stop the compiler from moving LDS accesses across it and wait for the wave's own outstanding LDS operations
-__device__ __forceinline__ void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
+// wave 0 runs the pruning phases alone, separated by wave_lds_fence() (gcnpt_common.h)
 
 // Phases of wave 0: lengths, LCA, path, distances, kept tokens, degrees, row offsets, compacted edge rows.
 __device__ void prune_sentence(const int64_t* __restrict__ head, const int64_t* __restrict__ subj_pos,

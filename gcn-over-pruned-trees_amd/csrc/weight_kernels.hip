@@ -100,16 +100,29 @@ __device__ __forceinline__ float frag_sum(const uint4& u) {
     }
 }
 
+// One launch serves the weight gradients of several layers (they all become computable at the end of the backward
+// sweep and each alone fills at most one workgroup per CU): layer l owns blocks [first[l], first[l+1]), first[l] % 8 == 0.
+constexpr int WG_MAX_LAYERS = 8;
+struct WeightGradMulti {
+    WeightGradParams l[WG_MAX_LAYERS];
+    int first[WG_MAX_LAYERS + 1];
+    int n;
+};
+
 template <typename CT>
-__global__ __launch_bounds__(LAYER_THREADS) void weight_grad_kernel(const WeightGradParams p) {
+__global__ __launch_bounds__(LAYER_THREADS) void weight_grad_kernel(const WeightGradMulti mp) {
     __shared__ f32x4_t red[4][WG_MT * WG_NT][WAVE];        // 48 KiB: per-wave partial tiles
     __shared__ float dbred[4][WG_MT][16];
 
+    int layer = 0;
+#pragma unroll
+    for (int i = 1; i < WG_MAX_LAYERS; ++i) layer += (i < mp.n && (int)blockIdx.x >= mp.first[i]) ? 1 : 0;
+    const WeightGradParams& p = mp.l[layer];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Workgroups are dealt round-robin over the 8 XCDs (id % 8 labels the XCD group), each with its own L2.
     // All blocks of one contraction slice read the same rows of both images, so a slice is pinned to one
     // XCD group: its rows cross the fabric once and every other read hits that XCD's L2.  (Speed only.)
-    const int id = blockIdx.x, xg = id & 7, rest = id >> 3;
+    const int id = (int)blockIdx.x - mp.first[layer], xg = id & 7, rest = id >> 3;
     int slice, blk;
     if ((p.slices & 7) == 0) { const int sp = p.slices >> 3; slice = xg + 8 * (rest % sp); blk = rest / sp; }
     else                     { const int gp = 8 / p.slices;  slice = xg % p.slices;       blk = rest * gp + xg / p.slices; }
@@ -255,39 +268,59 @@ extern "C" size_t gcnpt_frag_bytes(int rows, int width, int dtype) {
     return (size_t)ceil_div(width, 16) * ksteps * 64 * 16;
 }
 
-static int launch_weight_grad(hipStream_t s, const void* z_frag, const void* s_frag, int nks, int Din, int H, float* dW, float* db,
-                              int compute_dtype) {
-    WeightGradParams p{};
+// fills p for one layer; returns the number of workgroups it takes (a multiple of 8)
+static int plan_weight_grad(WeightGradParams& p, const void* z_frag, const void* s_frag, int nks, int Din, int H, float* dW, float* db,
+                            int layers_in_launch) {
+    p = WeightGradParams{};
     p.stamps = static_cast<unsigned long long*>(g_debug_stamps); p.knob = g_debug_knob;
     p.zf = static_cast<const uint4*>(z_frag); p.sf = static_cast<const uint4*>(s_frag);
     p.dW = dW; p.db = db; p.H = H; p.Din = Din;
     p.m_tiles = ceil_div(H, 16); p.n_tiles = ceil_div(Din, 16);
     p.nks = nks;
     const int mb = ceil_div(p.m_tiles, WG_MT), nb = ceil_div(p.n_tiles, WG_NT);
-    // one workgroup per CU: split the contraction so that blocks x slices ~ 256 with at least one k-step per
-    // wave; slices is 1, 2, 4 or a multiple of 8 so that each slice maps onto whole XCD groups
-    // (rounded DOWN: one more workgroup than CUs costs a whole second round)
+    // split the contraction so that blocks x slices ~ 256 (one workgroup per CU when the layer is alone in the launch; with
+    // several layers their workgroups share CUs, two fit) with at least one k-step per wave; slices is 1, 2, 4 or a multiple
+    // of 8 so that each slice maps onto whole XCD groups (rounded DOWN: one more workgroup than CUs costs a second round)
+    (void)layers_in_launch;
     int want = std::max(1, std::min(ceil_div(p.nks, 4), 256 / (mb * nb)));
     int slices = want >= 8 ? want / 8 * 8 : (want >= 4 ? 4 : (want >= 2 ? 2 : 1));
     p.ks_per_wg = ceil_div(p.nks, slices);
     p.mb = mb; p.nb = nb; p.slices = slices;
     const int per_group = (slices & 7) == 0 ? mb * nb * (slices / 8) : ceil_div(mb * nb, 8 / slices);
-    const dim3 grid(8 * per_group);
+    return 8 * per_group;
+}
+
+static int launch_weight_grad(hipStream_t s, const WeightGradMulti& mp, int compute_dtype) {
+    const dim3 grid(mp.first[mp.n]);
     if (compute_dtype == GCNPT_BF16)
-        hipLaunchKernelGGL(weight_grad_kernel<bf16_t>, grid, dim3(LAYER_THREADS), 0, s, p);
+        hipLaunchKernelGGL(weight_grad_kernel<bf16_t>, grid, dim3(LAYER_THREADS), 0, s, mp);
     else
-        hipLaunchKernelGGL(weight_grad_kernel<float>, grid, dim3(LAYER_THREADS), 0, s, p);
+        hipLaunchKernelGGL(weight_grad_kernel<float>, grid, dim3(LAYER_THREADS), 0, s, mp);
     GCNPT_HIP_CHECK(hipGetLastError());
     return GCNPT_OK;
 }
 
-extern "C" int gcnpt_layer_bwd_weight(void* stream, const void* z_frag, const void* s_frag, int B, int T, int Din, int H,
-                                      float* dW, float* db, int compute_dtype) {
-    GCNPT_REQUIRE(z_frag && s_frag && dW && db, "layer_bwd_weight: null pointer");
-    GCNPT_REQUIRE(B > 0 && T > 0 && Din > 0 && H > 0, "layer_bwd_weight: sizes must be positive");
+extern "C" int gcnpt_layer_bwd_weight_multi(void* stream, int n_layers, const void* const* z_frag, const void* const* s_frag,
+                                            int B, int T, const int* Din, const int* H, float* const* dW, float* const* db,
+                                            int compute_dtype) {
+    GCNPT_REQUIRE(n_layers >= 1 && n_layers <= WG_MAX_LAYERS, "layer_bwd_weight: 1..%d layers per call", WG_MAX_LAYERS);
+    GCNPT_REQUIRE(z_frag && s_frag && Din && H && dW && db, "layer_bwd_weight: null pointer");
+    GCNPT_REQUIRE(B > 0 && T > 0, "layer_bwd_weight: sizes must be positive");
     GCNPT_REQUIRE(dtype_ok(compute_dtype), "layer_bwd_weight: bad dtype");
     const int nks = ceil_div(B * T, 32) * (compute_dtype == GCNPT_BF16 ? 1 : 2);
-    return launch_weight_grad((hipStream_t)stream, z_frag, s_frag, nks, Din, H, dW, db, compute_dtype);
+    WeightGradMulti mp{};
+    mp.n = n_layers;
+    for (int l = 0; l < n_layers; ++l) {
+        GCNPT_REQUIRE(z_frag[l] && s_frag[l] && dW[l] && db[l], "layer_bwd_weight: null pointer (layer %d)", l);
+        GCNPT_REQUIRE(Din[l] > 0 && H[l] > 0, "layer_bwd_weight: sizes must be positive (layer %d)", l);
+        mp.first[l + 1] = mp.first[l] + plan_weight_grad(mp.l[l], z_frag[l], s_frag[l], nks, Din[l], H[l], dW[l], db[l], n_layers);
+    }
+    return launch_weight_grad((hipStream_t)stream, mp, compute_dtype);
+}
+
+extern "C" int gcnpt_layer_bwd_weight(void* stream, const void* z_frag, const void* s_frag, int B, int T, int Din, int H,
+                                      float* dW, float* db, int compute_dtype) {
+    return gcnpt_layer_bwd_weight_multi(stream, 1, &z_frag, &s_frag, B, T, &Din, &H, &dW, &db, compute_dtype);
 }
 
 // weight gradients of the sentence-resident stack: dW_l += G_l^T h_l from the two per-sentence fragment images
@@ -297,9 +330,11 @@ extern "C" int gcnpt_stack_bwd_weight(void* stream, int n_layers, const void* co
     GCNPT_REQUIRE(g_frag && h_frag && dW && n_layers >= 1 && n_layers <= 8, "stack_bwd_weight: bad argument");
     GCNPT_REQUIRE(B > 0 && T > 0 && Din > 0 && H > 0, "stack_bwd_weight: sizes must be positive");
     const int nks = B * ceil_div(T, 32);
-    for (int l = n_layers - 1; l >= 0; --l) {
+    WeightGradMulti mp{};
+    mp.n = n_layers;
+    for (int l = 0; l < n_layers; ++l) {
         GCNPT_REQUIRE(g_frag[l] && h_frag[l] && dW[l], "stack_bwd_weight: null pointer (layer %d)", l);
-        if (int rc = launch_weight_grad((hipStream_t)stream, g_frag[l], h_frag[l], nks, l == 0 ? Din : H, H, dW[l], nullptr, GCNPT_BF16)) return rc;
+        mp.first[l + 1] = mp.first[l] + plan_weight_grad(mp.l[l], g_frag[l], h_frag[l], nks, l == 0 ? Din : H, H, dW[l], nullptr, n_layers);
     }
-    return GCNPT_OK;
+    return launch_weight_grad((hipStream_t)stream, mp, GCNPT_BF16);
 }

@@ -116,6 +116,110 @@ def gcn_layer(h, weight, bias, trees, drop_p=0.0, seed=0, compute_dtype=torch.fl
     return _GCNLayerFn.apply(h, weight, bias, trees, float(drop_p), int(seed), compute, out_dtype, bool(no_adj))
 
 
+class _GCNLayersFn(torch.autograd.Function):
+    """The reference's layer loop (model/gcn.py:266-393) as ONE autograd op over the per-layer kernels: one launch packs
+    every layer's weights, one launch per layer and direction does the layer, one launch at the end of the backward sweep
+    computes every layer's weight gradient (2L + 2 launches instead of 4L)."""
+
+    @staticmethod
+    def forward(ctx, x, trees, cfg, *params):
+        Ws, bs = params[0::2], params[1::2]
+        L = len(Ws)
+        B, T, Din = x.shape
+        if (B, T) != (trees.B, trees.T):
+            raise RuntimeError("GCN layers: inputs are [%d,%d,*] but the adjacency is for [%d,%d]" % (B, T, trees.B, trees.T))
+        dims = [tuple(w.shape) for w in Ws]                           # (H_l, Din_l)
+        for l, (h, k) in enumerate(dims):
+            if k != (Din if l == 0 else dims[l - 1][0]):
+                raise RuntimeError("GCN layer %d: weight %s does not fit an input of width %d" % (l, (h, k), Din if l == 0 else dims[l - 1][0]))
+        lib, st, dev, compute = _lib.lib(), _lib.stream(), x.device, cfg["compute"]
+        x = x.contiguous()
+        w32 = [w.detach().to(torch.float32).contiguous() for w in Ws]
+        b32 = [b.detach().to(torch.float32).contiguous() for b in bs]
+        u8 = dict(dtype=torch.uint8, device=dev)
+        wf = [torch.empty((lib.gcnpt_packed_bytes(h, k, compute),), **u8) for h, k in dims]
+        wb = [torch.empty((lib.gcnpt_packed_bytes(k, h, compute),), **u8) for h, k in dims]
+        ints = lambda v: (ctypes.c_int * L)(*v)  # noqa: E731
+        _lib.check(lib.gcnpt_pack_weights_multi(st, L, _lib.ptr_array(w32), ints([h for h, _ in dims]), ints([k for _, k in dims]),
+                                                compute, _lib.ptr_array(wf), _lib.ptr_array(wb)))
+        need_w = any(p.requires_grad for p in params)
+        g_ell = trees.empty_ell() if cfg["no_adj"] else trees.ell
+        outs, s_frag, h = [], [], x
+        for l, (H, K) in enumerate(dims):
+            out = torch.empty((B, T, H), dtype=cfg["out_dtype"] if l == L - 1 else cfg["mid_dtype"], device=dev)
+            sf = torch.empty((lib.gcnpt_frag_bytes(B * T, K, compute),), **u8) if need_w else None
+            _lib.check(lib.gcnpt_layer_fwd(st, _lib.ptr(h), _lib.dtype_code(h.dtype), _lib.ptr(wf[l]), _lib.ptr(b32[l]),
+                                           _lib.ptr(trees.row_ptr), _lib.ptr(trees.col_idx), _lib.ptr(g_ell), _lib.ptr(trees.ell), B, T, K, H,
+                                           _lib.ptr(out), _lib.dtype_code(out.dtype), compute, float(cfg["drop_p"][l]), int(cfg["seed"][l]),
+                                           _lib.ptr(sf)))
+            outs.append(out)
+            s_frag.append(sf)
+            h = out
+        ctx.save_for_backward(*outs, *wb, *[f for f in s_frag if f is not None])
+        ctx.trees, ctx.cfg, ctx.dims, ctx.shape, ctx.need_w = trees, cfg, dims, (B, T, Din, L), need_w
+        ctx.x_dtype = x.dtype
+        ctx.param_dtypes = [p.dtype for p in params]
+        return outs[-1]
+
+    @staticmethod
+    def backward(ctx, gout):
+        B, T, Din, L = ctx.shape
+        saved = ctx.saved_tensors
+        outs, wb, s_frag = saved[:L], saved[L:2 * L], saved[2 * L:]
+        trees, cfg, dims = ctx.trees, ctx.cfg, ctx.dims
+        lib, st, dev, compute = _lib.lib(), _lib.stream(), gout.device, cfg["compute"]
+        want_w = ctx.need_w and any(ctx.needs_input_grad[3:])
+        g_ellT = trees.empty_ell() if cfg["no_adj"] else trees.ellT
+        u8 = dict(dtype=torch.uint8, device=dev)
+        z_frag, dWs, dbs = [None] * L, [None] * L, [None] * L
+        g = gout.to(outs[-1].dtype).contiguous()
+        for l in reversed(range(L)):
+            H, K = dims[l]
+            in_dtype = ctx.x_dtype if l == 0 else outs[l - 1].dtype
+            dh = torch.empty((B, T, K), dtype=in_dtype, device=dev) if (l > 0 or ctx.needs_input_grad[0]) else None
+            if want_w:
+                z_frag[l] = torch.empty((lib.gcnpt_frag_bytes(B * T, H, compute),), **u8)
+                dWs[l] = torch.empty((H, K), dtype=torch.float32, device=dev)          # cleared by bwd_data, filled at the end
+                dbs[l] = torch.empty((H,), dtype=torch.float32, device=dev)
+            if dh is not None or want_w:
+                scale = 1.0 / (1.0 - cfg["drop_p"][l]) if cfg["drop_p"][l] > 0 else 1.0
+                _lib.check(lib.gcnpt_layer_bwd_data(st, _lib.ptr(g), _lib.ptr(outs[l]), _lib.dtype_code(outs[l].dtype), _lib.ptr(wb[l]),
+                                                    _lib.ptr(trees.ell), _lib.ptr(trees.rowT_ptr), _lib.ptr(trees.colT_idx), _lib.ptr(g_ellT),
+                                                    B, T, K, H, _lib.ptr(dh), _lib.dtype_code(in_dtype), compute, scale, _lib.ptr(z_frag[l]),
+                                                    _lib.ptr(dWs[l]), _lib.ptr(dbs[l])))
+            g = dh
+        grads = [None] * (2 * L)
+        if want_w:
+            ints = lambda v: (ctypes.c_int * L)(*v)  # noqa: E731
+            _lib.check(lib.gcnpt_layer_bwd_weight_multi(st, L, _lib.ptr_array(z_frag), _lib.ptr_array(list(s_frag)), B, T,
+                                                        ints([k for _, k in dims]), ints([h for h, _ in dims]), _lib.ptr_array(dWs),
+                                                        _lib.ptr_array(dbs), compute))
+            for l in range(L):
+                grads[2 * l] = dWs[l].to(ctx.param_dtypes[2 * l])
+                grads[2 * l + 1] = dbs[l].to(ctx.param_dtypes[2 * l + 1])
+        return (g if ctx.needs_input_grad[0] else None, None, None) + tuple(grads)
+
+
+def gcn_layers(x, weights, biases, trees, drop_p=None, seeds=None, compute_dtype=torch.float32, out_dtype=torch.float32, no_adj=False):
+    """
+    The reference's whole layer loop (model/gcn.py:266-393) over the per-layer kernels.  x [B,T,Din] float32/bfloat16 CUDA;
+    weights / biases: lists of the nn.Linear parameters (any widths that chain); drop_p[l]: dropout applied to the output of
+    layer l (0 for the last).  compute_dtype float32 = exact fp32 MFMA (activations stay float32), bfloat16 = bf16 operands
+    and bf16 activations between the layers, fp32 accumulation; the last layer's output has out_dtype.
+    """
+    if not isinstance(trees, PrunedTrees):
+        raise TypeError("trees must be a PrunedTrees (see model.tree.prune_to_csr / adj_to_csr)")
+    _lib.require_gpu(x)
+    L = len(weights)
+    compute = _lib.dtype_code(compute_dtype)
+    if compute == _lib.F32:
+        x, out_dtype = (x.float() if x.dtype != torch.float32 else x), torch.float32
+    cfg = dict(drop_p=[float(p) for p in (drop_p or [0.0] * L)], seed=[int(s) for s in (seeds or [0] * L)], compute=compute,
+               mid_dtype=torch.float32 if compute == _lib.F32 else torch.bfloat16, out_dtype=out_dtype, no_adj=bool(no_adj))
+    params = [t for wb in zip(weights, biases) for t in wb]
+    return _GCNLayersFn.apply(x, trees, cfg, *params)
+
+
 class _GCNStackFn(torch.autograd.Function):
     """The whole L-layer stack as ONE op: sentence-resident kernels (csrc/stack_kernels.hip), one launch per direction."""
 
@@ -397,19 +501,14 @@ class GCN(nn.Module):
         no_adj = bool(self.opt.get('no_adj', False))                                           # gcn.py:264-265
         x = gcn_inputs
         B, T, Din = x.shape
+        ps = [self.gcn_drop.p if (self.training and l < self.layers - 1) else 0.0 for l in range(self.layers)]   # gcn.py:393
+        seeds = [int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0 for p in ps]        # CPU generator: no GPU sync
+        Ws, bs = [lin.weight for lin in self.W], [lin.bias for lin in self.W]
         if (self.compute_dtype == torch.bfloat16 and self.opt.get('gcn_fused', False)
                 and gcn_stack_supported(T, Din, self.mem_dim, self.layers)):
             # whole stack in one launch per direction (sentence-resident kernels)
-            ps = [self.gcn_drop.p if (self.training and l < self.layers - 1) else 0.0 for l in range(self.layers)]
-            seeds = [int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0 for p in ps]
-            h = gcn_stack(x, [lin.weight for lin in self.W], [lin.bias for lin in self.W], trees, ps, seeds, torch.float32, no_adj)
-            return h, trees.pool_mask
-        for l in range(self.layers):
-            last = l == self.layers - 1
-            p = self.gcn_drop.p if (self.training and not last) else 0.0                      # gcn.py:393
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0              # CPU generator: no GPU sync
-            out_dtype = torch.float32 if last else self.compute_dtype
-            x = gcn_layer(x, self.W[l].weight, self.W[l].bias, trees, p, seed, self.compute_dtype, out_dtype, no_adj)
+            return gcn_stack(x, Ws, bs, trees, ps, seeds, torch.float32, no_adj), trees.pool_mask
+        x = gcn_layers(x, Ws, bs, trees, ps, seeds, self.compute_dtype, torch.float32, no_adj)
         return x, trees.pool_mask
 
 

@@ -147,6 +147,12 @@ int gcnpt_layer_bwd_data(void* stream, const void* dY, const void* Y, int g_dtyp
                          void* z_frag, float* zero_dW, float* zero_db);
 int gcnpt_layer_bwd_weight(void* stream, const void* z_frag, const void* s_frag, int B, int T, int Din, int H,
                            float* dW, float* db, int compute_dtype);
+/* The weight gradients of n_layers (<= 8) layers in ONE launch: they all become computable at the end of the backward
+ * sweep, and each alone fills at most one workgroup per CU.  Arrays of n_layers entries (host memory), same meaning
+ * per layer as above; every layer sees the same B x T rows. */
+int gcnpt_layer_bwd_weight_multi(void* stream, int n_layers, const void* const* z_frag, const void* const* s_frag, int B,
+                                 int T, const int* Din, const int* H, float* const* dW, float* const* db,
+                                 int compute_dtype);
 
 /* ---- optional: the whole L-layer stack in ONE launch per direction (sentence-resident kernels) ---------------
  * A workgroup owns a whole sentence (T <= 112 rows) and runs every layer with the inter-layer activations in LDS;

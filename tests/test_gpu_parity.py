@@ -368,6 +368,43 @@ def test_layers_full_size_vs_oracle(api, dev, cfg):
     assert max_rel(r2["outs"][0], 2 * res[torch.float32]["outs"][0]) <= 1e-6
 
 
+@pytest.mark.parametrize("compute", [torch.float32, torch.bfloat16])
+def test_layer_loop_op_matches_chained_layers(api, dev, compute):
+    """gcn_layers (one pack launch, one weight-gradient launch for all layers: gcnpt_layer_bwd_weight_multi) against the
+    same layers chained one autograd op at a time: identical activations, gradients equal up to the order of the atomics."""
+    gcn, tree = api
+    g = layer_case("layers_c2s.npz")
+    base = _run_stack(api, dev, g, compute, drop=(0.5, 777))
+    trees = _prune(tree, g, int(g["prune_k"]), dev)
+    x = _t(g["x"], dev).requires_grad_()
+    Ws = [_t(w, dev).requires_grad_() for w in g["Ws"]]
+    bs = [_t(b, dev).requires_grad_() for b in g["bs"]]
+    h = gcn.gcn_layers(x, Ws, bs, trees, [0.5, 0.0], [777, 0], compute, torch.float32)
+    h.backward(_t(g["gy"], dev))
+    f = lambda t: t.detach().float().cpu().numpy()  # noqa: E731
+    np.testing.assert_array_equal(f(h), base["h"])
+    np.testing.assert_array_equal(f(x.grad), base["dx"])
+    for l in range(2):
+        assert max_rel(f(Ws[l].grad), base["dW"][l]) <= 1e-5 and max_rel(f(bs[l].grad), base["db"][l]) <= 1e-5
+    # three layers of different widths, no input gradient wanted
+    rng = np.random.RandomState(3)
+    dims = [(96, g["x"].shape[2]), (40, 96), (72, 40)]
+    Ws = [_t((rng.standard_normal(d) * 0.1).astype(np.float32), dev).requires_grad_() for d in dims]
+    bs = [_t((rng.standard_normal(d[0]) * 0.1).astype(np.float32), dev).requires_grad_() for d in dims]
+    x = _t(g["x"], dev)
+    gy = _t(rng.standard_normal(g["x"].shape[:2] + (72,)).astype(np.float32), dev)
+    gcn.gcn_layers(x, Ws, bs, trees, None, None, compute, torch.float32).backward(gy)
+    got = [f(w.grad) for w in Ws] + [f(b.grad) for b in bs]
+    for t in Ws + bs:
+        t.grad = None
+    hh = x
+    for l in range(3):
+        hh = gcn.gcn_layer(hh, Ws[l], bs[l], trees, 0.0, 0, compute, torch.float32 if l == 2 else compute)
+    hh.backward(gy)
+    for a, t in zip(got, Ws + bs):
+        assert max_rel(a, f(t.grad)) <= 1e-5
+
+
 # ---------------------------------------------------------------------------------------------------
 # sentence-resident stack (gcnpt_stack_fwd / bwd / bwd_weight): all layers in one launch per direction
 # ---------------------------------------------------------------------------------------------------
@@ -487,7 +524,7 @@ def _run_diag(api, dev, g, L, dtype=torch.float32, trees=None, drop=None):
     acts = []
     for l in range(L):
         p, seed = drop if (drop and l < L - 1) else (0.0, 0)
-        h = gcn.diag_layer(h, E, deprel, trees, p, seed)
+        h = gcn.diag_layer(h, E, deprel, trees, p, seed + 1000 * l)      # one seed per layer, as GCN.forward draws them
         acts.append(h)
     h.backward(_t(g["gy"], dev).to(dtype))
     f = lambda t: t.detach().float().cpu().numpy()  # noqa: E731

@@ -24,7 +24,7 @@ constexpr int RT_THREADS = 512;      // 8 waves; wave w owns output tiles w, w+8
 constexpr int RT_WAVES = RT_THREADS / WAVE;
 constexpr int NB_INLINE = 7;         // neighbours per row that the ELL head carries (include/gcnpt.h)
 #ifndef GCNPT_W_EARLY_NUM
-#define GCNPT_W_EARLY_NUM 2          // quarters of a wave's weight fragments requested before the adjacency is known
+#define GCNPT_W_EARLY_NUM 1          // quarters of a wave's weight fragments requested before the adjacency is known (0..4 measured: 1 is best)
 #endif
 
 struct RowTileParams {

@@ -39,7 +39,7 @@ def bench_names(rows):
         elif n.startswith("rowtile"):
             k = "bwd_data1"
         elif n.startswith("weight_grad"):
-            k = "bwd_weight%d" % (1 - seen["wg"] % 2); seen["wg"] += 1
+            k = "bwd_weight"                                   # one launch per step serves both layers
         elif n.startswith("pack"):
             k = "pack"
         elif n.startswith("prune"):
@@ -54,7 +54,7 @@ def per_kernel(run):
     files = glob.glob(os.path.join(SRC, run, "*", "*counter_collection.csv"))
     if not files:
         return {}
-    rows = list(csv.DictReader(open(files[0])))
+    rows = list(csv.DictReader(open(max(files, key=os.path.getmtime))))       # gpurun_out/ keeps earlier runs too
     by_disp = collections.OrderedDict()
     for r in rows:
         by_disp.setdefault(r["Dispatch_Id"], []).append(r)
@@ -72,7 +72,7 @@ def per_kernel(run):
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 stats = glob.glob(os.path.join(SRC, "trace", "*", "*kernel_stats.csv"))
 if stats:
-    shutil.copy(stats[0], os.path.join(ROOT, "profiles", "%s_kernel_stats.csv" % tag))
+    shutil.copy(max(stats, key=os.path.getmtime), os.path.join(ROOT, "profiles", "%s_kernel_stats.csv" % tag))
 merged = collections.defaultdict(dict)
 for run in ("fetch", "write", "sq", "mfma"):
     for k, cs in per_kernel(run).items():

@@ -9,8 +9,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GCNPT_LIB") or os.path.join(_HERE, "csrc", "libgcnpt.so")   # GCNPT_LIB: diagnostic builds
 
 F32, BF16 = 0, 1
-OK, E_INVALID, E_PRUNE_NEGATIVE, E_NO_SUBJECT, E_NO_LCA, E_CYCLE, E_BAD_HEAD, E_ASSERT, E_CAPACITY, E_HIP, E_UNSUPPORTED = \
-    0, -1, -2, -3, -4, -5, -6, -7, -8, -9, -10
+OK, E_INVALID, E_PRUNE_NEGATIVE, E_NO_SUBJECT, E_NO_LCA, E_CYCLE, E_BAD_HEAD, E_ASSERT, E_CAPACITY, E_HIP, E_UNSUPPORTED, E_LENGTH = \
+    0, -1, -2, -3, -4, -5, -6, -7, -8, -9, -10, -11
 
 # every symbol include/gcnpt.h declares: (restype, argtypes)
 _p, _i, _f, _u64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_uint64, ctypes.c_size_t
@@ -32,6 +32,7 @@ SIGNATURES = {
     "gcnpt_pool3_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i]),
     "gcnpt_diag_layer_fwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p, _f, _u64]),
     "gcnpt_diag_layer_bwd": (_i, [_p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _f]),
+    "gcnpt_gather_trees": (_i, [_p] * 11 + [_i, _i, _i, _p, _i, _i, _i] + [_p] * 9),
     "gcnpt_stack_supported": (_i, [_i, _i, _i, _i, _i]),
     "gcnpt_stack_frag_bytes": (_sz, [_i, _i, _i]),
     "gcnpt_stack_fwd": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p]),

@@ -433,6 +433,72 @@ __global__ void csr_to_adj_kernel(const int32_t* __restrict__ row_ptr, const int
         adj[((size_t)b * T + i) * T + col_idx[e]] = label ? (float)label[e] : 1.0f;
 }
 
+// ---- N4: a batch assembled from a dataset that was pruned once (loader.py:81-141 builds batches from cached features) ----
+// Sentence idx[b] of the cached PrunedTrees (S sentences padded to Ts, capacity cap_s) becomes sentence b of a PrunedTrees
+// for [B, T].  Columns are sentence-local, so entries and ELL heads are copied as they are; only offsets are re-based.
+constexpr int GATHER_THREADS = 256;
+struct TreeArrays {
+    int32_t *row_ptr, *col_idx, *label, *rowT_ptr, *colT_idx, *ell, *ellT;
+    uint8_t* pool_mask;
+    int32_t* status;
+};
+__global__ __launch_bounds__(GATHER_THREADS) void gather_trees_kernel(const TreeArrays src, const int32_t* __restrict__ src_len,
+                                                                     int S, int Ts, int cap_s, const int64_t* __restrict__ idx,
+                                                                     int B, int T, int cap, const TreeArrays dst) {
+    __shared__ int s_max[GATHER_THREADS / WAVE];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int64_t s64 = idx[b];
+    const bool known = s64 >= 0 && s64 < S;
+    const size_t s = known ? (size_t)s64 : 0;
+    const int len = known ? src_len[s] : 0;
+    const int nnz = src.row_ptr[s * (Ts + 1) + Ts] - (int)s * cap_s;
+    const int nnzT = src.rowT_ptr ? src.rowT_ptr[s * (Ts + 1) + Ts] - (int)s * cap_s : 0;
+    int code = known ? src.status[s] : GCNPT_E_INVALID;
+    if (code == 0 && len > T) code = GCNPT_E_LENGTH;
+    if (code == 0 && (nnz > cap || nnzT > cap)) code = GCNPT_E_CAPACITY;
+    const bool ok = code == 0;                           // otherwise: an empty, fully masked sentence, as the pruner leaves it
+    for (int i = t; i <= T; i += GATHER_THREADS) {
+        const size_t o = s * (Ts + 1) + min(i, Ts);
+        dst.row_ptr[(size_t)b * (T + 1) + i] = b * cap + (ok ? src.row_ptr[o] - (int)s * cap_s : 0);
+        if (dst.rowT_ptr) dst.rowT_ptr[(size_t)b * (T + 1) + i] = b * cap + (ok ? src.rowT_ptr[o] - (int)s * cap_s : 0);
+    }
+    if (ok) {
+        for (int k = t; k < nnz; k += GATHER_THREADS) {
+            dst.col_idx[(size_t)b * cap + k] = src.col_idx[s * cap_s + k];
+            if (dst.label) dst.label[(size_t)b * cap + k] = src.label[s * cap_s + k];
+        }
+        if (dst.colT_idx)
+            for (int k = t; k < nnzT; k += GATHER_THREADS) dst.colT_idx[(size_t)b * cap + k] = src.colT_idx[s * cap_s + k];
+    }
+    const int4 z = make_int4(0, 0, 0, 0);
+    for (int q = t; q < 2 * T; q += GATHER_THREADS) {    // ELL heads, 16 bytes at a time
+        const int i = q >> 1;
+        const bool have = ok && i < Ts;
+        const size_t o = (s * Ts + min(i, Ts - 1)) * 2 + (q & 1);
+        reinterpret_cast<int4*>(dst.ell)[(size_t)b * T * 2 + q] = have ? reinterpret_cast<const int4*>(src.ell)[o] : z;
+        if (dst.ellT) reinterpret_cast<int4*>(dst.ellT)[(size_t)b * T * 2 + q] = have ? reinterpret_cast<const int4*>(src.ellT)[o] : z;
+    }
+    if (dst.pool_mask)
+        for (int i = t; i < T; i += GATHER_THREADS)
+            dst.pool_mask[(size_t)b * T + i] = (ok && i < Ts) ? src.pool_mask[s * Ts + i] : (uint8_t)1;
+    if (t == 0) dst.status[b] = code;
+    if (b == 0) {                                        // status[B] = longest sentence of the batch (gcn.py:97): no memset, no atomics
+        int m = 0;
+        for (int j = t; j < B; j += GATHER_THREADS) {
+            const int64_t sj = idx[j];
+            if (sj >= 0 && sj < S) m = max(m, src_len[sj]);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d));
+        if ((t & 63) == 0) s_max[t >> 6] = m;
+        __syncthreads();
+        if (t == 0) {
+            for (int w = 1; w < GATHER_THREADS / WAVE; ++w) m = max(m, s_max[w]);
+            dst.status[B] = m;
+        }
+    }
+}
+
 }  // namespace gcnpt
 
 using namespace gcnpt;
@@ -488,6 +554,32 @@ extern "C" int gcnpt_csr_to_adj(void* stream, const int32_t* row_ptr, const int3
     GCNPT_HIP_CHECK(hipMemsetAsync(adj, 0, sizeof(float) * (size_t)B * T * T, s));
     const int rows = B * T;
     hipLaunchKernelGGL(csr_to_adj_kernel, dim3(ceil_div(rows, 256)), dim3(256), 0, s, row_ptr, col_idx, label, B, T, adj);
+    GCNPT_HIP_CHECK(hipGetLastError());
+    return GCNPT_OK;
+}
+
+extern "C" int gcnpt_gather_trees(void* stream, const int32_t* src_row_ptr, const int32_t* src_col_idx, const int32_t* src_label,
+                                  const int32_t* src_rowT_ptr, const int32_t* src_colT_idx, const int32_t* src_ell,
+                                  const int32_t* src_ellT, const uint8_t* src_pool_mask, const int32_t* src_status,
+                                  const int32_t* src_len, int S, int Ts, int cap_s, const int64_t* idx, int B, int T, int cap,
+                                  int32_t* row_ptr, int32_t* col_idx, int32_t* label, int32_t* rowT_ptr, int32_t* colT_idx,
+                                  int32_t* ell, int32_t* ellT, uint8_t* pool_mask, int32_t* status) {
+    GCNPT_REQUIRE(src_row_ptr && src_col_idx && src_ell && src_status && src_len && idx, "gather_trees: null cache pointer");
+    GCNPT_REQUIRE(row_ptr && col_idx && ell && status, "gather_trees: null output pointer");
+    GCNPT_REQUIRE(S > 0 && Ts > 0 && cap_s > 0 && B > 0 && T > 0 && cap > 0, "gather_trees: sizes must be positive");
+    GCNPT_REQUIRE(!label || src_label, "gather_trees: labels wanted but the cache holds none");
+    GCNPT_REQUIRE((rowT_ptr == nullptr) == (colT_idx == nullptr) && (rowT_ptr == nullptr) == (ellT == nullptr),
+                  "gather_trees: rowT_ptr, colT_idx and ellT go together");
+    GCNPT_REQUIRE(!rowT_ptr || (src_rowT_ptr && src_colT_idx && src_ellT), "gather_trees: transposed pattern wanted but the cache holds none");
+    GCNPT_REQUIRE(!pool_mask || src_pool_mask, "gather_trees: pool mask wanted but the cache holds none");
+    if ((long long)B * cap > 0x7fffffffLL) return fail(GCNPT_E_UNSUPPORTED, "gather_trees: B*cap overflows int32");
+    const TreeArrays src{const_cast<int32_t*>(src_row_ptr), const_cast<int32_t*>(src_col_idx), const_cast<int32_t*>(src_label),
+                         const_cast<int32_t*>(rowT_ptr ? src_rowT_ptr : nullptr), const_cast<int32_t*>(src_colT_idx),
+                         const_cast<int32_t*>(src_ell), const_cast<int32_t*>(src_ellT), const_cast<uint8_t*>(src_pool_mask),
+                         const_cast<int32_t*>(src_status)};
+    const TreeArrays dst{row_ptr, col_idx, label, rowT_ptr, colT_idx, ell, ellT, pool_mask, status};
+    hipLaunchKernelGGL(gather_trees_kernel, dim3(B), dim3(GATHER_THREADS), 0, (hipStream_t)stream, src, src_len, S, Ts, cap_s, idx, B, T,
+                       cap, dst);
     GCNPT_HIP_CHECK(hipGetLastError());
     return GCNPT_OK;
 }

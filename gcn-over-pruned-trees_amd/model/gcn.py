@@ -325,8 +325,8 @@ class GCNClassifier(nn.Module):
     def conv_l2(self):
         return self.gcn_model.gcn.conv_l2()
 
-    def forward(self, inputs):
-        outputs, pooling_output = self.gcn_model(inputs)
+    def forward(self, inputs, trees=None):
+        outputs, pooling_output = self.gcn_model(inputs, trees)
         return self.classifier(outputs), pooling_output
 
     def get_deprel_emb(self):
@@ -385,14 +385,19 @@ class GCNRelationModel(nn.Module):
                 return grad
             self.emb.weight.register_hook(keep_top)
 
-    def forward(self, inputs):
+    def forward(self, inputs, trees=None):
+        """`trees`: optional PrunedTrees of this batch from a TreeCache (model.tree, loader-side pre-pruning); by default
+        the batch is pruned here."""
         if self.opt['dataset'] == 'tacred':
             words, masks, pos, ner, deprel, head, subj_pos, obj_pos = inputs
         else:
             words, masks, pos, deprel, head, subj_pos, obj_pos = inputs
-        # lengths, head_to_tree, tree_to_adj and the upload (gcn.py:96-112) in one launch, no host round trip
-        trees = prune_to_csr(head, subj_pos, obj_pos, deprel, self.opt['prune_k'], masks=masks,
-                             want_label=self.adj_type != 'regular')
+        if trees is None:
+            # lengths, head_to_tree, tree_to_adj and the upload (gcn.py:96-112) in one launch, no host round trip
+            trees = prune_to_csr(head, subj_pos, obj_pos, deprel, self.opt['prune_k'], masks=masks,
+                                 want_label=self.adj_type != 'regular')
+        elif (trees.B, trees.T) != tuple(head.shape):
+            raise ValueError("trees are for a [%d,%d] batch, the inputs are %s" % (trees.B, trees.T, tuple(head.shape)))
         if self.opt.get('gcn_check_trees', True):
             trees.check(expect_maxlen=head.shape[1])
         h, pool_mask = self.gcn(trees, inputs)

@@ -23,6 +23,8 @@ REFERENCE_EXCEPTION = {
     _lib.E_BAD_HEAD: "IndexError (model/tree.py:94, head points past the sentence)",
     _lib.E_ASSERT: "AssertionError (model/tree.py:159)",
     _lib.E_CAPACITY: "n/a (adjacency capacity exceeded)",
+    _lib.E_INVALID: "IndexError (sentence index outside the cached dataset)",
+    _lib.E_LENGTH: "n/a (cached sentence longer than the batch is padded to)",
 }
 
 
@@ -156,6 +158,50 @@ def adj_to_csr(adj, want_label=True):
                                            _lib.ptr(label), _lib.ptr(rowT_ptr), _lib.ptr(colT_idx), _lib.ptr(ell), _lib.ptr(ellT),
                                            _lib.ptr(pool_mask), _lib.ptr(status)))
     return PrunedTrees(B, T, cap, *bufs)
+
+
+class TreeCache(object):
+    """
+    Loader-side pre-pruning (reference data/loader.py:81-141 + model/gcn.py:96-110): pruning depends on
+    the parse alone, so the whole dataset is pruned once on the device and stays in HBM; `batch(idx, T)` assembles the
+    PrunedTrees of a batch from the cached rows (one small copy kernel), bit-identical to pruning that batch directly.
+    """
+
+    def __init__(self, trees, lens, prune_k):
+        self.trees, self.lens, self.prune_k = trees, lens, int(prune_k)
+
+    def __len__(self):
+        return self.trees.B
+
+    @classmethod
+    def build(cls, head, subj_pos, obj_pos, deprel, prune_k, masks=None, lens=None, want_label=True):
+        """head/subj_pos/obj_pos/deprel: int64 [S,Ts] CUDA tensors of the WHOLE dataset padded to its longest sentence;
+        masks (True = pad) or lens as in prune_to_csr.  Per-sentence errors stay in the cache and surface in the
+        batches that contain the sentence (PrunedTrees.check)."""
+        trees = prune_to_csr(head, subj_pos, obj_pos, deprel, prune_k, masks=masks, lens=lens, want_label=want_label)
+        if lens is None:
+            lens = (masks == 0).sum(1)
+        lens = lens.to(device=head.device, dtype=torch.int32).contiguous()
+        return cls(trees, lens, prune_k)
+
+    def batch(self, idx, T, want_label=None):
+        """idx: int64 [B] sentence numbers (CUDA tensor; repeats allowed); T: the width the batch tensors are padded to
+        (the reference pads to the longest sentence of the batch, gcn.py:97)."""
+        src = self.trees
+        idx = _lib.require_gpu(idx).to(torch.int64).contiguous()
+        B, T = int(idx.numel()), int(T)
+        want_label = (src.label is not None) if want_label is None else want_label
+        if want_label and src.label is None:
+            raise ValueError("the cache was built without labels")
+        cap = 3 * T
+        bufs = _alloc(B, T, cap, src.device, want_label, True)
+        row_ptr, col_idx, label, rowT_ptr, colT_idx, ell, ellT, pool_mask, status = bufs
+        P = _lib.ptr
+        _lib.check(_lib.lib().gcnpt_gather_trees(
+            _lib.stream(), P(src.row_ptr), P(src.col_idx), P(src.label), P(src.rowT_ptr), P(src.colT_idx), P(src.ell), P(src.ellT),
+            P(src.pool_mask), P(src.status), P(self.lens), src.B, src.T, src.cap, P(idx), B, T, cap,
+            P(row_ptr), P(col_idx), P(label), P(rowT_ptr), P(colT_idx), P(ell), P(ellT), P(pool_mask), P(status)))
+        return PrunedTrees(B, T, cap, *bufs)
 
 
 def inputs_to_tree_reps(head, words, l, prune, subj_pos, obj_pos, deprel):

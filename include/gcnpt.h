@@ -58,6 +58,7 @@ extern "C" {
 #define GCNPT_E_CAPACITY -8       /* a sentence needs more than `cap` adjacency entries */
 #define GCNPT_E_HIP -9            /* a HIP runtime call failed */
 #define GCNPT_E_UNSUPPORTED -10   /* shape outside what the kernels are built for */
+#define GCNPT_E_LENGTH -11        /* gcnpt_gather_trees: a cached sentence is longer than the batch's T */
 
 int gcnpt_abi_version(void);
 const char* gcnpt_last_error(void);
@@ -204,6 +205,21 @@ int gcnpt_diag_layer_bwd(void* stream, const void* dY, const void* Y, const void
                          const int64_t* deprel, const int32_t* row_ptr, const int32_t* col_idx, const int32_t* label,
                          const int32_t* rowT_ptr, const int32_t* colT_idx, int B, int T, int H, void* dh, float* dE,
                          float scale);
+
+/* ---- N4: loader-side pre-pruning (data/loader.py:81-141 builds batches from per-sentence features; trainer.py:52-73) ----
+ * Pruning depends on the parse alone, so a dataset is pruned ONCE -- gcnpt_prune_to_csr over all S sentences padded to
+ * the dataset's longest sentence Ts, capacity cap_s -- and the result stays in HBM.  gcnpt_gather_trees assembles the
+ * arrays of a batch from it: cached sentence idx[b] becomes sentence b of a [B, T] batch (src_* = the cached arrays,
+ * src_len int32 [S] = sentence lengths; the outputs have exactly the layout gcnpt_prune_to_csr writes for B, T, cap and
+ * are bit-identical to pruning that batch directly).  label / rowT_ptr+colT_idx+ellT / pool_mask may be NULL.
+ * status[b] = the cached sentence's own code, GCNPT_E_INVALID for an index outside [0,S), GCNPT_E_LENGTH when the
+ * sentence has more than T tokens, GCNPT_E_CAPACITY when it has more than cap entries; status[B] = longest sentence. */
+int gcnpt_gather_trees(void* stream, const int32_t* src_row_ptr, const int32_t* src_col_idx, const int32_t* src_label,
+                       const int32_t* src_rowT_ptr, const int32_t* src_colT_idx, const int32_t* src_ell,
+                       const int32_t* src_ellT, const uint8_t* src_pool_mask, const int32_t* src_status,
+                       const int32_t* src_len, int S, int Ts, int cap_s, const int64_t* idx, int B, int T, int cap,
+                       int32_t* row_ptr, int32_t* col_idx, int32_t* label, int32_t* rowT_ptr, int32_t* colT_idx,
+                       int32_t* ell, int32_t* ellT, uint8_t* pool_mask, int32_t* status);
 
 #ifdef __cplusplus
 }

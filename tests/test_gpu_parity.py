@@ -507,6 +507,94 @@ def test_fused_stack_dropout_no_adj_and_dense_adjacency(api, dev):
 
 
 # ---------------------------------------------------------------------------------------------------
+# N4: loader-side pre-pruning (TreeCache / gcnpt_gather_trees)
+# ---------------------------------------------------------------------------------------------------
+def _same_trees(a, b):
+    """Two PrunedTrees are the same adjacency: offsets, ELL heads, masks, status exact; entries compared where they exist."""
+    for name in ("row_ptr", "rowT_ptr", "ell", "ellT", "pool_mask", "status"):
+        np.testing.assert_array_equal(getattr(a, name).cpu().numpy(), getattr(b, name).cpu().numpy(), err_msg=name)
+    rp = a.row_ptr.view(a.B, a.T + 1).cpu().numpy()
+    rpT = a.rowT_ptr.view(a.B, a.T + 1).cpu().numpy()
+    for name, ptr in (("col_idx", rp), ("label", rp), ("colT_idx", rpT)):
+        x, y = getattr(a, name), getattr(b, name)
+        assert (x is None) == (y is None)
+        if x is None:
+            continue
+        x, y = x.cpu().numpy(), y.cpu().numpy()
+        for s in range(a.B):
+            np.testing.assert_array_equal(x[ptr[s, 0]:ptr[s, -1]], y[ptr[s, 0]:ptr[s, -1]], err_msg="%s, sentence %d" % (name, s))
+
+
+def test_tree_cache_batches_equal_direct_pruning(api, dev):
+    """A dataset pruned once + gcnpt_gather_trees gives bit-identical PrunedTrees to pruning each batch on its own, for
+    any batch composition (repeats, any padded width >= the longest sentence)."""
+    gcn, tree = api
+    g = load_golden("trees_random.npz")
+    S, Ts = g["head"].shape
+    lens = g["lens"].astype(np.int32)
+    rng = np.random.RandomState(11)
+    for K in (0, 1, 2):
+        cache = tree.TreeCache.build(_t(g["head"], dev), _t(g["subj_pos"], dev), _t(g["obj_pos"], dev), _t(g["deprel"], dev), K,
+                                     lens=_t(lens, dev))
+        assert len(cache) == S
+        for B, extra in ((50, 0), (37, 0), (128, 9), (1, 3)):
+            idx = rng.randint(0, S, size=B)
+            T = int(lens[idx].max()) + extra
+            got = cache.batch(_t(idx.astype(np.int64), dev), T).check(expect_maxlen=T if extra == 0 else None)
+
+            def pad(a, fill=0):
+                out = np.full((B, T), fill, dtype=a.dtype)
+                w = min(T, Ts)
+                out[:, :w] = a[idx][:, :w]
+                return out
+            want = tree.prune_to_csr(_t(pad(g["head"]), dev), _t(pad(g["subj_pos"], 999), dev), _t(pad(g["obj_pos"], 999), dev),
+                                     _t(pad(g["deprel"]), dev), K, lens=_t(lens[idx], dev))
+            _same_trees(got, want)
+            ref = dense_from_coo(g["coo_k%d" % K], S, Ts)[idx]                     # and both equal the reference's matrices
+            dense = got.to_dense().cpu().numpy()
+            w = min(T, Ts)
+            np.testing.assert_array_equal(dense[:, :w, :w], ref[:, :w, :w])
+            assert not dense[:, w:, :].any() and not dense[:, :, w:].any()
+
+
+def test_tree_cache_errors_and_model_hook(api, dev):
+    gcn, tree = api
+    from gcn_over_pruned_trees_amd import _lib
+    g = load_golden("trees_edge_cases.npz")
+    S, Ts = g["head"].shape
+    cache = tree.TreeCache.build(_t(g["head"], dev), _t(g["subj_pos"], dev), _t(g["obj_pos"], dev), _t(g["deprel"], dev), 1,
+                                 lens=_t(g["lens"].astype(np.int32), dev))
+    idx = np.array(list(range(S)) + [S, -1, 3], dtype=np.int64)
+    got = cache.batch(_t(idx, dev), Ts)
+    st = got.status.cpu().numpy()
+    np.testing.assert_array_equal(st[:S], g["status_k1"])                          # cached errors travel with the sentence
+    assert st[S] == _lib.E_INVALID and st[S + 1] == _lib.E_INVALID and st[S + 2] == g["status_k1"][3]
+    assert st[-1] == g["lens"].max()
+    with pytest.raises(tree.TreeError):
+        got.check()
+    short = cache.batch(_t(np.array([0, 7], dtype=np.int64), dev), int(g["lens"][7]) - 1)      # sentence 7 does not fit
+    assert short.status.cpu().numpy()[1] == _lib.E_LENGTH
+    empty = short.to_dense().cpu().numpy()[1]
+    assert not empty.any() and short.pool_mask.cpu().numpy()[1].all()
+    # the module takes cached trees in place of pruning the batch itself: same logits
+    import json
+    e = load_golden("e2e_gcn.npz")
+    opt = json.loads(str(e["opt"]))
+    opt["cuda"] = True
+    model = gcn.GCNClassifier(opt)
+    model.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in e.items() if k.startswith("sd:")}, strict=True)
+    model.to(dev).eval()
+    inputs = tuple(_t(e[k], dev) for k in ("words", "masks", "pos", "ner", "deprel", "head", "subj_pos", "obj_pos"))
+    words, masks, pos, ner, deprel, head, subj_pos, obj_pos = inputs
+    cache = tree.TreeCache.build(head, subj_pos, obj_pos, deprel, opt["prune_k"], masks=masks, want_label=False)
+    perm = torch.randperm(head.shape[0], device=dev)
+    with torch.no_grad():
+        base, _ = model(inputs)
+        shuffled, _ = model(tuple(t[perm] for t in inputs), trees=cache.batch(perm, head.shape[1]))
+    assert max_rel(shuffled.cpu().numpy(), base[perm].cpu().numpy()) <= 1e-5      # (library GEMMs may tile rows differently)
+
+
+# ---------------------------------------------------------------------------------------------------
 # N2: adj_type == 'diagonal_deprel' (gcnpt_diag_layer_fwd / bwd)
 # ---------------------------------------------------------------------------------------------------
 def _run_diag(api, dev, g, L, dtype=torch.float32, trees=None, drop=None):

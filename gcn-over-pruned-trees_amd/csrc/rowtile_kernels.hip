@@ -22,6 +22,7 @@ namespace gcnpt {
 constexpr int ROWS = 32;             // token rows per workgroup (two 16-row MFMA tiles)
 constexpr int RT_THREADS = 512;      // 8 waves; wave w owns output tiles w, w+8, ...
 constexpr int RT_WAVES = RT_THREADS / WAVE;
+static_assert(RT_THREADS == 16 * ROWS, "the row store loop gives every row 16 threads");
 constexpr int NB_INLINE = 7;         // neighbours per row that the ELL head carries (include/gcnpt.h)
 #ifndef GCNPT_W_EARLY_NUM
 #define GCNPT_W_EARLY_NUM 1          // quarters of a wave's weight fragments requested before the adjacency is known (0..4 measured: 1 is best)
@@ -42,6 +43,7 @@ struct RowTileParams {
     float* zero_b;
     int zero_a_n, zero_b_n;
     int N, T, K, NOUT, Kpad;
+    unsigned chunk_magic;   // ceil(2^32 / (Kpad / 8)): division by the chunks per row as a multiply-high
     int vec_in, vec_out;    // rows may be read / written 16 bytes at a time (vec_in selects the VEC instantiation)
     float scale;            // bwd: 1/(1-p) of the dropout applied to Y; fwd: 1/(1-drop_p)
     float drop_p;           // fwd
@@ -72,7 +74,8 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
     int* glist = meta + 10 * ROWS;            // [ROWS] tile rows that aggregate at least one entry, compacted
     int* gcount = meta + 11 * ROWS;           // [1] their number
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // `wave` through readfirstlane: the compiler then knows it is uniform and does every wave-dependent address in SALU
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r0 = blockIdx.x * ROWS;
     const IT* src = static_cast<const IT*>(p.src);
     const IT* yref = static_cast<const IT*>(p.yref);
@@ -92,6 +95,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
 
     // own rows of the first batch (everyone)
     const int nchunk = p.Kpad / 8;
+    auto div_chunk = [&](int x) { return (int)__umulhi((unsigned)x, p.chunk_magic); };    // x / nchunk, exact for x * nchunk < 2^32
     const int n_items = ROWS * nchunk;
     const int kmax8 = VEC ? p.K - 8 : p.K - 1;
     raw8<IT> self[ITEMS], selfy[ITEMS];
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
 #pragma unroll
         for (int u = 0; u < ITEMS; ++u) {
             const int it = (batch * ITEMS + u) * RT_THREADS + tid;
-            const int row = it / nchunk, k0 = (it - row * nchunk) * 8;
+            const int row = div_chunk(it), k0 = (it - row * nchunk) * 8;
             const size_t r = (size_t)min(r0 + row, p.N - 1);
             issue8<IT, VEC>(src, r, p.K, min(k0, kmax8), self[u]);
             if (BWD) issue8<IT, VEC>(yref, r, p.K, min(k0, kmax8), selfy[u]);
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
     const int n_g = *gcount * nchunk;
     auto g_decode = [&](int gi, int& row, int& k0, int& n) {
         const bool has = gi < n_g;
-        const int li = has ? gi / nchunk : 0;
+        const int li = has ? div_chunk(gi) : 0;
         row = has ? glist[li] : 0;
         k0 = has ? (gi - li * nchunk) * 8 : 0;
         n = (has && k0 < p.K) ? rell[row * 8] : 0;
@@ -289,8 +293,13 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
         for (int u = 0; u < ITEMS; ++u) {
             const int it = (batch * ITEMS + u) * RT_THREADS + tid;
             if (it >= n_items) continue;
-            const int row = it / nchunk, k0 = (it - row * nchunk) * 8;
+            const int row = div_chunk(it), k0 = (it - row * nchunk) * 8;
             const bool live = r0 + row < p.N && k0 < p.K;
+            if constexpr (!BWD && sizeof(IT) == 2 && sizeof(CT) == 2) {     // bf16 rows into a bf16 tile: the 16 bytes as they are
+                if (!(p.out && rell[row * 8] > 0))
+                    *reinterpret_cast<uint4*>(S + (size_t)row * stride + k0) = live ? self[u].a : make_uint4(0, 0, 0, 0);
+                continue;
+            }
             float acc[8];
             unpack8<IT>(self[u], live, acc);                            // the explicit W(h) term, gcn.py:271
             if (BWD) {
@@ -464,14 +473,12 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
         const int width = c_hi - c_lo;
         constexpr int PER = 16 / (int)sizeof(OT);
         if (p.vec_out && (width % PER) == 0 && (c_lo % PER) == 0) {
-            const int pieces = width / PER;
-            for (int it = tid; it < ROWS * pieces; it += RT_THREADS) {
-                const int row = it / pieces, pc = it - row * pieces;
-                const int r = r0 + row;
-                if (r < p.N)
+            const int pieces = width / PER;                                  // 16 threads per row: no division, 256 contiguous bytes each round
+            const int row = tid >> 4, r = r0 + row;
+            if (r < p.N)
+                for (int pc = tid & 15; pc < pieces; pc += 16)
                     *reinterpret_cast<uint4*>(out + (size_t)r * p.NOUT + c_lo + pc * PER) =
                         *reinterpret_cast<const uint4*>(O + (size_t)row * ostride + pc * PER);
-            }
         } else {
             for (int it = tid; it < ROWS * width; it += RT_THREADS) {
                 const int row = it / width, c = it - row * width;
@@ -545,7 +552,7 @@ extern "C" int gcnpt_layer_fwd(void* stream, const void* h, int h_dtype, const v
     p.src = h; p.yref = nullptr; p.wfrag = w_fwd; p.bias = bias;
     p.g_row_ptr = row_ptr; p.g_col_idx = col_idx; p.g_ell = ell; p.d_ell = deg_ell ? deg_ell : ell; p.out = out;
     p.frag_out = s_frag;
-    p.N = B * T; p.T = T; p.K = Din; p.NOUT = H; p.Kpad = round_up(Din, kstep_of(compute_dtype));
+    p.N = B * T; p.T = T; p.K = Din; p.NOUT = H; p.Kpad = round_up(Din, kstep_of(compute_dtype)); p.chunk_magic = 0xffffffffu / (unsigned)(p.Kpad / 8) + 1u;
     p.vec_in = (Din % 8 == 0) && aligned16(h);
     p.vec_out = ((H * esize(out_dtype)) % 16 == 0) && aligned16(out);
     p.drop_p = drop_p; p.scale = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
@@ -569,7 +576,7 @@ extern "C" int gcnpt_layer_bwd_data(void* stream, const void* dY, const void* Y,
     p.g_row_ptr = rowT_ptr; p.g_col_idx = colT_idx; p.g_ell = ellT; p.d_ell = ell; p.out = dh;
     p.frag_out = z_frag;
     p.zero_a = zero_dW; p.zero_a_n = H * Din; p.zero_b = zero_db; p.zero_b_n = H;
-    p.N = B * T; p.T = T; p.K = H; p.NOUT = Din; p.Kpad = round_up(H, kstep_of(compute_dtype));
+    p.N = B * T; p.T = T; p.K = H; p.NOUT = Din; p.Kpad = round_up(H, kstep_of(compute_dtype)); p.chunk_magic = 0xffffffffu / (unsigned)(p.Kpad / 8) + 1u;
     p.vec_in = (H % 8 == 0) && aligned16(dY) && aligned16(Y);
     p.vec_out = dh && ((Din * esize(dh_dtype)) % 16 == 0) && aligned16(dh);
     p.scale = scale; p.drop_p = 0.0f;

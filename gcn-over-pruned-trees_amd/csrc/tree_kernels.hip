@@ -273,6 +273,7 @@ __device__ void emit_rows(int b, int T, int cap, int* smem, int err, int n_edge_
                           int32_t* __restrict__ col_idx, int32_t* __restrict__ label, int32_t* __restrict__ colT_idx,
                           int32_t* __restrict__ ell, int32_t* __restrict__ ellT, unsigned long long* stamps) {
     if (err) return;
+    GCNPT_STAMP(stamps, 8);
     int* deg = smem + 2 * T;
     int* degT = deg + T + 1;
     int* lab = degT + 2 * (T + 1);
@@ -320,6 +321,9 @@ __device__ void emit_rows(int b, int T, int cap, int* smem, int err, int n_edge_
                 if (lane == 0) hd[0] = n_e; else if (lane > n_e) hd[lane] = 0;
                 if (hdT) { if (lane == 0) hdT[0] = n_eT; else if (lane > n_eT) hdT[lane] = 0; }
             }
+#ifdef GCNPT_STAMPS
+            if (qq < 12) GCNPT_STAMP(stamps, 9 + qq / 4);            // diagnostic: wave 0's rows 0, 4, 8 of the chunk
+#endif
         }
     }
     GCNPT_STAMP(stamps, 7);

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(LAYER_THREADS) void weight_grad_kernel(const Weight
 #pragma unroll
     for (int i = 1; i < WG_MAX_LAYERS; ++i) layer += (i < mp.n && (int)blockIdx.x >= mp.first[i]) ? 1 : 0;
     const WeightGradParams& p = mp.l[layer];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // Workgroups are dealt round-robin over the 8 XCDs (id % 8 labels the XCD group), each with its own L2.
     // All blocks of one contraction slice read the same rows of both images, so a slice is pinned to one
     // XCD group: its rows cross the fabric once and every other read hits that XCD's L2.  (Speed only.)

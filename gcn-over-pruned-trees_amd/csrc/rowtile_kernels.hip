@@ -72,7 +72,8 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
     float* rinv = reinterpret_cast<float*>(meta + 8 * ROWS);   // [ROWS] fwd: 1/(deg+1)   bwd: scale/(deg+1)
     float* rden = reinterpret_cast<float*>(meta + 9 * ROWS);   // [ROWS] deg+1
     int* glist = meta + 10 * ROWS;            // [ROWS] tile rows that aggregate at least one entry, compacted
-    int* gcount = meta + 11 * ROWS;           // [1] their number
+    int* rsb = meta + 11 * ROWS;              // [ROWS] first row of the row's sentence (b * T)
+    int* gcount = meta + 12 * ROWS;           // [1] the number of entries of glist
 
     // `wave` through readfirstlane: the compiler then knows it is uniform and does every wave-dependent address in SALU
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
     const size_t er = (size_t)min(r0 + erow, p.N - 1);
     const int4 ell_v = reinterpret_cast<const int4*>(p.g_ell)[er * 2 + ehalf];
     const int deg_v = p.d_ell[er * 8];                                                   // gcn.py:261
+    const int sb_v = (int)er / p.T * p.T;          // the one division by T, done while the loads are on their way
 
     // own rows of the first batch (everyone)
     const int nchunk = p.Kpad / 8;
@@ -157,6 +159,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
         const int e0 = (first && r0 + erow >= p.N) ? 0 : ell_v.x;                    // rows past the end aggregate nothing
         reinterpret_cast<int4*>(rell)[erow * 2 + ehalf] = make_int4(e0, ell_v.y, ell_v.z, ell_v.w);
         const float dn = (float)(deg_v + 1);
+        rsb[erow] = sb_v;
         rinv[erow] = (BWD ? p.scale : 1.0f) / dn;       // both lanes of a row write it: a use under `first` only would let
         rden[erow] = dn;                                // hipcc sink the degree load into that branch, behind a full wait
         const bool agg = first && e0 > 0 && p.out != nullptr;
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
         int row, k0, n;
         g_decode(gi, row, k0, n);
         const size_t r = (size_t)min(r0 + row, p.N - 1);
-        const int sbase = (int)(r / p.T) * p.T;                        // first row of this row's sentence
+        const int sbase = rsb[row];                                    // first row of this row's sentence
         const int k0c = min(k0, kmax8);
         issue8<IT, VEC>(src, r, p.K, k0c, g.s);
         if (BWD) issue8<IT, VEC>(yref, r, p.K, k0c, g.sy);
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
         const bool has = g_decode(gi, row, k0, n);
         const bool live = has && k0 < p.K;
         const size_t rc = (size_t)min(r0 + row, p.N - 1);
-        const int sbase = (int)(rc / p.T) * p.T;
+        const int sbase = rsb[row];
         const int k0c = min(k0, kmax8);
         float acc[8];
         unpack8<IT>(g.s, live, acc);                                    // the explicit W(h) term, gcn.py:271
@@ -314,8 +317,8 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
         }
     };
     copy_batch(0);
-    // (2a)
-    g_finish(tid, g0);
+    // (2a) -- only the waves that own an item: the sums cost a wave ~120 VALU instructions whether its lanes are live or not
+    if (wave * WAVE < n_g) g_finish(tid, g0);
     for (int base = RT_THREADS; base < n_g; base += RT_THREADS) {      // tiles with more than 512 / (K/8) aggregating rows
         GItem g;
         g_issue(base + tid, g);
@@ -503,7 +506,7 @@ static int launch_rowtile_cfg(hipStream_t s, const RowTileParams& p) {
     const int ncols_pass = RT_WAVES * NTW * 16;
     const int ostride = out_stride_dw(std::min(round_up(p.NOUT, 16), ncols_pass) * (int)sizeof(OT) / 4) * 4 / (int)sizeof(OT);
     const size_t lds = (size_t)(BWD ? 2 : 1) * ROWS * stride * sizeof(CT) + (size_t)ROWS * ostride * sizeof(OT) +
-                       (size_t)ROWS * 12 * sizeof(int);
+                       (size_t)ROWS * 13 * sizeof(int);
     if (lds > 160 * 1024) return fail(GCNPT_E_UNSUPPORTED, "layer: K=%d needs %zu B of LDS per workgroup", p.K, lds);
     auto kern = rowtile_kernel<CT, IT, OT, BWD, VEC, NTW, KSMAX>;
     if (lds > 64 * 1024)

@@ -165,6 +165,9 @@ __global__ __launch_bounds__(LAYER_THREADS) void weight_grad_kernel(const Weight
 #pragma unroll
             for (int i = 0; i < WG_MT; ++i) {
                 const uint4 av = live ? a[u][i] : zero4;
+                // db on the VALU, in every block.  Tried and measured slower: the column sums as one more MFMA against a fragment
+                // of ones (+3.4 us: hipcc then schedules for occupancy and no longer keeps the batch of loads in flight), and
+                // summing only in the blocks that store db (a branch here makes every wait in the batch a full drain, +1.8 us)
                 dbp[i] += frag_sum<CT>(av);
 #pragma unroll
                 for (int j = 0; j < WG_NT; ++j) {

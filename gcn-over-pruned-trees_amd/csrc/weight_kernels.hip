@@ -4,7 +4,6 @@
 
 namespace gcnpt {
 
-constexpr int LAYER_THREADS = 256;
 
 // ---------------------------------------------------------------------------------------------------
 // nn.Linear weight [H,Din] fp32 -> MFMA B-operand fragments
@@ -109,10 +108,15 @@ struct WeightGradMulti {
     int n;
 };
 
-template <typename CT>
-__global__ __launch_bounds__(LAYER_THREADS) void weight_grad_kernel(const WeightGradMulti mp) {
-    __shared__ f32x4_t red[4][WG_MT * WG_NT][WAVE];        // 48 KiB: per-wave partial tiles
-    __shared__ float dbred[4][WG_MT][16];
+// WG_WAVES waves split a workgroup's k-steps: 4 when a layer has the launch to itself (its slices are short), 8 when several
+// layers share the CUs (twice the k-steps per workgroup: 8 waves still take them in ONE batch of loads each)
+template <typename CT, int WG_WAVES>
+__global__ __launch_bounds__(WG_WAVES * WAVE, 2) void weight_grad_kernel(const WeightGradMulti mp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
+    typedef f32x4_t RedTile[WG_MT * WG_NT][WAVE];
+    RedTile* red = reinterpret_cast<RedTile*>(wg_smem);                                   // [WG_WAVES] per-wave partial tiles, 12 KiB each
+    typedef float DbTile[WG_MT][16];
+    DbTile* dbred = reinterpret_cast<DbTile*>(wg_smem + sizeof(RedTile) * WG_WAVES);     // [WG_WAVES]
 
     int layer = 0;
 #pragma unroll
@@ -146,11 +150,11 @@ __global__ __launch_bounds__(LAYER_THREADS) void weight_grad_kernel(const Weight
     // Every load below is unconditional (clamped indices): a load behind a runtime condition gets its own basic
     // block and an s_waitcnt vmcnt(0) from hipcc, which would turn this batch into 35 serial round trips.
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
-    for (int base = ks_lo + wave; base < ks_hi; base += 4 * WG_KB) {
+    for (int base = ks_lo + wave; base < ks_hi; base += WG_WAVES * WG_KB) {
         uint4 a[WG_KB][WG_MT], b[WG_KB][WG_NT];
 #pragma unroll
         for (int u = 0; u < WG_KB; ++u) {
-            int ks = min(base + 4 * u, p.nks - 1);
+            int ks = min(base + WG_WAVES * u, p.nks - 1);
 #ifdef GCNPT_STAMPS
             if (p.knob & 2) ks = 0;                                       // experiment: every load hits the same lines
 #endif
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(LAYER_THREADS) void weight_grad_kernel(const Weight
         }
 #pragma unroll
         for (int u = 0; u < WG_KB; ++u) {
-            const bool live = base + 4 * u < ks_hi;                       // past the slice: contributes zeros
+            const bool live = base + WG_WAVES * u < ks_hi;                       // past the slice: contributes zeros
 #pragma unroll
             for (int i = 0; i < WG_MT; ++i) {
                 const uint4 av = live ? a[u][i] : zero4;
@@ -202,10 +206,12 @@ __global__ __launch_bounds__(LAYER_THREADS) void weight_grad_kernel(const Weight
     }
     __syncthreads();
     GCNPT_STAMP(p.stamps, 2);
-    for (int tt = wave; tt < WG_MT * WG_NT; tt += 4) {
+    for (int tt = wave; tt < WG_MT * WG_NT; tt += WG_WAVES) {
         const int i = tt / WG_NT, j = tt - i * WG_NT;
         if (m0 + i >= p.m_tiles || n0 + j >= p.n_tiles) continue;
-        const f32x4_t v = red[0][tt][lane] + red[1][tt][lane] + red[2][tt][lane] + red[3][tt][lane];
+        f32x4_t v = red[0][tt][lane];
+#pragma unroll
+        for (int w = 1; w < WG_WAVES; ++w) v += red[w][tt][lane];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int m = (m0 + i) * 16 + (lane >> 4) * 4 + g;
@@ -217,7 +223,12 @@ __global__ __launch_bounds__(LAYER_THREADS) void weight_grad_kernel(const Weight
         const int i = tid >> 4, c = tid & 15;
         const int m = (m0 + i) * 16 + c;
         if (m0 + i < p.m_tiles && m < p.H)
-            atomicAdd(p.db + m, 2.0f * (dbred[0][i][c] + dbred[1][i][c] + dbred[2][i][c] + dbred[3][i][c]));   // bias enters twice
+        {
+            float sdb = dbred[0][i][c];
+#pragma unroll
+            for (int w = 1; w < WG_WAVES; ++w) sdb += dbred[w][i][c];
+            atomicAdd(p.db + m, 2.0f * sdb);                                 // bias enters twice
+        }
     }
     GCNPT_STAMP(p.stamps, 3);
 }
@@ -285,7 +296,7 @@ static int plan_weight_grad(WeightGradParams& p, const void* z_frag, const void*
     // them: measured 2 us faster per step than letting each layer bring 256 of its own), with at least one k-step per wave;
     // slices is 1, 2, 4 or a multiple of 8 so that each slice maps onto whole XCD groups (rounded DOWN: one more
     // workgroup than CUs costs a second round)
-    int want = std::max(1, std::min(ceil_div(p.nks, 4), 256 / (mb * nb * layers_in_launch)));
+    int want = std::max(1, std::min(ceil_div(p.nks, layers_in_launch > 1 ? 8 : 4), 256 / (mb * nb * layers_in_launch)));
     int slices = want >= 8 ? want / 8 * 8 : (want >= 4 ? 4 : (want >= 2 ? 2 : 1));
     p.ks_per_wg = ceil_div(p.nks, slices);
     p.mb = mb; p.nb = nb; p.slices = slices;
@@ -293,14 +304,22 @@ static int plan_weight_grad(WeightGradParams& p, const void* z_frag, const void*
     return 8 * per_group;
 }
 
-static int launch_weight_grad(hipStream_t s, const WeightGradMulti& mp, int compute_dtype) {
-    const dim3 grid(mp.first[mp.n]);
-    if (compute_dtype == GCNPT_BF16)
-        hipLaunchKernelGGL(weight_grad_kernel<bf16_t>, grid, dim3(LAYER_THREADS), 0, s, mp);
-    else
-        hipLaunchKernelGGL(weight_grad_kernel<float>, grid, dim3(LAYER_THREADS), 0, s, mp);
+template <typename CT, int NW>
+static int launch_weight_grad_cfg(hipStream_t s, const WeightGradMulti& mp) {
+    const size_t lds = (sizeof(f32x4_t) * WG_MT * WG_NT * WAVE + sizeof(float) * WG_MT * 16) * NW;      // 49 / 98 KiB
+    static bool attr_set = false;                       // once per instantiation (and so never first inside a stream capture replay)
+    if (lds > 64 * 1024 && !attr_set) {
+        GCNPT_HIP_CHECK(hipFuncSetAttribute((const void*)weight_grad_kernel<CT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((weight_grad_kernel<CT, NW>), dim3(mp.first[mp.n]), dim3(NW * WAVE), lds, s, mp);
     GCNPT_HIP_CHECK(hipGetLastError());
     return GCNPT_OK;
+}
+
+static int launch_weight_grad(hipStream_t s, const WeightGradMulti& mp, int compute_dtype) {
+    if (compute_dtype == GCNPT_BF16) return mp.n > 1 ? launch_weight_grad_cfg<bf16_t, 8>(s, mp) : launch_weight_grad_cfg<bf16_t, 4>(s, mp);
+    return mp.n > 1 ? launch_weight_grad_cfg<float, 8>(s, mp) : launch_weight_grad_cfg<float, 4>(s, mp);
 }
 
 extern "C" int gcnpt_layer_bwd_weight_multi(void* stream, int n_layers, const void* const* z_frag, const void* const* s_frag,

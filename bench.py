@@ -55,8 +55,8 @@ def parse():
                     help="one weight-gradient launch per layer (right after that layer's backward-data) instead of one launch "
                          "for all layers at the end of the backward sweep")
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
-                    help="2 = run layer-1 bwd-weight beside layer-0 bwd-data (and the tree build beside the pack) on a side stream; "
-                         "measured slower than 1 on MI355X: the cross-stream graph edges cost more than the overlap gains")
+                    help="2 = run the tree build beside the weight pack on a side stream (only matters for with_prune / with_cached_trees); "
+                         "measured slower on MI355X (85 -> 88 us with the pruner, 68 -> 82 with cached trees): parallel graph branches cost more than they hide")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -233,9 +233,8 @@ class Stack(object):
 
     def step(self, k=0, with_prune=False):
         """
-        One step.  With --streams 2: the weight gradient of layer 1 only needs layer 1's dZ image, so it runs beside the
-        backward-data kernel of layer 0; the tree build only needs the loader tensors, so it runs beside the weight pack.
-        Every kernel of the step is still launched and finished inside the step (fork and join are inside it).
+        One step.  With --streams 2 the tree build, which only needs the loader tensors, runs beside the weight pack on a
+        side stream (fork and join are inside the step, so they become parallel branches of the captured graph).
         """
         if self.args.streams == 1 or self.fused:
             if with_prune == "cached":
@@ -247,20 +246,16 @@ class Stack(object):
             return
         main = torch.cuda.current_stream()
         side = self.side
-        if with_prune:
+        if with_prune:                                   # fork: the tree build beside the weight pack
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                self.prune()
-        self.pack_all()
+                self.gather() if with_prune == "cached" else self.prune()
+        calls = self.calls(k)
+        calls[0][1]()                                    # pack
         if with_prune:
-            main.wait_stream(side)
-        self.fwd(0); self.fwd(1)
-        self.bwd_data(1, k)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            self.bwd_weight(1, k)
-        self.bwd_data(0, k); self.bwd_weight(0, k)
-        main.wait_stream(side)
+            main.wait_stream(side)                       # join before the first layer
+        for _, call in calls[1:]:
+            call()
 
     # ---- algorithmic bytes per launch (DESIGN.md "Measurement") ----
     def algorithmic_bytes(self):

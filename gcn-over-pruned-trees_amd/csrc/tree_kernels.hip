@@ -15,7 +15,8 @@
 
 namespace gcnpt {
 
-constexpr int PRUNE_THREADS = 256;   // wave 0 prunes the sentence (wave-local phases); all 4 waves then emit the rows
+constexpr int PRUNE_THREADS = 1024;  // wave 0 prunes the sentence (wave-local phases); all 16 waves then emit the rows (one each, typically)
+constexpr int PRUNE_SCAN_MAX = 1 << 16;   // B*T up to which workgroup 0 finds the longest sentence itself (no memset, no atomics)
 constexpr int ADJ_THREADS = 256;
 
 enum : int {
@@ -115,7 +116,7 @@ __device__ void prune_sentence(const int64_t* __restrict__ head, const int64_t* 
     }
     // sentence length = number of non-pad slots (gcn.py:96)
     const int len = pad_mask ? T - wave_sum(npad) : min(max(len_in[b], 0), T);
-    if (lane == 0) atomicMax(&status[B], len);
+    if (lane == 0 && (long long)B * T > PRUNE_SCAN_MAX) atomicMax(&status[B], len);     // small batches: workgroup 0 scans, see the kernel
     int nsubj = 0, nent = 0;
     for (int i = lane; i < T; i += WAVE) {
         const int w = pw[i];
@@ -344,10 +345,32 @@ __global__ __launch_bounds__(PRUNE_THREADS) void prune_to_csr_kernel(
     if (threadIdx.x == 0) { s_err = 0; s_status = 0; s_nrows = 0; }
     GCNPT_STAMP_REAL(stamps);
     GCNPT_STAMP(stamps, 0);
+    __shared__ int s_maxlen;
+    if (threadIdx.x == 0) s_maxlen = 0;
     __syncthreads();
     if (wave == 0) prune_sentence(head, subj_pos, obj_pos, deprel, pad_mask, len_in, b, B, T, prune_k, cap, smem, &s_err, &s_status,
                                   &s_nrows, row_ptr, rowT_ptr, ell, ellT, pool_mask, status, stamps);
+    else if (b == 0 && (long long)B * T <= PRUNE_SCAN_MAX) {
+        // status[B] = longest sentence of the batch (gcn.py:97): the idle waves of workgroup 0 count every sentence's non-pad
+        // slots while wave 0 prunes, so the launch needs neither a memset of that word nor one atomic per sentence
+        int m = 0;
+        for (int sidx = wave - 1; sidx < B; sidx += PRUNE_THREADS / WAVE - 1) {
+            int n;
+            if (pad_mask) {
+                n = 0;
+                for (int i0 = 0; i0 < T; i0 += WAVE) {
+                    const int i = i0 + lane;
+                    n += __popcll(__ballot(i < T && pad_mask[(size_t)sidx * T + min(i, T - 1)] == 0));
+                }
+            } else {
+                n = min(max(len_in[sidx], 0), T);
+            }
+            m = max(m, n);
+        }
+        if (lane == 0) atomicMax(&s_maxlen, m);
+    }
     __syncthreads();
+    if (b == 0 && threadIdx.x == 0 && (long long)B * T <= PRUNE_SCAN_MAX) status[B] = s_maxlen;
     emit_rows(b, T, cap, smem, s_status, s_nrows, lane, wave, col_idx, label, colT_idx, ell, ellT, stamps);
 }
 
@@ -524,7 +547,7 @@ extern "C" int gcnpt_prune_to_csr(void* stream, const int64_t* head, const int64
     const size_t lds = sizeof(int) * ((size_t)7 * T + 4);
     if (T > PRUNE_MAX_T) return fail(GCNPT_E_UNSUPPORTED, "prune_to_csr: T=%d exceeds the %d tokens a sentence may have", T, PRUNE_MAX_T);
     hipStream_t s = (hipStream_t)stream;
-    GCNPT_HIP_CHECK(hipMemsetAsync(status + B, 0, sizeof(int32_t), s));
+    if ((long long)B * T > PRUNE_SCAN_MAX) GCNPT_HIP_CHECK(hipMemsetAsync(status + B, 0, sizeof(int32_t), s));   // big batches: atomicMax per sentence
     hipLaunchKernelGGL(prune_to_csr_kernel, dim3(B), dim3(PRUNE_THREADS), lds, s, head, subj_pos, obj_pos, deprel,
                        pad_mask, len, B, T, prune_k, cap, row_ptr, col_idx, label, rowT_ptr, colT_idx, ell, ellT, pool_mask, status,
                        static_cast<unsigned long long*>(g_debug_stamps));

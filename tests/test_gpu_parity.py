@@ -557,6 +557,25 @@ def test_tree_cache_batches_equal_direct_pruning(api, dev):
             assert not dense[:, w:, :].any() and not dense[:, :, w:].any()
 
 
+def test_pruner_large_batch_longest_sentence(api, dev):
+    """Above 65536 token slots the longest-sentence word is kept with a memset + one atomic per sentence instead of
+    workgroup 0's scan: both ways give the same arrays."""
+    gcn, tree = api
+    g = load_golden("trees_random.npz")
+    rep = lambda a: np.concatenate([a, a[::-1]], 0)  # noqa: E731
+    S, Ts = g["head"].shape
+    lens = rep(g["lens"].astype(np.int32))
+    big = tree.prune_to_csr(_t(rep(g["head"]), dev), _t(rep(g["subj_pos"]), dev), _t(rep(g["obj_pos"]), dev), _t(rep(g["deprel"]), dev), 1,
+                            lens=_t(lens, dev)).check()
+    assert 2 * S * Ts > 65536 and int(big.status[-1]) == lens.max()
+    ref = dense_from_coo(g["coo_k1"], S, Ts)
+    np.testing.assert_array_equal(big.to_dense().cpu().numpy(), rep(ref))
+    masks = np.arange(Ts)[None, :] >= lens[:, None]
+    viam = tree.prune_to_csr(_t(rep(g["head"]), dev), _t(rep(g["subj_pos"]), dev), _t(rep(g["obj_pos"]), dev), _t(rep(g["deprel"]), dev), 1,
+                             masks=_t(masks, dev))
+    _same_trees(big, viam)
+
+
 def test_tree_cache_errors_and_model_hook(api, dev):
     gcn, tree = api
     from gcn_over_pruned_trees_amd import _lib

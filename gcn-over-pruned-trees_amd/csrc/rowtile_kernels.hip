@@ -74,6 +74,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
     int* glist = meta + 10 * ROWS;            // [ROWS] tile rows that aggregate at least one entry, compacted
     int* rsb = meta + 11 * ROWS;              // [ROWS] first row of the row's sentence (b * T)
     int* gcount = meta + 12 * ROWS;           // [1] the number of entries of glist
+    float* sbias = reinterpret_cast<float*>(meta + 13 * ROWS);   // [RT_THREADS] fwd: the bias of this pass's columns
 
     // `wave` through readfirstlane: the compiler then knows it is uniform and does every wave-dependent address in SALU
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -94,6 +95,8 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
     const int4 ell_v = reinterpret_cast<const int4*>(p.g_ell)[er * 2 + ehalf];
     const int deg_v = p.d_ell[er * 8];                                                   // gcn.py:261
     const int sb_v = (int)er / p.T * p.T;          // the one division by T, done while the loads are on their way
+    float bias_v = 0.0f;                           // fwd: one bias element per thread, parked in LDS with the heads (registers are
+    if constexpr (!BWD) bias_v = p.bias[min(tid, p.NOUT - 1)];      // too scarce to carry 4 per tile through the whole kernel)
 
     // own rows of the first batch (everyone)
     const int nchunk = p.Kpad / 8;
@@ -132,23 +135,8 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
                 wreg[ks][j] = wfrag[((size_t)tl * ksteps + kk) * 64 + lane];
             }
     };
-    // fwd epilogue operand, fetched now, used last.  The MFMAs run with swapped operands (weights as A), so a lane
-    // ends up with 4 CONSECUTIVE output columns of one row: columns 16 tile + 4 (lane>>4) + g.
-    // (only loaded here: any arithmetic on it now would be a wait for everything issued before it)
-    float braw[NTW][4];
-    auto load_bias = [&](int pass) {
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) {
-            const int col0 = (pass * RT_WAVES * NTW + j * RT_WAVES + wave) * 16 + (lane >> 4) * 4;
-            if ((p.NOUT & 3) == 0) {                                  // kernel-uniform: one 16-byte load per tile
-                const float4 bv = *reinterpret_cast<const float4*>(p.bias + min(col0, p.NOUT - 4));
-                braw[j][0] = bv.x; braw[j][1] = bv.y; braw[j][2] = bv.z; braw[j][3] = bv.w;
-            } else {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) braw[j][g] = p.bias[min(col0 + g, p.NOUT - 1)];
-            }
-        }
-    };
+    // (The MFMAs run with swapped operands, weights as A, so a lane ends up with 4 CONSECUTIVE output columns of one row:
+    // columns 16 tile + 4 (lane>>4) + g.)
     load_w(0, 0, 0, KS_EARLY);              // unconditional even when only the side outputs are wanted: a branch here would
                                             // make every later wait assume the shorter queue
 
@@ -160,6 +148,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
         reinterpret_cast<int4*>(rell)[erow * 2 + ehalf] = make_int4(e0, ell_v.y, ell_v.z, ell_v.w);
         const float dn = (float)(deg_v + 1);
         rsb[erow] = sb_v;
+        if constexpr (!BWD) sbias[tid] = bias_v;
         rinv[erow] = (BWD ? p.scale : 1.0f) / dn;       // both lanes of a row write it: a use under `first` only would let
         rden[erow] = dn;                                // hipcc sink the degree load into that branch, behind a full wait
         const bool agg = first && e0 > 0 && p.out != nullptr;
@@ -287,7 +276,6 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
     GItem g0;
     g_issue(tid, g0);
     load_w(0, 0, KS_EARLY, KSMAX);                              // 156 KB per workgroup at Din=360, H=200
-    if constexpr (!BWD) load_bias(0);
 
     // (2b)
     const int n_batches = ceil_div(n_items, ITEMS * RT_THREADS);
@@ -425,7 +413,10 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
         // Lane (i = lane & 15, q = lane >> 4) holds, per 16x16 tile, row i and the 4 consecutive columns 4q..4q+3.
         if (pass > 0) {
             __syncthreads();                                             // previous pass's rows have left O
-            if constexpr (!BWD) load_bias(pass);
+            if constexpr (!BWD) {                                        // (NOUT > 512 only) this pass's bias
+                sbias[tid] = p.bias[min(pass * ncols_pass + tid, p.NOUT - 1)];
+                __syncthreads();
+            }
         }
         float den[2], inv[2];
 #pragma unroll
@@ -440,11 +431,16 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
             for (int mt = 0; mt < 2; ++mt) {
                 const int row = mt * 16 + (lane & 15);
                 float v[4];
+                float bq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if constexpr (!BWD) {
+                    const float4 bv = *reinterpret_cast<const float4*>(sbias + lcol0);
+                    bq[0] = bv.x; bq[1] = bv.y; bq[2] = bv.z; bq[3] = bv.w;
+                }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float x = acc[mt][j][g];
                     if (!BWD) {
-                        x = div_by(x + 2.0f * braw[j][g], den[mt], inv[mt]);   // gcn.py:270-271 (the bias enters twice), 390
+                        x = div_by(x + 2.0f * bq[g], den[mt], inv[mt]);   // gcn.py:270-271 (the bias enters twice), 390
                         x = x > 0.0f ? x : 0.0f;                         // gcn.py:392
                     }
                     v[g] = x;
@@ -506,7 +502,7 @@ static int launch_rowtile_cfg(hipStream_t s, const RowTileParams& p) {
     const int ncols_pass = RT_WAVES * NTW * 16;
     const int ostride = out_stride_dw(std::min(round_up(p.NOUT, 16), ncols_pass) * (int)sizeof(OT) / 4) * 4 / (int)sizeof(OT);
     const size_t lds = (size_t)(BWD ? 2 : 1) * ROWS * stride * sizeof(CT) + (size_t)ROWS * ostride * sizeof(OT) +
-                       (size_t)ROWS * 13 * sizeof(int);
+                       (size_t)ROWS * 13 * sizeof(int) + (size_t)RT_THREADS * sizeof(float);
     if (lds > 160 * 1024) return fail(GCNPT_E_UNSUPPORTED, "layer: K=%d needs %zu B of LDS per workgroup", p.K, lds);
     auto kern = rowtile_kernel<CT, IT, OT, BWD, VEC, NTW, KSMAX>;
     if (lds > 64 * 1024)
@@ -522,8 +518,12 @@ static int launch_rowtile_cfg(hipStream_t s, const RowTileParams& p) {
 template <typename CT, typename IT, typename OT, bool BWD>
 static int launch_rowtile(hipStream_t s, const RowTileParams& p) {
     const int n_tiles = ceil_div(p.NOUT, 16);
-    if (!p.vec_in) return launch_rowtile_cfg<CT, IT, OT, BWD, false, 4, 4>(s, p);
-    if (n_tiles <= RT_WAVES * 2) return launch_rowtile_cfg<CT, IT, OT, BWD, true, 2, 12>(s, p);
+    if (!p.vec_in) return launch_rowtile_cfg<CT, IT, OT, BWD, false, 4, BWD ? 3 : 4>(s, p);
+    if (n_tiles <= RT_WAVES * 2) {
+        // 13 k-steps = the C-GCN input width (2 x 200 BiLSTM states): one more resident k-step instead of a second load phase
+        if (p.Kpad / (sizeof(CT) == 2 ? 32 : 16) == 13) return launch_rowtile_cfg<CT, IT, OT, BWD, true, 2, 13>(s, p);
+        return launch_rowtile_cfg<CT, IT, OT, BWD, true, 2, 12>(s, p);
+    }
     if (n_tiles <= RT_WAVES * 3) return launch_rowtile_cfg<CT, IT, OT, BWD, true, 3, 7>(s, p);
     return launch_rowtile_cfg<CT, IT, OT, BWD, true, 4, 5>(s, p);
 }

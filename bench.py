@@ -479,8 +479,16 @@ def main():
                                   "note": "in-step duration: HIP events around hipGraph replays of the step truncated after k launches, t(k)-t(k-1); includes the launch boundary"}
             result["kernels"] = {k: {"avg_us": kt[k] * 1e6, "algorithmic_bytes": alg[k], "GBps": alg[k] / kt[k] / 1e9} for k in kt}
             tot_b = sum(alg[k] for k in step_keys)
+            # SURVEY.md 8(d) counts the layer math only (S = (A+I)h recomputed in backward, no saved-operand images, no pack):
+            e, Nr, csr = (2 if args.dtype == "bf16" else 4), args.batch * args.seq, 4 * (args.batch * args.seq + 1) + 4 * stack.nnz
+            survey = sum(e * Nr * (Din + H) + e * Din * H + 4 * H + csr + e * Nr * (2 * H + 2 * Din) + (e + 4) * Din * H + 4 * H + csr
+                         for H, Din in [tuple(w.shape) for w in stack.W])
+            t_step = wall / args.steps
             result["step_roofline"] = {"algorithmic_bytes": tot_b, "sum_kernel_us": sum(kt[k] for k in step_keys) * 1e6,
-                                       "frac_of_hbm_peak": tot_b / sum(kt[k] for k in step_keys) / 1e9 / HBM_PEAK_GBS}
+                                       "frac_of_hbm_peak": tot_b / sum(kt[k] for k in step_keys) / 1e9 / HBM_PEAK_GBS,
+                                       "survey_8d_bytes": survey, "survey_8d_frac_of_hbm_peak": survey / t_step / 1e9 / HBM_PEAK_GBS,
+                                       "note": "algorithmic_bytes = what this dataflow must move (incl. the saved-operand images and the "
+                                               "weight pack); survey_8d_bytes = SURVEY.md 8(d)'s formula for the layer math alone, over the whole step time"}
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         print(json.dumps(result))

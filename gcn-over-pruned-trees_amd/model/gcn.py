@@ -344,16 +344,15 @@ class GCNRelationModel(nn.Module):
         self.opt = opt
         self.emb_matrix = emb_matrix
         self.adj_type = opt.get('adj_type', 'regular')
-        if self.adj_type not in ('regular', 'diagonal_deprel'):
-            raise NotImplementedError("adj_type=%r: 'regular' and 'diagonal_deprel' are built; full_deprel is the next "
-                                      "row of the scope table" % opt['adj_type'])
+        if self.adj_type not in ('regular', 'diagonal_deprel', 'full_deprel'):
+            raise ValueError('Adjacency aggregation type not supported.')            # gcn.py:388 (concat_deprel is dead code there)
         self.emb = nn.Embedding(opt['vocab_size'], opt['emb_dim'], padding_idx=constant.PAD_ID)
         self.pos_emb = nn.Embedding(constant.N_POS, opt['pos_dim']) if opt['pos_dim'] > 0 else None
         self.ner_emb = nn.Embedding(constant.N_NER, opt['ner_dim']) if opt['ner_dim'] > 0 else None
         # gcn.py:48-56: the reference keeps a 1-wide dummy table on the regular path (kept for checkpoints);
-        # diagonal_deprel scales hidden vectors element-wise, so its table is hidden_dim wide
-        self.deprel_emb = nn.Embedding(constant.N_DEPREL, opt['hidden_dim'] if self.adj_type == 'diagonal_deprel' else 1,
-                                       padding_idx=0)
+        # diagonal_deprel scales hidden vectors element-wise, so its table is hidden_dim wide; full_deprel mixes deprel_emb_dim matrices
+        width = {'regular': 1, 'diagonal_deprel': opt['hidden_dim']}.get(self.adj_type) or opt['deprel_emb_dim']
+        self.deprel_emb = nn.Embedding(constant.N_DEPREL, width, padding_idx=0)
         self.init_embeddings()
         self.gcn = GCN(opt, (self.emb, self.pos_emb, self.ner_emb, self.deprel_emb), opt['hidden_dim'], opt['num_layers'])
         mlp = [nn.Linear(opt['hidden_dim'] * 3, opt['hidden_dim']), nn.ReLU()]
@@ -421,8 +420,8 @@ class GCN(nn.Module):
         self.in_dim = opt['emb_dim'] + opt['pos_dim'] + (opt['ner_dim'] if tacred else 0)
         self.emb, self.pos_emb, self.ner_emb, self.deprel_emb = embeddings
         self.adj_type = opt.get('adj_type', 'regular')
-        if self.adj_type not in ('regular', 'diagonal_deprel'):
-            raise NotImplementedError("adj_type=%r is not built yet; 'regular' and 'diagonal_deprel' are" % opt['adj_type'])
+        if self.adj_type not in ('regular', 'diagonal_deprel', 'full_deprel'):
+            raise ValueError('Adjacency aggregation type not supported.')            # gcn.py:388
         if opt.get('rnn', False):
             self.rnn = nn.LSTM(self.in_dim, opt['rnn_hidden'], opt['rnn_layers'], batch_first=True,
                                dropout=opt['rnn_dropout'], bidirectional=True)
@@ -434,6 +433,8 @@ class GCN(nn.Module):
         if self.adj_type == 'diagonal_deprel':                  # gcn.py:153-155: no per-layer weights in this variant
             self.preprocessor = nn.Linear(self.in_dim, mem_dim)
             self.in_dim = mem_dim
+        elif self.adj_type == 'full_deprel':                    # gcn.py:156-167: ONE Linear, reshaped to [D, in_dim, H], for every layer
+            self.W = nn.Linear(self.in_dim, opt['deprel_emb_dim'] * mem_dim, bias=True)
         else:
             self.W = nn.ModuleList(nn.Linear(self.in_dim if l == 0 else mem_dim, mem_dim) for l in range(num_layers))
         kind = opt.get('gcn_dtype', 'fp32')
@@ -442,8 +443,8 @@ class GCN(nn.Module):
         self.compute_dtype = torch.float32 if kind == 'fp32' else torch.bfloat16
 
     def conv_l2(self):
-        # the reference's diagonal_deprel model has no W list, so its conv_l2() / get_gcn_parameters() raise
-        # AttributeError (gcn.py:207-215); the same happens here
+        # the reference's diagonal_deprel model has no W list, so its conv_l2() / get_gcn_parameters() raise AttributeError
+        # (gcn.py:180-184, 397-398), and full_deprel's single nn.Linear is not iterable (TypeError); the same happens here
         return sum(p.pow(2).sum() for lin in self.W for p in (lin.weight, lin.bias))
 
     def get_gcn_parameters(self):
@@ -483,6 +484,72 @@ class GCN(nn.Module):
             x = diag_layer(x, table, deprel, trees, p, seed)
         return x.float(), trees.pool_mask
 
+    def _forward_full(self, adj, gcn_inputs, deprel):
+        """adj_type='full_deprel', gcn.py:296-388 + traverse_deprel / traverse_self_loop 400-434, fp32.
+        trav(x, e)[n] = sum_d e[n,d] (x[n] W3[d] + b3[d]) is only needed for tokens that sit in a pruned tree, so those are
+        compacted (one host sync for their number), their outer products e (x) x meet W3 as [D*Tin, H] in ONE library GEMM per
+        direction, and the results travel along the CSR entries of the device pruner (value ranges pick forward / reverse).
+        The reference materialises [B,T,D,Tin] for all tokens and multiplies dense [B,T,T] matrices instead."""
+        opt = self.opt
+        trees = adj if isinstance(adj, PrunedTrees) else adj_to_csr(adj, want_label=True)
+        if trees.label is None:
+            raise ValueError("full_deprel needs the adjacency values: build the trees with want_label=True")
+        B, T, cap = trees.B, trees.T, trees.cap
+        N, D, H = B * T, opt['deprel_emb_dim'], self.mem_dim
+        dev = trees.device
+        max_depth = opt.get('deprel_max_depth', 2)
+        directed, self_loop = bool(opt.get('deprel_directed', False)), bool(opt.get('deprel_self_loop', True))
+        # CSR slots -> (row, column) token numbers; slots past a sentence's entries are invalid (no host sync)
+        rp = trees.row_ptr.view(B, T + 1).to(torch.int64)
+        slot = torch.arange(B * cap, device=dev).view(B, cap)
+        valid = (slot < rp[:, -1:]).view(-1)
+        base = (torch.arange(B, device=dev) * T).view(B, 1)
+        rows = (torch.searchsorted(rp[:, 1:].contiguous(), slot, right=True).clamp_(max=T - 1) + base).view(-1)
+        cols = (trees.col_idx.view(B, cap).to(torch.int64).clamp(0, T - 1) + base).view(-1)
+        lab = trees.label.view(-1)
+        fwd_e = valid & (lab > 0) & (lab < constant.DEPREL_FORWARD_BOUND)                        # gcn.py:308-311
+        rev_e = valid & (lab > constant.DEPREL_FORWARD_BOUND) & (lab < constant.DEPREL_REVERSE_BOUND)   # gcn.py:340-344
+        denom = (trees.ell.view(N, 8)[:, 0] + 1).to(torch.float32).unsqueeze(1)                  # gcn.py:261
+        tok = torch.nonzero(~trees.pool_mask.view(-1)).squeeze(1)                                # tokens of the pruned trees
+        pos = torch.zeros((N,), dtype=torch.int64, device=dev)
+        pos[tok] = torch.arange(tok.numel(), device=dev)
+        deprel_tok = deprel.reshape(-1)[tok]
+        b3 = self.W.bias.reshape(D, H)                                                            # gcn.py:303
+        x = gcn_inputs.to(torch.float32)
+        for l in range(self.layers):
+            Tin = x.shape[-1]
+            if self.W.weight.shape[1] != Tin:       # the reference's einsum fails the same way when in_dim != mem_dim (layer 1)
+                raise RuntimeError("full_deprel: layer %d input has %d features but the shared weight is [D, %d, H] (gcn.py:167, 301)"
+                                   % (l, Tin, self.W.weight.shape[1]))
+            Wk = self.W.weight.reshape(D * Tin, H)                                                # W3[d,t,h] flattened over (d,t), gcn.py:301
+            xf = x.reshape(N, Tin)
+            xt = xf[tok]
+            plain = l >= max_depth                                                                # gcn.py:323-324, 355-356, 371-374
+            agg = torch.zeros((N, H), dtype=torch.float32, device=dev)
+            for edges, shift, on in ((fwd_e, 0, True), (rev_e, constant.DEPREL_FORWARD_BOUND, not directed)):
+                if not on or tok.numel() == 0:
+                    continue
+                e = self.deprel_emb(deprel_tok + shift)
+                keep_prop = opt.get('deprel_keep_prop', 1.0)
+                if self.training and keep_prop < 1.0:                                             # maybe_forget_deprels, gcn.py:451-470
+                    kept = torch.empty((tok.numel(), 1), device=dev).bernoulli_(keep_prop) == 1
+                    e = torch.where(kept, e, torch.ones_like(e))
+                if plain:
+                    e = torch.ones_like(e)
+                y = torch.mm((e.unsqueeze(2) * xt.unsqueeze(1)).reshape(-1, D * Tin), Wk) + torch.mm(e, b3)     # gcn.py:408-414
+                w = edges.to(torch.float32)
+                edge_keep = opt.get('edge_keep_prob', 1.0)
+                if self.training and edge_keep < 1.0:                                             # maybe_drop_edges, gcn.py:436-449
+                    w = w * torch.empty_like(w).bernoulli_(edge_keep)
+                agg.index_add_(0, rows, y[pos[cols]] * w.unsqueeze(1))                           # gcn.py:331, 362
+            if self_loop:                                                                         # gcn.py:366-385, 417-434
+                se = torch.ones((D,), device=dev) if plain else self.deprel_emb.weight[constant.SELF_LOOP_INDEX]
+                agg = agg + torch.mm(xf, torch.mm(se.unsqueeze(0), self.W.weight.reshape(D, Tin * H)).reshape(Tin, H)) + torch.mv(b3.t(), se)
+            x = torch.relu(agg / denom).view(B, T, H)                                            # gcn.py:390-392
+            if l < self.layers - 1:
+                x = self.gcn_drop(x)                                                              # gcn.py:393
+        return x, trees.pool_mask
+
     def forward(self, adj, inputs):
         if self.opt['dataset'] == 'tacred':
             words, masks, pos, ner, deprel, head, subj_pos, obj_pos = inputs
@@ -502,6 +569,8 @@ class GCN(nn.Module):
 
         if self.adj_type == 'diagonal_deprel':
             return self._forward_diagonal(adj, gcn_inputs, deprel)
+        if self.adj_type == 'full_deprel':
+            return self._forward_full(adj, gcn_inputs, deprel)
         trees = adj if isinstance(adj, PrunedTrees) else adj_to_csr(adj, want_label=False)   # gcn.py:260-262
         no_adj = bool(self.opt.get('no_adj', False))                                           # gcn.py:264-265
         x = gcn_inputs

@@ -207,3 +207,85 @@ def diag_backward(adj, x, deprel, Wp, bp, E, layers, gy, drop_masks=None, drop_p
     dbp = g.reshape(-1, Wp.shape[0]).sum(0).astype(np.float32)
     dx = np.matmul(g, Wp).astype(np.float32)
     return dx, dWp, dbp, dE.astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------------------
+# adj_type == 'full_deprel' (SURVEY.md 8f row N3): reference model/gcn.py:156-167 (one Linear reused by every layer),
+# 296-388 (layer body), 400-434 (traverse_deprel / traverse_self_loop).  Eval-mode semantics: edge dropout
+# (maybe_drop_edges, 436-449) and relation forgetting (maybe_forget_deprels, 451-470) are training-time RNG.
+#   trav(x, e)[n] = sum_d e[n,d] * (x[n] @ W3[d] + b3[d]),   W3 = W.weight.reshape(D, Tin, H), b3 = W.bias.reshape(D, H)
+#   z = F trav(x, E[deprel]) + [not directed] R trav(x, E[deprel+42]) + [self_loop] trav(x, E[84]);  out = relu(z / denom)
+#   layers l >= deprel_max_depth use all-ones relation vectors (gcn.py:323-324, 355-356, 371-374)
+# ----------------------------------------------------------------------------------------------
+def _full_setup(adj, deprel, W, b, E, D, layer, max_depth, Tin):
+    F = ((adj > 0) & (adj < DEPREL_FORWARD_BOUND)).astype(np.float32)
+    R = ((adj > DEPREL_FORWARD_BOUND) & (adj < DEPREL_REVERSE_BOUND)).astype(np.float32)
+    W3 = np.asarray(W, np.float32).reshape(D, Tin, -1)                 # gcn.py:301 (a reinterpretation, not a transpose)
+    b3 = np.asarray(b, np.float32).reshape(D, -1)                      # gcn.py:303
+    E = np.asarray(E, np.float32)
+    plain = layer >= max_depth
+    ones = np.ones(deprel.shape + (D,), np.float32)
+    fe = ones if plain else E[deprel]
+    re = ones if plain else E[deprel + DEPREL_FORWARD_BOUND]
+    se = np.ones((D,), np.float32) if plain else E[SELF_LOOP_INDEX]
+    return F, R, W3, b3, fe, re, se, plain
+
+
+def _trav(x, e, W3, b3):
+    return np.einsum("bnd,bnt,dth->bnh", e, x, W3, optimize=True) + np.matmul(e, b3)          # gcn.py:408-414
+
+
+def full_forward(adj, x, deprel, W, b, E, layers, max_depth=2, directed=False, self_loop=True, return_saved=False):
+    _, denom, mask = adjacency_prep(adj)
+    D = np.asarray(E).shape[1]
+    h = np.asarray(x, np.float32)
+    saved = []
+    for l in range(layers):
+        F, R, W3, b3, fe, re, se, _ = _full_setup(adj, deprel, W, b, E, D, l, max_depth, h.shape[-1])
+        z = np.matmul(F, _trav(h, fe, W3, b3))
+        if not directed:
+            z = z + np.matmul(R, _trav(h, re, W3, b3))
+        if self_loop:
+            z = z + np.matmul(h, np.einsum("d,dth->th", se, W3)) + se @ b3                    # gcn.py:426-433
+        g = np.maximum(z / denom, 0.0).astype(np.float32)
+        saved.append((h, g))
+        h = g
+    return (h, mask, saved) if return_saved else (h, mask)
+
+
+def full_backward(adj, x, deprel, W, b, E, layers, gy, max_depth=2, directed=False, self_loop=True):
+    """returns (dx, dW, db, dE) with dW/db in the nn.Linear layout and dE[0] = 0 (padding_idx)."""
+    _, denom, _ = adjacency_prep(adj)
+    D = np.asarray(E).shape[1]
+    _, _, saved = full_forward(adj, x, deprel, W, b, E, layers, max_depth, directed, self_loop, True)
+    dW3 = np.zeros((D, saved[0][0].shape[-1], saved[0][1].shape[-1]), np.float64)
+    db3 = np.zeros((D, dW3.shape[2]), np.float64)
+    dE = np.zeros(np.asarray(E).shape, np.float64)
+    g = np.asarray(gy, np.float32)
+    for l in reversed(range(layers)):
+        h, out = saved[l]
+        F, R, W3, b3, fe, re, se, plain = _full_setup(adj, deprel, W, b, E, D, l, max_depth, h.shape[-1])
+        dz = g * (out > 0) / denom
+        dh = np.zeros_like(h)
+        for A, e, ids in ((F, fe, deprel), (None if directed else R, re, deprel + DEPREL_FORWARD_BOUND)):
+            if A is None:
+                continue
+            dy = np.matmul(np.transpose(A, (0, 2, 1)), dz)
+            dh += np.einsum("bnh,bnd,dth->bnt", dy, e, W3, optimize=True)
+            dW3 += np.einsum("bnd,bnt,bnh->dth", e, h, dy, optimize=True)
+            db3 += np.einsum("bnd,bnh->dh", e, dy)
+            if not plain:
+                de = np.einsum("bnh,bnt,dth->bnd", dy, h, W3, optimize=True) + np.matmul(dy, b3.T)
+                np.add.at(dE, ids, de.astype(np.float64))
+        if self_loop:
+            Wsl = np.einsum("d,dth->th", se, W3)
+            dh += np.matmul(dz, Wsl.T)
+            dWsl = np.einsum("bnt,bnh->th", h, dz)
+            dbsl = dz.reshape(-1, dz.shape[-1]).sum(0)
+            dW3 += se[:, None, None] * dWsl[None]
+            db3 += se[:, None] * dbsl[None]
+            if not plain:
+                dE[SELF_LOOP_INDEX] += np.einsum("th,dth->d", dWsl, W3) + b3 @ dbsl
+        g = dh.astype(np.float32)
+    dE[0] = 0.0
+    return g, dW3.reshape(np.asarray(W).shape).astype(np.float32), db3.reshape(-1).astype(np.float32), dE.astype(np.float32)

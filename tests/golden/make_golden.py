@@ -237,6 +237,50 @@ def gen_diag():
 
 
 # ------------------------------------------------------------------------------------------------
+def gen_full():
+    """adj_type='full_deprel' (gcn.py:156-167, 296-388, 400-434) isolated behind the reference's GCN.forward, eval mode
+    (edge dropout and relation forgetting are training-time RNG).  in_dim == mem_dim, as the variant needs for > 1 layer."""
+    seed, B, T, hidden, D, K = 170, 4, 36, 24, 6, 1
+    batch = synthetic.random_tree_batch(seed, B, T, "tacred")
+    adj, _, status = ref_adj(batch["head"], batch["subj_pos"], batch["obj_pos"], batch["deprel"], batch["lens"], T, K)
+    assert (status == 0).all()
+    rng = np.random.RandomState(seed + 1)
+    E = rng.uniform(-1, 1, size=(85, D)).astype(np.float32)
+    E[0] = 0.0
+    W = (rng.uniform(-1, 1, size=(D * hidden, hidden)) / np.sqrt(hidden)).astype(np.float32)
+    b = (rng.uniform(-1, 1, size=(D * hidden,)) / np.sqrt(hidden)).astype(np.float32)
+    x = synthetic.normal(seed + 3, (B, T, hidden))
+    gy = synthetic.normal(seed + 4, (B, T, hidden))
+    out = dict(B=np.int64(B), T=np.int64(T), hidden=np.int64(hidden), D=np.int64(D), prune_k=np.int64(K), lens=batch["lens"],
+               head=batch["head"], deprel=batch["deprel"], subj_pos=batch["subj_pos"], obj_pos=batch["obj_pos"], coo=coo(adj),
+               x=x, gy=gy, E=E, W=W, b=b)
+    cases = [dict(layers=2, deprel_max_depth=2, deprel_directed=False, deprel_self_loop=True),
+             dict(layers=2, deprel_max_depth=1, deprel_directed=False, deprel_self_loop=True),
+             dict(layers=1, deprel_max_depth=2, deprel_directed=True, deprel_self_loop=True),
+             dict(layers=3, deprel_max_depth=0, deprel_directed=False, deprel_self_loop=False)]
+    out["cases"] = np.array(json.dumps(cases))
+    t = lambda a: torch.from_numpy(a)  # noqa: E731
+    for ci, c in enumerate(cases):
+        opt = dict(ref_opt(hidden, hidden, c["layers"], K), adj_type="full_deprel", deprel_emb_dim=D, deprel_max_depth=c["deprel_max_depth"],
+                   deprel_directed=c["deprel_directed"], deprel_self_loop=c["deprel_self_loop"])
+        demb = torch.nn.Embedding(85, D, padding_idx=0)
+        gcn = GCN(opt, (None, None, None, demb), hidden, c["layers"])
+        with torch.no_grad():
+            demb.weight.copy_(t(E))
+            gcn.W.weight.copy_(t(W))
+            gcn.W.bias.copy_(t(b))
+        gcn.eval()
+        xt = t(x.copy()).requires_grad_()
+        inputs = (xt, t(batch["masks"]), None, None, t(batch["deprel"]), t(batch["head"]), t(batch["subj_pos"]), t(batch["obj_pos"]))
+        h, mask = gcn(t(adj), inputs)
+        h.backward(t(gy))
+        out["h%d" % ci], out["mask%d" % ci] = h.detach().numpy(), mask.numpy()
+        out["dx%d" % ci], out["dW%d" % ci], out["db%d" % ci] = xt.grad.numpy(), gcn.W.weight.grad.numpy(), gcn.W.bias.grad.numpy()
+        out["dE%d" % ci] = demb.weight.grad.numpy() if demb.weight.grad is not None else np.zeros_like(E)
+    save("layers_full_deprel.npz", **out)
+
+
+# ------------------------------------------------------------------------------------------------
 def gen_end_to_end():
     """GCNClassifier logits for 10 sample sentences, eval mode, seeded weights (GCN and C-GCN)."""
     arr, sents = tacred_sample_arrays()
@@ -283,12 +327,14 @@ def gen_end_to_end():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["trees", "layers", "diag", "e2e"]
+    which = sys.argv[1:] or ["trees", "layers", "diag", "full", "e2e"]
     if "trees" in which:
         gen_trees()
     if "layers" in which:
         gen_layers()
     if "diag" in which:
         gen_diag()
+    if "full" in which:
+        gen_full()
     if "e2e" in which:
         gen_end_to_end()

@@ -75,5 +75,8 @@ def test_host_mirror_keeps_reference_surface():
         assert k in keys, k
     assert m.gcn_model.gcn.W[0].weight.shape == (16, 8) and m.gcn_model.deprel_emb.weight.shape == (85, 1)
     assert float(m.conv_l2()) > 0
-    with pytest.raises(NotImplementedError):
-        gcn.GCNClassifier(dict(opt, adj_type="full_deprel"))
+    with pytest.raises(ValueError):               # gcn.py:388: 'Adjacency aggregation type not supported.'
+        gcn.GCNClassifier(dict(opt, adj_type="concat_deprel"))
+    full = gcn.GCNClassifier(dict(opt, adj_type="full_deprel", deprel_emb_dim=5))
+    assert tuple(full.state_dict()["gcn_model.gcn.W.weight"].shape) == (5 * opt["hidden_dim"], full.gcn_model.gcn.in_dim)
+    assert tuple(full.state_dict()["gcn_model.deprel_emb.weight"].shape) == (85, 5)

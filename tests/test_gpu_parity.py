@@ -738,6 +738,105 @@ def test_diag_deprel_classifier_end_to_end_golden(api, dev):
 
 
 # ---------------------------------------------------------------------------------------------------
+# N3: adj_type == 'full_deprel' (library GEMMs for the bilinear contraction, the device pruner's CSR for the edges)
+# ---------------------------------------------------------------------------------------------------
+def _full_gcn(api, dev, D, hidden, layers, **kw):
+    gcn, _ = api
+    opt = dict(emb_dim=hidden, pos_dim=0, ner_dim=0, input_dropout=0.0, gcn_dropout=0.0, emb_dropout=0.0, rnn=False, cuda=True,
+               dataset="tacred", prune_k=1, hidden_dim=hidden, num_layers=layers, adj_type="full_deprel", deprel_emb_dim=D, **kw)
+    demb = torch.nn.Embedding(85, D, padding_idx=0)
+    return gcn.GCN(opt, (None, None, None, demb), hidden, layers), demb
+
+
+def _run_full(api, dev, g, c, trees_from="pruner"):
+    gcn, tree = api
+    B, T, hidden, D = int(g["B"]), int(g["T"]), int(g["hidden"]), int(g["D"])
+    net, demb = _full_gcn(api, dev, D, hidden, c["layers"], deprel_max_depth=c["deprel_max_depth"], deprel_directed=c["deprel_directed"],
+                          deprel_self_loop=c["deprel_self_loop"])
+    with torch.no_grad():
+        demb.weight.copy_(torch.from_numpy(g["E"]))
+        net.W.weight.copy_(torch.from_numpy(g["W"]))
+        net.W.bias.copy_(torch.from_numpy(g["b"]))
+    net.to(dev).eval()
+    demb.to(dev)
+    x = _t(g["x"], dev).requires_grad_()
+    masks = np.arange(T)[None, :] >= g["lens"][:, None]
+    inputs = (x, _t(masks, dev), None, None, _t(g["deprel"], dev), _t(g["head"], dev), _t(g["subj_pos"], dev), _t(g["obj_pos"], dev))
+    if trees_from == "pruner":
+        adj = tree.prune_to_csr(inputs[5], inputs[6], inputs[7], inputs[4], int(g["prune_k"]), masks=inputs[1], want_label=True)
+    else:
+        adj = _t(g["adj"], dev)                                       # the reference's own dense labelled matrix
+    h, mask = net(adj, inputs)
+    h.backward(_t(g["gy"], dev))
+    f = lambda t: t.detach().cpu().numpy()  # noqa: E731
+    dE = f(demb.weight.grad) if demb.weight.grad is not None else np.zeros_like(g["E"])
+    return dict(h=f(h), mask=f(mask), dx=f(x.grad), dW=f(net.W.weight.grad), db=f(net.W.bias.grad), dE=dE)
+
+
+def test_full_deprel_golden(api, dev):
+    """fp32 against outputs and gradients recorded from the reference's GCN(adj_type='full_deprel'), four option sets."""
+    import json
+    g = dict(load_golden("layers_full_deprel.npz"))
+    g["adj"] = dense_from_coo(g["coo"], int(g["B"]), int(g["T"]))
+    for ci, c in enumerate(json.loads(str(g["cases"]))):
+        for src in ("pruner", "dense"):
+            r = _run_full(api, dev, g, c, src)
+            np.testing.assert_array_equal(r["mask"], g["mask%d" % ci])
+            assert max_rel(r["h"], g["h%d" % ci]) <= 1e-4, (ci, src)
+            for key in ("dx", "dW", "db", "dE"):
+                ref = g["%s%d" % (key, ci)]
+                assert np.abs(r[key] - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), (key, ci, src)
+
+
+def test_full_deprel_vs_oracle_and_training_noise(api, dev):
+    from gcn_over_pruned_trees_amd.utils import synthetic
+    from oracle import gcn_ref, prune_ref
+    gcn, tree = api
+    B, T, hidden, D, K, L = 12, 70, 64, 16, 1, 2
+    tb = synthetic.random_tree_batch(91, B, T, "tacred")
+    adj = prune_ref.batch_adj(tb["head"], tb["subj_pos"], tb["obj_pos"], tb["deprel"], tb["lens"], K)["adj"]
+    rng = np.random.RandomState(4)
+    g = dict(tb, B=B, T=T, hidden=hidden, D=D, prune_k=K, x=synthetic.normal(5, (B, T, hidden)), gy=synthetic.normal(6, (B, T, hidden)),
+             E=rng.uniform(-1, 1, size=(85, D)).astype(np.float32),
+             W=(rng.uniform(-1, 1, size=(D * hidden, hidden)) / np.sqrt(hidden * D)).astype(np.float32),
+             b=(rng.uniform(-1, 1, size=(D * hidden,)) / np.sqrt(hidden)).astype(np.float32))
+    c = dict(layers=L, deprel_max_depth=1, deprel_directed=False, deprel_self_loop=True)
+    r = _run_full(api, dev, g, c)
+    kw = dict(max_depth=1, directed=False, self_loop=True)
+    h, mask = gcn_ref.full_forward(adj, g["x"], g["deprel"], g["W"], g["b"], g["E"], L, **kw)
+    np.testing.assert_array_equal(r["mask"], mask)
+    assert max_rel(r["h"], h) <= 1e-4
+    dx, dW, db, dE = gcn_ref.full_backward(adj, g["x"], g["deprel"], g["W"], g["b"], g["E"], L, g["gy"], **kw)
+    dEg = r["dE"].copy()
+    dEg[0] = 0
+    for got, want, key in ((r["dx"], dx, "dx"), (r["dW"], dW, "dW"), (r["db"], db, "db"), (dEg, dE, "dE")):
+        assert max_rel(got, want) <= 5e-4, key
+    # training mode with edge dropout and relation forgetting: stochastic, finite, and back to deterministic in eval
+    net, demb = _full_gcn(api, dev, D, hidden, L, deprel_max_depth=2, deprel_directed=False, deprel_self_loop=True, edge_keep_prob=0.7,
+                          deprel_keep_prop=0.5)
+    net.to(dev).train()
+    masks = np.arange(T)[None, :] >= tb["lens"][:, None]
+    inputs = (_t(g["x"], dev), _t(masks, dev), None, None, _t(tb["deprel"], dev), _t(tb["head"], dev), _t(tb["subj_pos"], dev), _t(tb["obj_pos"], dev))
+    trees = tree.prune_to_csr(inputs[5], inputs[6], inputs[7], inputs[4], K, masks=inputs[1], want_label=True)
+    a, _ = net(trees, inputs)
+    b2, _ = net(trees, inputs)
+    assert torch.isfinite(a).all() and not torch.equal(a, b2)
+    net.eval()
+    a, _ = net(trees, inputs)
+    b2, _ = net(trees, inputs)
+    assert torch.allclose(a, b2, rtol=1e-5, atol=1e-6)          # (index_add_ sums with atomics: order, not value, varies)
+    with pytest.raises(TypeError):               # as in the reference: the single nn.Linear is not iterable (gcn.py:180-184)
+        net.conv_l2()
+    # in_dim != mem_dim: one layer works, the second fails as the reference's einsum does (SURVEY 2)
+    gcn_mod, _ = api
+    opt = dict(net.opt, emb_dim=hidden + 8)
+    bad = gcn_mod.GCN(opt, (None, None, None, demb), hidden, 2).to(dev).eval()
+    wide = (torch.randn(B, T, hidden + 8, device=dev),) + inputs[1:]
+    with pytest.raises(RuntimeError):
+        bad(trees, wide)
+
+
+# ---------------------------------------------------------------------------------------------------
 # drop-in boundary: the reference's module surface
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("tag", ["gcn", "cgcn"])

@@ -140,3 +140,20 @@ def test_diag_deprel_oracle_matches_reference_golden():
     for got, key in ((dx, "dx"), (dWp, "dWp"), (dbp, "dbp"), (dE, "dE")):
         np.testing.assert_allclose(got, g[key], rtol=2e-4, atol=2e-5, err_msg=key)
     assert (g["dE"][0] == 0).all() and np.abs(g["dE"]).max() > 0
+
+
+def test_full_deprel_oracle_matches_reference_golden():
+    """N3: numpy restatement of the full_deprel layers vs outputs/gradients recorded from the reference (4 option sets)."""
+    import json
+    g = load_golden("layers_full_deprel.npz")
+    B, T = int(g["B"]), int(g["T"])
+    adj = dense_from_coo(g["coo"], B, T)
+    for ci, c in enumerate(json.loads(str(g["cases"]))):
+        kw = dict(max_depth=c["deprel_max_depth"], directed=c["deprel_directed"], self_loop=c["deprel_self_loop"])
+        h, mask = gcn_ref.full_forward(adj, g["x"], g["deprel"], g["W"], g["b"], g["E"], c["layers"], **kw)
+        np.testing.assert_allclose(h, g["h%d" % ci], rtol=1e-4, atol=1e-5, err_msg="h, case %d" % ci)
+        assert (mask == g["mask%d" % ci]).all()
+        got = gcn_ref.full_backward(adj, g["x"], g["deprel"], g["W"], g["b"], g["E"], c["layers"], g["gy"], **kw)
+        for a, key in zip(got, ("dx", "dW", "db", "dE")):
+            ref = g["%s%d" % (key, ci)]
+            assert np.abs(a - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), (key, ci)

@@ -162,7 +162,7 @@ class Stack(object):
         H, Din = self.W[l].shape
         p = self.args.drop if l == 0 else 0.0
         self._lib.check(self.L.gcnpt_layer_fwd(self._lib.stream(), P(src), self.act, P(self.wf[l]), P(self.b[l]), P(tr.row_ptr), P(tr.col_idx),
-                                               P(tr.ell), None, self.B, self.T, Din, H, P(dst), self.act, self.compute, p, 0x5eed, P(self.sf[l])))
+                                               P(tr.ell), None, self.B, self.T, Din, H, P(dst), self.act, self.compute, p, 0x5eed, P(self.sf[l]), None))
 
     def _dw_db(self, l, k):
         g = self.grads(k)
@@ -202,7 +202,7 @@ class Stack(object):
         self._lib.check(self.L.gcnpt_stack_fwd(
             self._lib.stream(), L, P(self.x), self.act, A(self.wf), A(self.b), P(tr.row_ptr), P(tr.col_idx), P(tr.ell), None,
             self.B, self.T, self.Din, self.H, A([self.h1, self.h2]), self.act, (ctypes.c_float * L)(self.args.drop, 0.0),
-            (ctypes.c_uint64 * L)(0x5eed, 0), A(self.hf), A([g[0], g[2]]), A([g[1], g[3]])))
+            (ctypes.c_uint64 * L)(0x5eed, 0), A(self.hf), A([g[0], g[2]]), A([g[1], g[3]]), None))
 
     def stack_bwd(self, k=0):
         P, A, tr, L = self._lib.ptr, self._lib.ptr_array, self.trees, 2

@@ -24,18 +24,18 @@ SIGNATURES = {
     "gcnpt_pack_weights": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "gcnpt_pack_weights_multi": (_i, [_p, _i, _p, _p, _p, _i, _p, _p]),
     "gcnpt_frag_bytes": (_sz, [_i, _i, _i]),
-    "gcnpt_layer_fwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _f, _u64, _p]),
+    "gcnpt_layer_fwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _f, _u64, _p, _p]),
     "gcnpt_layer_bwd_data": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _f, _p, _p, _p]),
     "gcnpt_layer_bwd_weight": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _i]),
     "gcnpt_layer_bwd_weight_multi": (_i, [_p, _i, _p, _p, _i, _i, _p, _p, _p, _p, _i]),
     "gcnpt_pool3_fwd": (_i, [_p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "gcnpt_pool3_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i]),
-    "gcnpt_diag_layer_fwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p, _f, _u64]),
+    "gcnpt_diag_layer_fwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p, _f, _u64, _p]),
     "gcnpt_diag_layer_bwd": (_i, [_p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _f]),
     "gcnpt_gather_trees": (_i, [_p] * 11 + [_i, _i, _i, _p, _i, _i, _i] + [_p] * 9),
     "gcnpt_stack_supported": (_i, [_i, _i, _i, _i, _i]),
     "gcnpt_stack_frag_bytes": (_sz, [_i, _i, _i]),
-    "gcnpt_stack_fwd": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p]),
+    "gcnpt_stack_fwd": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p]),
     "gcnpt_stack_bwd": (_i, [_p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p]),
     "gcnpt_stack_bwd_weight": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _p]),
 }
@@ -62,8 +62,8 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)          # AttributeError here = header and library disagree
             fn.restype, fn.argtypes = res, args
-        if handle.gcnpt_abi_version() != 1:
-            raise ImportError("libgcnpt.so has ABI version %d, this binding needs 1" % handle.gcnpt_abi_version())
+        if handle.gcnpt_abi_version() != 2:
+            raise ImportError("libgcnpt.so has ABI version %d, this binding needs 2" % handle.gcnpt_abi_version())
         _lib = handle
     return _lib
 

@@ -36,6 +36,7 @@ struct DiagParams {
     float scale;
     unsigned drop_thresh16;
     uint64_t seed;
+    const uint64_t* seed_dev;  // NULL or a device word added to seed
 };
 
 template <typename T, int CPL> struct dgio;
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(DG_THREADS) void diag_fwd_kernel(const DiagParams p
     const T* h = static_cast<const T*>(p.h);
     T* out = static_cast<T*>(p.out);
     const int H = p.H;
+    const uint64_t seed = p.seed + (p.seed_dev ? *p.seed_dev : 0ull);
     for (int rr = wave; rr < DG_ROWS; rr += DG_WAVES) {
         const int r = blockIdx.x * DG_ROWS + rr;
         if (r >= p.N) break;
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(DG_THREADS) void diag_fwd_kernel(const DiagParams p
                 x = x > 0.0f ? x : 0.0f;
                 if (p.scale != 1.0f) {                                                  // gcn.py:393
                     const unsigned col = (unsigned)(cc + j);
-                    x = drop_keep(drop_hash(p.seed, (unsigned)r, col >> 1), col & 1u, p.drop_thresh16) ? x * p.scale : 0.0f;
+                    x = drop_keep(drop_hash(seed, (unsigned)r, col >> 1), col & 1u, p.drop_thresh16) ? x * p.scale : 0.0f;
                 }
                 acc[j] = x;
             }
@@ -238,7 +240,7 @@ using namespace gcnpt;
 
 extern "C" int gcnpt_diag_layer_fwd(void* stream, const void* h, int dtype, const float* E, const int64_t* deprel,
                                     const int32_t* row_ptr, const int32_t* col_idx, const int32_t* label, int B, int T, int H,
-                                    void* out, float drop_p, uint64_t seed) {
+                                    void* out, float drop_p, uint64_t seed, const uint64_t* seed_dev) {
     GCNPT_REQUIRE(h && E && deprel && row_ptr && col_idx && label && out, "diag_layer_fwd: null pointer");
     GCNPT_REQUIRE(B > 0 && T > 0 && H > 0 && dtype_ok(dtype), "diag_layer_fwd: bad argument");
     GCNPT_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "diag_layer_fwd: drop_p must be in [0,1)");
@@ -248,7 +250,7 @@ extern "C" int gcnpt_diag_layer_fwd(void* stream, const void* h, int dtype, cons
     p.N = B * T; p.T = T; p.H = H;
     p.scale = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
     p.drop_thresh16 = (unsigned)((double)drop_p * 65536.0);
-    p.seed = seed;
+    p.seed = seed; p.seed_dev = seed_dev;
     const bool vec = H % 4 == 0 && aligned16(h) && aligned16(out) && aligned16(E);
     return launch_diag<false>((hipStream_t)stream, p, dtype, vec);
 }

@@ -49,6 +49,7 @@ struct RowTileParams {
     float drop_p;           // fwd
     unsigned drop_thresh16;
     uint64_t seed;
+    const uint64_t* seed_dev;   // NULL, or a device word added to `seed` (a counter the caller advances between graph replays)
     unsigned long long* stamps;   // diagnostic builds only
     int knob;
 };
@@ -84,6 +85,8 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
     const uint4* wfrag = static_cast<const uint4*>(p.wfrag);
     const int n_tiles = ceil_div(p.NOUT, 16);
     const int ksteps = p.Kpad / KSTEP;
+    uint64_t seed_off = 0;                                  // scalar load, consumed in the epilogue
+    if (!BWD && p.seed_dev) seed_off = *p.seed_dev;
     GCNPT_STAMP_REAL(p.stamps);
     GCNPT_STAMP(p.stamps, 0);
 
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
                 if (!BWD && p.drop_p > 0.0f) {                            // gcn.py:393: one hash per column pair
 #pragma unroll
                     for (int h2 = 0; h2 < 2; ++h2) {
-                        const unsigned dh = drop_hash(p.seed, (unsigned)(r0 + row), (unsigned)(col0 >> 1) + h2);
+                        const unsigned dh = drop_hash(p.seed + seed_off, (unsigned)(r0 + row), (unsigned)(col0 >> 1) + h2);
                         v[2 * h2] = drop_keep(dh, 0u, p.drop_thresh16) ? v[2 * h2] * p.scale : 0.0f;
                         v[2 * h2 + 1] = drop_keep(dh, 1u, p.drop_thresh16) ? v[2 * h2 + 1] * p.scale : 0.0f;
                     }
@@ -544,7 +547,7 @@ static int dispatch_rowtile(hipStream_t s, const RowTileParams& p, int in_dtype,
 extern "C" int gcnpt_layer_fwd(void* stream, const void* h, int h_dtype, const void* w_fwd, const float* bias,
                                const int32_t* row_ptr, const int32_t* col_idx, const int32_t* ell, const int32_t* deg_ell,
                                int B, int T, int Din, int H, void* out, int out_dtype, int compute_dtype, float drop_p,
-                               uint64_t seed, void* s_frag) {
+                               uint64_t seed, void* s_frag, const uint64_t* seed_dev) {
     GCNPT_REQUIRE(h && w_fwd && bias && row_ptr && col_idx && ell && out, "layer_fwd: null pointer");
     GCNPT_REQUIRE(B > 0 && T > 0 && Din > 0 && H > 0, "layer_fwd: sizes must be positive");
     GCNPT_REQUIRE(dtype_ok(h_dtype) && dtype_ok(out_dtype) && dtype_ok(compute_dtype), "layer_fwd: bad dtype");
@@ -560,7 +563,7 @@ extern "C" int gcnpt_layer_fwd(void* stream, const void* h, int h_dtype, const v
     p.vec_out = ((H * esize(out_dtype)) % 16 == 0) && aligned16(out);
     p.drop_p = drop_p; p.scale = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
     p.drop_thresh16 = (unsigned)((double)drop_p * 65536.0);
-    p.seed = seed;
+    p.seed = seed; p.seed_dev = seed_dev;
     return dispatch_rowtile<false>((hipStream_t)stream, p, h_dtype, out_dtype, compute_dtype);
 }
 

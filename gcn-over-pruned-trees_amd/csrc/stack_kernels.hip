@@ -39,6 +39,7 @@ struct StackFwdParams {
     float drop_p[ST_MAXL], drop_scale[ST_MAXL];
     unsigned thresh16[ST_MAXL];
     uint64_t seed[ST_MAXL];
+    const uint64_t* seed_dev;   // NULL or a device word added to every seed
     int vec_h, vec_out;
     unsigned long long* stamps;   // diagnostic builds only
 };
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void stack_fwd_kernel(const StackFwd
             if (p.drop_p[l] > 0.0f) {                                       // gcn.py:393
 #pragma unroll
                 for (int h2 = 0; h2 < 4; ++h2) {
-                    const unsigned dh = drop_hash(p.seed[l], (unsigned)(row0 + row), (unsigned)(k0 >> 1) + h2);
+                    const unsigned dh = drop_hash(p.seed[l] + (p.seed_dev ? *p.seed_dev : 0ull), (unsigned)(row0 + row), (unsigned)(k0 >> 1) + h2);
                     o[2 * h2] = drop_keep(dh, 0u, p.thresh16[l]) ? o[2 * h2] * p.drop_scale[l] : 0.0f;
                     o[2 * h2 + 1] = drop_keep(dh, 1u, p.thresh16[l]) ? o[2 * h2 + 1] * p.drop_scale[l] : 0.0f;
                 }
@@ -527,13 +528,13 @@ extern "C" int gcnpt_stack_fwd(void* stream, int n_layers, const void* x, int x_
                                const float* const* bias, const int32_t* row_ptr, const int32_t* col_idx, const int32_t* ell,
                                const int32_t* deg_ell, int B, int T, int Din, int H, void* const* h_out, int out_dtype,
                                const float* drop_p, const uint64_t* seed, void* const* h_frag, float* const* zero_dW,
-                               float* const* zero_db) {
+                               float* const* zero_db, const uint64_t* seed_dev) {
     GCNPT_REQUIRE(x && w_fwd && bias && row_ptr && col_idx && ell && h_out && drop_p && seed, "stack_fwd: null pointer");
     GCNPT_REQUIRE(B > 0 && dtype_ok(x_dtype) && dtype_ok(out_dtype), "stack_fwd: bad argument");
     if (int rc = stack_check("stack_fwd", T, Din, H, n_layers)) return rc;
     StackFwdParams p{};
     p.stamps = static_cast<unsigned long long*>(g_debug_stamps);
-    p.L = n_layers; p.B = B; p.T = T; p.Din = Din; p.H = H; p.x = x;
+    p.L = n_layers; p.B = B; p.T = T; p.Din = Din; p.H = H; p.x = x; p.seed_dev = seed_dev;
     p.g_ell = ell; p.d_ell = deg_ell ? deg_ell : ell; p.row_ptr = row_ptr; p.col_idx = col_idx;
     p.vec_h = (H % 8 == 0);
     for (int l = 0; l < n_layers; ++l) {

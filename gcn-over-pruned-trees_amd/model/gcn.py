@@ -18,7 +18,9 @@ the output MLP stay ordinary PyTorch-ROCm modules, as in the reference.
 New optional `opt` keys (defaults reproduce the reference): `gcn_dtype` = 'fp32' | 'bf16' (MFMA operand /
 activation storage type inside the layer stack), `gcn_fused` = False (bf16 only: run the whole stack with the
 sentence-resident one-launch-per-direction kernels when the shape fits; slower than one launch per layer at B=50), `gcn_check_trees` = True (synchronise once per forward to
-raise on malformed trees the way the reference does; False keeps the step free of host syncs).
+raise on malformed trees the way the reference does; False keeps the step free of host syncs), `gcn_graph_rng` = False
+(True: dropout seeds that survive hipGraph capture -- with `gcn_check_trees=False` a whole training step of the no-LSTM
+model can be captured with torch.cuda.graph and replayed, see tests/test_gpu_parity.py::test_training_step_graph_capture).
 """
 import ctypes
 
@@ -38,7 +40,7 @@ class _GCNLayerFn(torch.autograd.Function):
     """out = dropout(relu((((A+I) h) W^T + 2 b) / (deg + 1)))  -- model/gcn.py:269-271, 390-393."""
 
     @staticmethod
-    def forward(ctx, h, weight, bias, trees, drop_p, seed, compute, out_dtype, no_adj):
+    def forward(ctx, h, weight, bias, trees, drop_p, seed, compute, out_dtype, no_adj, seed_dev=None):
         B, T, Din = h.shape
         H = weight.shape[0]
         if weight.shape[1] != Din:
@@ -60,7 +62,7 @@ class _GCNLayerFn(torch.autograd.Function):
         s_frag = torch.empty((L.gcnpt_frag_bytes(B * T, Din, compute),), dtype=torch.uint8, device=h.device) if want_wgrad else None
         _lib.check(L.gcnpt_layer_fwd(st, _lib.ptr(h), _lib.dtype_code(h.dtype), _lib.ptr(w_fwd), _lib.ptr(b32),
                                      _lib.ptr(trees.row_ptr), _lib.ptr(trees.col_idx), _lib.ptr(g_ell), _lib.ptr(trees.ell), B, T, Din, H,
-                                     _lib.ptr(out), _lib.dtype_code(out_dtype), compute, float(drop_p), int(seed), _lib.ptr(s_frag)))
+                                     _lib.ptr(out), _lib.dtype_code(out_dtype), compute, float(drop_p), int(seed), _lib.ptr(s_frag), _lib.ptr(seed_dev)))
         ctx.save_for_backward(out, w_bwd, s_frag)
         ctx.h_dtype = h.dtype
         ctx.trees, ctx.no_adj, ctx.compute = trees, no_adj, compute
@@ -95,14 +97,15 @@ class _GCNLayerFn(torch.autograd.Function):
             _lib.check(L.gcnpt_layer_bwd_weight(st, _lib.ptr(z_frag), _lib.ptr(s_frag), B, T, Din, H, _lib.ptr(dW), _lib.ptr(db),
                                                 ctx.compute))
             dW, db = dW.to(ctx.param_dtypes[0]), db.to(ctx.param_dtypes[1])
-        return dh, dW, db, None, None, None, None, None, None
+        return dh, dW, db, None, None, None, None, None, None, None
 
 
-def gcn_layer(h, weight, bias, trees, drop_p=0.0, seed=0, compute_dtype=torch.float32, out_dtype=None, no_adj=False):
+def gcn_layer(h, weight, bias, trees, drop_p=0.0, seed=0, compute_dtype=torch.float32, out_dtype=None, no_adj=False, seed_dev=None):
     """
     Functional form of one iteration of the reference's layer loop.  h [B,T,Din] (float32 or bfloat16, CUDA),
     weight [H,Din], bias [H] (nn.Linear layout), trees: PrunedTrees.  compute_dtype float32 = exact fp32 MFMA,
-    bfloat16 = bf16 operands with fp32 accumulation.
+    bfloat16 = bf16 operands with fp32 accumulation.  seed_dev: optional int64 [1] CUDA tensor added to `seed` on the device
+    (advance it between replays of a captured graph to get fresh dropout masks).
     """
     if not isinstance(trees, PrunedTrees):
         raise TypeError("trees must be a PrunedTrees (see model.tree.prune_to_csr / adj_to_csr)")
@@ -113,7 +116,7 @@ def gcn_layer(h, weight, bias, trees, drop_p=0.0, seed=0, compute_dtype=torch.fl
     out_dtype = out_dtype or h.dtype
     if compute == _lib.F32:
         out_dtype = torch.float32
-    return _GCNLayerFn.apply(h, weight, bias, trees, float(drop_p), int(seed), compute, out_dtype, bool(no_adj))
+    return _GCNLayerFn.apply(h, weight, bias, trees, float(drop_p), int(seed), compute, out_dtype, bool(no_adj), seed_dev)
 
 
 class _GCNLayersFn(torch.autograd.Function):
@@ -151,7 +154,7 @@ class _GCNLayersFn(torch.autograd.Function):
             _lib.check(lib.gcnpt_layer_fwd(st, _lib.ptr(h), _lib.dtype_code(h.dtype), _lib.ptr(wf[l]), _lib.ptr(b32[l]),
                                            _lib.ptr(trees.row_ptr), _lib.ptr(trees.col_idx), _lib.ptr(g_ell), _lib.ptr(trees.ell), B, T, K, H,
                                            _lib.ptr(out), _lib.dtype_code(out.dtype), compute, float(cfg["drop_p"][l]), int(cfg["seed"][l]),
-                                           _lib.ptr(sf)))
+                                           _lib.ptr(sf), _lib.ptr(cfg.get("seed_dev"))))
             outs.append(out)
             s_frag.append(sf)
             h = out
@@ -200,7 +203,8 @@ class _GCNLayersFn(torch.autograd.Function):
         return (g if ctx.needs_input_grad[0] else None, None, None) + tuple(grads)
 
 
-def gcn_layers(x, weights, biases, trees, drop_p=None, seeds=None, compute_dtype=torch.float32, out_dtype=torch.float32, no_adj=False):
+def gcn_layers(x, weights, biases, trees, drop_p=None, seeds=None, compute_dtype=torch.float32, out_dtype=torch.float32, no_adj=False,
+               seed_dev=None):
     """
     The reference's whole layer loop (model/gcn.py:266-393) over the per-layer kernels.  x [B,T,Din] float32/bfloat16 CUDA;
     weights / biases: lists of the nn.Linear parameters (any widths that chain); drop_p[l]: dropout applied to the output of
@@ -215,7 +219,8 @@ def gcn_layers(x, weights, biases, trees, drop_p=None, seeds=None, compute_dtype
     if compute == _lib.F32:
         x, out_dtype = (x.float() if x.dtype != torch.float32 else x), torch.float32
     cfg = dict(drop_p=[float(p) for p in (drop_p or [0.0] * L)], seed=[int(s) for s in (seeds or [0] * L)], compute=compute,
-               mid_dtype=torch.float32 if compute == _lib.F32 else torch.bfloat16, out_dtype=out_dtype, no_adj=bool(no_adj))
+               mid_dtype=torch.float32 if compute == _lib.F32 else torch.bfloat16, out_dtype=out_dtype, no_adj=bool(no_adj),
+               seed_dev=seed_dev)
     params = [t for wb in zip(weights, biases) for t in wb]
     return _GCNLayersFn.apply(x, trees, cfg, *params)
 
@@ -248,7 +253,7 @@ class _GCNStackFn(torch.autograd.Function):
             st, L, _lib.ptr(x), _lib.dtype_code(x.dtype), _lib.ptr_array(wf), _lib.ptr_array(b32), _lib.ptr(trees.row_ptr),
             _lib.ptr(trees.col_idx), _lib.ptr(g_ell), _lib.ptr(trees.ell), B, T, Din, H, _lib.ptr_array(h_out),
             _lib.dtype_code(cfg["out_dtype"]), (ctypes.c_float * L)(*cfg["drop_p"]), (ctypes.c_uint64 * L)(*cfg["seed"]),
-            _lib.ptr_array(h_frag), None, None))
+            _lib.ptr_array(h_frag), None, None, _lib.ptr(cfg.get("seed_dev"))))
         ctx.save_for_backward(*h_out, *wb, *[f for f in h_frag if f is not None])
         ctx.trees, ctx.cfg, ctx.dims, ctx.shape, ctx.need_w = trees, cfg, dims, (B, T, Din, H, L), need_w
         ctx.x_dtype = x.dtype
@@ -294,7 +299,7 @@ def gcn_stack_supported(T, Din, H, n_layers, compute_dtype=torch.bfloat16):
     return bool(_lib.lib().gcnpt_stack_supported(int(T), int(Din), int(H), int(n_layers), _lib.dtype_code(compute_dtype)))
 
 
-def gcn_stack(x, weights, biases, trees, drop_p=None, seeds=None, out_dtype=torch.float32, no_adj=False):
+def gcn_stack(x, weights, biases, trees, drop_p=None, seeds=None, out_dtype=torch.float32, no_adj=False, seed_dev=None):
     """
     The reference's whole layer loop (model/gcn.py:266-393) as one op.  x [B,T,Din] float32/bfloat16 CUDA; weights /
     biases: lists of the nn.Linear parameters; drop_p[l]: dropout applied to the output of layer l (0 for the last).
@@ -305,7 +310,7 @@ def gcn_stack(x, weights, biases, trees, drop_p=None, seeds=None, out_dtype=torc
     _lib.require_gpu(x)
     L = len(weights)
     cfg = dict(drop_p=[float(p) for p in (drop_p or [0.0] * L)], seed=[int(s) for s in (seeds or [0] * L)],
-               out_dtype=out_dtype, no_adj=bool(no_adj))
+               out_dtype=out_dtype, no_adj=bool(no_adj), seed_dev=seed_dev)
     params = [t for wb in zip(weights, biases) for t in wb]
     return _GCNStackFn.apply(x, trees, cfg, *params)
 
@@ -441,6 +446,12 @@ class GCN(nn.Module):
         if kind not in ('fp32', 'bf16'):
             raise ValueError("gcn_dtype must be 'fp32' or 'bf16'")
         self.compute_dtype = torch.float32 if kind == 'fp32' else torch.bfloat16
+        # graph-safe dropout: a by-value seed is frozen into a captured hipGraph, so with opt['gcn_graph_rng'] the per-layer
+        # seeds are fixed at construction and a device counter (advanced by one captured op per forward) is added in the kernel
+        self.graph_rng = bool(opt.get('gcn_graph_rng', False))
+        if self.graph_rng:
+            self.register_buffer('_rng_step', torch.zeros(1, dtype=torch.int64), persistent=False)
+            self._base_seeds = [int(torch.randint(0, 2 ** 62, (1,)).item()) for _ in range(num_layers)]
 
     def conv_l2(self):
         # the reference's diagonal_deprel model has no W list, so its conv_l2() / get_gcn_parameters() raise AttributeError
@@ -469,6 +480,15 @@ class GCN(nn.Module):
         out, _ = nn.utils.rnn.pad_packed_sequence(out, batch_first=True)
         return out
 
+    def _dropout_plan(self):
+        """(p per layer, seed per layer, device seed word or None) for this forward -- gcn.py:393: every layer but the last."""
+        ps = [self.gcn_drop.p if (self.training and l < self.layers - 1) else 0.0 for l in range(self.layers)]
+        if self.graph_rng:
+            if any(p > 0 for p in ps):
+                self._rng_step.add_(1)                                # on the stream: part of a captured graph
+            return ps, [s if p > 0 else 0 for s, p in zip(self._base_seeds, ps)], self._rng_step
+        return ps, [int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0 for p in ps], None      # CPU generator: no GPU sync
+
     def _forward_diagonal(self, adj, gcn_inputs, deprel):
         """gcn.py:255-257, 272-294: Linear preprocessor (host BLAS), then the element-wise relation-scaled layers.
         no_adj has no effect on this variant in the reference either (it only zeroes the matrix the regular path uses)."""
@@ -478,10 +498,9 @@ class GCN(nn.Module):
         if table.requires_grad and not getattr(self, '_pad_hooked', False):
             table.register_hook(_zero_pad_row)
             self._pad_hooked = True
+        ps, seeds, seed_dev = self._dropout_plan()
         for l in range(self.layers):
-            p = self.gcn_drop.p if (self.training and l < self.layers - 1) else 0.0
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
-            x = diag_layer(x, table, deprel, trees, p, seed)
+            x = diag_layer(x, table, deprel, trees, ps[l], seeds[l], seed_dev)
         return x.float(), trees.pool_mask
 
     def _forward_full(self, adj, gcn_inputs, deprel):
@@ -575,14 +594,13 @@ class GCN(nn.Module):
         no_adj = bool(self.opt.get('no_adj', False))                                           # gcn.py:264-265
         x = gcn_inputs
         B, T, Din = x.shape
-        ps = [self.gcn_drop.p if (self.training and l < self.layers - 1) else 0.0 for l in range(self.layers)]   # gcn.py:393
-        seeds = [int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0 for p in ps]        # CPU generator: no GPU sync
+        ps, seeds, seed_dev = self._dropout_plan()
         Ws, bs = [lin.weight for lin in self.W], [lin.bias for lin in self.W]
         if (self.compute_dtype == torch.bfloat16 and self.opt.get('gcn_fused', False)
                 and gcn_stack_supported(T, Din, self.mem_dim, self.layers)):
             # whole stack in one launch per direction (sentence-resident kernels)
-            return gcn_stack(x, Ws, bs, trees, ps, seeds, torch.float32, no_adj), trees.pool_mask
-        x = gcn_layers(x, Ws, bs, trees, ps, seeds, self.compute_dtype, torch.float32, no_adj)
+            return gcn_stack(x, Ws, bs, trees, ps, seeds, torch.float32, no_adj, seed_dev), trees.pool_mask
+        x = gcn_layers(x, Ws, bs, trees, ps, seeds, self.compute_dtype, torch.float32, no_adj, seed_dev)
         return x, trees.pool_mask
 
 
@@ -596,7 +614,7 @@ class _DiagLayerFn(torch.autograd.Function):
     """One diagonal_deprel layer (csrc/diag_kernels.hip): reference model/gcn.py:272-294 + 390-393."""
 
     @staticmethod
-    def forward(ctx, h, emb, deprel, trees, drop_p, seed):
+    def forward(ctx, h, emb, deprel, trees, drop_p, seed, seed_dev=None):
         for t in (h, emb, deprel):
             _lib.require_gpu(t)
         if trees.label is None:
@@ -612,7 +630,7 @@ class _DiagLayerFn(torch.autograd.Function):
         out = torch.empty_like(h)
         _lib.check(_lib.lib().gcnpt_diag_layer_fwd(_lib.stream(), _lib.ptr(h), _lib.dtype_code(h.dtype), _lib.ptr(E), _lib.ptr(deprel),
                                                    _lib.ptr(trees.row_ptr), _lib.ptr(trees.col_idx), _lib.ptr(trees.label), B, T, H,
-                                                   _lib.ptr(out), float(drop_p), int(seed)))
+                                                   _lib.ptr(out), float(drop_p), int(seed), _lib.ptr(seed_dev)))
         ctx.trees, ctx.scale = trees, (1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0)
         ctx.save_for_backward(h, out, E, deprel)
         return out
@@ -629,12 +647,12 @@ class _DiagLayerFn(torch.autograd.Function):
                                                    _lib.ptr(E), _lib.ptr(deprel), _lib.ptr(trees.row_ptr), _lib.ptr(trees.col_idx),
                                                    _lib.ptr(trees.label), _lib.ptr(trees.rowT_ptr), _lib.ptr(trees.colT_idx), B, T, H,
                                                    _lib.ptr(dh), _lib.ptr(dE), ctx.scale))
-        return dh, dE, None, None, None, None
+        return dh, dE, None, None, None, None, None
 
 
-def diag_layer(h, deprel_table, deprel, trees, drop_p=0.0, seed=0):
+def diag_layer(h, deprel_table, deprel, trees, drop_p=0.0, seed=0, seed_dev=None):
     """dropout(relu(((F (E[deprel] * h)) + (R (E[deprel+42] * h)) + E[84] * h) / (deg + 1))) for h [B,T,H] (fp32 or bf16)."""
-    return _DiagLayerFn.apply(h, deprel_table, deprel, trees, drop_p, seed)
+    return _DiagLayerFn.apply(h, deprel_table, deprel, trees, drop_p, seed, seed_dev)
 
 
 class _Pool3Fn(torch.autograd.Function):

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define GCNPT_ABI_VERSION 1
+#define GCNPT_ABI_VERSION 2
 
 /* element types of activation / gradient buffers and of the MFMA operands */
 #define GCNPT_F32 0
@@ -125,11 +125,14 @@ size_t gcnpt_frag_bytes(int rows, int width, int dtype);
  * they differ from the aggregated pattern's (the `no_adj` ablation, gcn.py:264-265: denominators from the real
  * adjacency, aggregation over an empty one = an all-zero ell).
  * s_frag: NULL (inference), or gcnpt_frag_bytes(B*T, Din, compute_dtype) bytes that receive the fragment image
- * of S = (A+I) h for gcnpt_layer_bwd_weight. */
+ * of S = (A+I) h for gcnpt_layer_bwd_weight.
+ * seed_dev: NULL, or [dev] one uint64 that the kernel adds to `seed` when it runs: a counter the caller advances
+ * between replays of a captured hipGraph, so that a replayed training step draws a new dropout mask (a by-value
+ * seed is frozen into the graph). */
 int gcnpt_layer_fwd(void* stream, const void* h, int h_dtype, const void* w_fwd, const float* bias,
                     const int32_t* row_ptr, const int32_t* col_idx, const int32_t* ell, const int32_t* deg_ell, int B,
                     int T, int Din, int H, void* out, int out_dtype, int compute_dtype, float drop_p, uint64_t seed,
-                    void* s_frag);
+                    void* s_frag, const uint64_t* seed_dev);
 
 /* ---- A7: autograd of A6 -----------------------------------------------------------------------------------
  * With dZ[r,:] = dY[r,:] * 1[Y[r,:] > 0] * scale / (deg[r] + 1)   (Y = the layer's stored output, which
@@ -172,7 +175,7 @@ int gcnpt_stack_fwd(void* stream, int n_layers, const void* x, int x_dtype, cons
                     const float* const* bias, const int32_t* row_ptr, const int32_t* col_idx, const int32_t* ell,
                     const int32_t* deg_ell, int B, int T, int Din, int H, void* const* h_out, int out_dtype,
                     const float* drop_p, const uint64_t* seed, void* const* h_frag, float* const* zero_dW,
-                    float* const* zero_db);
+                    float* const* zero_db, const uint64_t* seed_dev);
 int gcnpt_stack_bwd(void* stream, int n_layers, const void* dY, const void* const* Y, int g_dtype,
                     const void* const* w_bwd, const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
                     const int32_t* ellT, int B, int T, int Din, int H, void* dx, int dx_dtype, const float* scale,
@@ -200,7 +203,7 @@ int gcnpt_pool3_bwd(void* stream, const float* g, const int32_t* argmax, const u
  * the caller clears it once per backward pass); scale = 1/(1-drop_p) of the forward call. */
 int gcnpt_diag_layer_fwd(void* stream, const void* h, int dtype, const float* E, const int64_t* deprel,
                          const int32_t* row_ptr, const int32_t* col_idx, const int32_t* label, int B, int T, int H,
-                         void* out, float drop_p, uint64_t seed);
+                         void* out, float drop_p, uint64_t seed, const uint64_t* seed_dev);
 int gcnpt_diag_layer_bwd(void* stream, const void* dY, const void* Y, const void* h, int dtype, const float* E,
                          const int64_t* deprel, const int32_t* row_ptr, const int32_t* col_idx, const int32_t* label,
                          const int32_t* rowT_ptr, const int32_t* colT_idx, int B, int T, int H, void* dh, float* dE,

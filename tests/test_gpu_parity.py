@@ -877,6 +877,56 @@ def test_classifier_end_to_end_golden(api, dev, tag):
     assert model.gcn_model.emb.weight.grad.abs().sum() > 0
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_training_step_graph_capture(api, dev, dtype):
+    """A whole training step of the no-LSTM classifier (tree build, layers, pooling, MLP, loss, backward) captured as ONE
+    hipGraph with torch.cuda.graph and replayed: every C-ABI call only enqueues on the current stream, and with
+    opt['gcn_graph_rng'] the dropout masks advance from a device counter instead of a seed frozen into the graph."""
+    import json
+    gcn, _ = api
+    e = load_golden("e2e_gcn.npz")
+    opt = dict(json.loads(str(e["opt"])), cuda=True, gcn_dtype=dtype, gcn_graph_rng=True, gcn_check_trees=False,
+               input_dropout=0.0, emb_dropout=0.0, word_dropout=0.0, gcn_dropout=0.5)
+    model = gcn.GCNClassifier(opt)
+    model.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in e.items() if k.startswith("sd:")}, strict=True)
+    model.to(dev).train()
+    inputs = tuple(_t(e[k], dev) for k in ("words", "masks", "pos", "ner", "deprel", "head", "subj_pos", "obj_pos"))
+    labels = torch.arange(inputs[0].shape[0], device=dev) % 42
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        logits, pooled = model(inputs)
+        loss = torch.nn.functional.cross_entropy(logits, labels) + 0.003 * (pooled ** 2).sum(1).mean()
+        loss.backward()
+        return loss
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    counter = model.gcn_model.gcn._rng_step
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        loss = step()
+    W0 = model.gcn_model.gcn.W[0].weight
+    counter.fill_(100)
+    graph.replay()
+    l1, g1 = float(loss), W0.grad.clone()
+    graph.replay()
+    l2 = float(loss)
+    assert int(counter) == 102 and l1 != l2                      # the mask moved on
+    counter.fill_(100)
+    graph.replay()
+    assert float(loss) == l1                                      # same counter, same masks, same forward
+    assert torch.isfinite(W0.grad).all() and max_rel(W0.grad.cpu().numpy(), g1.cpu().numpy()) <= 1e-5
+    # and the replayed step is the eager step: same counter value, eager launches
+    counter.fill_(100)
+    le = step()
+    assert abs(float(le) - l1) <= 1e-6 * abs(l1)
+
+
 @pytest.mark.parametrize("kind", ["max", "avg", "sum"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_pool3_matches_three_pool_calls(api, dev, kind, dtype):

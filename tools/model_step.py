@@ -50,7 +50,7 @@ def main():
                 logits, pooled = model(inputs, trees=cache.batch(idx, T) if cached else None)
                 loss = torch.nn.functional.cross_entropy(logits, labels) + 0.003 * (pooled ** 2).sum(1).mean()
                 loss.backward()
-                return loss
+                return loss.detach()        # no reference to the autograd graph survives the step (its AccumulateGrad nodes would pin a stream)
             for cached in (False, True):
                 for _ in range(10):
                     step(cached)

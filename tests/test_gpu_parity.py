@@ -877,6 +877,53 @@ def test_classifier_end_to_end_golden(api, dev, tag):
     assert model.gcn_model.emb.weight.grad.abs().sum() > 0
 
 
+@pytest.mark.parametrize("compute", [torch.float32, torch.bfloat16])
+def test_graph_capture_full_size_ops(api, dev, compute):
+    """Tree build, 2-layer stack (B=50, T=100, 360 -> 200 -> 200), fused pooling, forward and backward, captured with
+    torch.cuda.graph (all temporaries from the graph's private pool) and replayed: same numbers as the eager run.  The fp32
+    row tiles need > 64 KB of LDS; their launch attribute is set once, in the eager warm-up, never inside a capture."""
+    from gcn_over_pruned_trees_amd.utils import synthetic
+    gcn, tree = api
+    B, T, din, hid = 50, 100, 360, 200
+    tb = synthetic.random_tree_batch(1234, B, T, "tacred")
+    Ws, bs = synthetic.layer_params(2, [din, hid, hid])
+    Ws = [_t(w, dev).requires_grad_() for w in Ws]
+    bs = [_t(b, dev).requires_grad_() for b in bs]
+    x = _t(synthetic.normal(3, (B, T, din)), dev).requires_grad_()
+    head, subj, obj, deprel, masks = (_t(tb[k], dev) for k in ("head", "subj_pos", "obj_pos", "deprel", "masks"))
+    counter = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def step():
+        for t in Ws + bs + [x]:
+            t.grad = None
+        trees = tree.prune_to_csr(head, subj, obj, deprel, 1, masks=masks, want_label=False)
+        h = gcn.gcn_layers(x, Ws, bs, trees, [0.5, 0.0], [11, 0], compute, torch.float32, seed_dev=counter)
+        pooled = gcn.pool3(h, trees.pool_mask, subj, obj, type="max")
+        loss = (pooled * pooled).mean()
+        loss.backward()
+        return loss.detach()
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            want = step()
+    torch.cuda.current_stream().wait_stream(side)
+    want, want_dx, want_dW = float(want), x.grad.clone(), Ws[0].grad.clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        loss = step()
+    for _ in range(20):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert float(loss) == want
+    np.testing.assert_array_equal(x.grad.cpu().numpy(), want_dx.cpu().numpy())
+    assert max_rel(Ws[0].grad.cpu().numpy(), want_dW.cpu().numpy()) <= 1e-5
+    counter.fill_(7)
+    graph.replay()
+    assert float(loss) != want                                   # another dropout mask
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_training_step_graph_capture(api, dev, dtype):
     """A whole training step of the no-LSTM classifier (tree build, layers, pooling, MLP, loss, backward) captured as ONE

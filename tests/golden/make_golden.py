@@ -302,7 +302,7 @@ def gen_end_to_end():
         ner[r, :n] = [ref_constant.NER_TO_ID.get(p, 1) for p in s["stanford_ner"]]
     fields = {k: arr[k][sel][:, :T] for k in ("head", "deprel", "subj_pos", "obj_pos")}
     masks = words == 0
-    for tag, rnn in (("gcn", False), ("cgcn", True), ("diag", False)):
+    for tag, rnn in (("gcn", False), ("cgcn", True), ("diag", False), ("full", False), ("semeval", False), ("avgpool", True)):
         opt = dict(vocab_size=len(vocab) + 2, emb_dim=24, pos_dim=6, ner_dim=6, hidden_dim=32, num_layers=2,
                    input_dropout=0.5, gcn_dropout=0.5, emb_dropout=0.0, word_dropout=0.04, topn=10 ** 10,
                    deprel_emb_dim=32, adj_type="regular", prune_k=1, pooling="max", mlp_layers=2,
@@ -310,12 +310,20 @@ def gen_end_to_end():
                    cuda=False, dataset="tacred", num_class=42, no_adj=False)
         if tag == "diag":
             opt["adj_type"] = "diagonal_deprel"
+        if tag == "full":           # in_dim == mem_dim, as the variant needs for two layers
+            opt.update(adj_type="full_deprel", deprel_emb_dim=5, emb_dim=20, deprel_max_depth=1, deprel_directed=False, deprel_self_loop=True)
+        if tag == "semeval":        # 7-tuple inputs, no NER embedding (gcn.py:94, 136-139)
+            opt.update(dataset="semeval", num_class=19)
+        if tag == "avgpool":        # C-GCN with average pooling and one MLP layer
+            opt.update(pooling="avg", mlp_layers=1)
         torch.manual_seed(4321)
         model = GCNClassifier(opt)
         model.eval()
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
         inputs = (t(words), t(masks), t(pos), t(ner), t(fields["deprel"]), t(fields["head"]),
                   t(fields["subj_pos"]), t(fields["obj_pos"]))
+        if tag == "semeval":
+            inputs = inputs[:3] + inputs[4:]
         with torch.no_grad():
             logits, pooled = model(inputs)
         out = dict(opt=np.array(json.dumps(opt)), words=words, masks=masks, pos=pos, ner=ner, **fields,

@@ -576,6 +576,34 @@ def test_pruner_large_batch_longest_sentence(api, dev):
     _same_trees(big, viam)
 
 
+def test_pinned_stager_uploads_batches(api, dev):
+    """N4, host half: bucketed batches staged through pinned buffers arrive as the padded tensors a plain upload gives, and
+    the cached trees of those batches equal pruning them directly."""
+    from gcn_over_pruned_trees_amd.utils import staging
+    gcn, tree = api
+    g = load_golden("trees_random.npz")
+    lens = g["lens"].astype(np.int32)
+    data = dict(head=g["head"], deprel=g["deprel"], subj_pos=g["subj_pos"], obj_pos=g["obj_pos"], lens=lens)
+    fields = dict(head=(torch.int64, 0), deprel=(torch.int64, 0), subj_pos=(torch.int64, 150), obj_pos=(torch.int64, 150))
+    stager = staging.PinnedStager(fields, 64, g["head"].shape[1], dev)
+    cache = tree.TreeCache.build(_t(g["head"], dev), _t(g["subj_pos"], dev), _t(g["obj_pos"], dev), _t(g["deprel"], dev), 1, lens=_t(lens, dev))
+    batches = staging.length_buckets(lens, 64, shuffle_seed=5)[:6]
+    pending = [stager.upload(data, b) for b in batches[:2]]            # two uploads in flight
+    for i, b in enumerate(batches):
+        out, masks, ev = pending.pop(0)
+        if i + 2 < len(batches):
+            pending.append(stager.upload(data, batches[i + 2]))
+        stager.ready(ev)
+        T = int(lens[b].max())
+        assert tuple(out["head"].shape) == (len(b), T)
+        np.testing.assert_array_equal(out["head"].cpu().numpy(), g["head"][b, :T])
+        np.testing.assert_array_equal(masks.cpu().numpy(), np.arange(T)[None, :] >= lens[b][:, None])
+        sp = out["subj_pos"].cpu().numpy()
+        assert (sp[masks.cpu().numpy()] == 150).all()
+        direct = tree.prune_to_csr(out["head"], out["subj_pos"], out["obj_pos"], out["deprel"], 1, masks=masks)
+        _same_trees(cache.batch(_t(b, dev), T), direct)
+
+
 def test_tree_cache_errors_and_model_hook(api, dev):
     gcn, tree = api
     from gcn_over_pruned_trees_amd import _lib
@@ -875,6 +903,33 @@ def test_classifier_end_to_end_golden(api, dev, tag):
     for lin in model.get_gcn_parameters():
         assert lin.weight.grad is not None and torch.isfinite(lin.weight.grad).all() and lin.weight.grad.abs().sum() > 0
     assert model.gcn_model.emb.weight.grad.abs().sum() > 0
+
+
+@pytest.mark.parametrize("tag", ["full", "semeval", "avgpool"])
+def test_classifier_end_to_end_golden_variants(api, dev, tag):
+    """More of the reference's module surface against its recorded logits: full_deprel end to end, the 7-tuple semeval
+    inputs (no NER embedding), C-GCN with average pooling and a one-layer MLP."""
+    import json
+    gcn, _ = api
+    g = load_golden("e2e_%s.npz" % tag)
+    opt = json.loads(str(g["opt"]))
+    opt["cuda"] = True
+    model = gcn.GCNClassifier(opt)
+    model.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd:")}, strict=True)
+    model.to(dev).eval()
+    keys = ("words", "masks", "pos", "ner", "deprel", "head", "subj_pos", "obj_pos")
+    if opt["dataset"] != "tacred":
+        keys = keys[:3] + keys[4:]
+    inputs = tuple(_t(g[k], dev) for k in keys)
+    with torch.no_grad():
+        logits, pooled = model(inputs)
+    assert max_rel(logits.cpu().numpy(), g["logits"]) <= 1e-4
+    assert max_rel(pooled.cpu().numpy(), g["pooling_output"]) <= 1e-4
+    model.train()
+    logits, pooled = model(inputs)
+    (logits.logsumexp(1).mean() + 0.003 * (pooled ** 2).sum(1).mean()).backward()
+    grads = [p.grad for p in model.parameters() if p.grad is not None]
+    assert grads and all(torch.isfinite(gr).all() for gr in grads)
 
 
 @pytest.mark.parametrize("compute", [torch.float32, torch.bfloat16])

@@ -173,7 +173,8 @@ def test_pruner_errors(api, dev):
         short.check(expect_maxlen=T)
 
 
-@pytest.mark.parametrize("B,T,K,lengths", [(50, 100, 1, "full"), (50, 100, 1, "tacred"), (128, 300, 2, "tacred"), (3, 1000, 3, "full")])
+@pytest.mark.parametrize("B,T,K,lengths", [(50, 100, 1, "full"), (50, 100, 1, "tacred"), (128, 300, 2, "tacred"), (3, 1000, 3, "full"),
+                                           (2, 4092, 2, "full")])      # the longest sentence the pruner takes (112 KB of LDS)
 def test_pruner_vs_oracle_full_size(api, dev, B, T, K, lengths):
     from gcn_over_pruned_trees_amd.utils import synthetic
     from oracle import prune_ref

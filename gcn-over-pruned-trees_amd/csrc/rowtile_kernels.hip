@@ -66,9 +66,13 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
     const int ostride = out_stride_dw(min(round_up(p.NOUT, 16), ncols_pass) * (int)sizeof(OT) / 4) * 4 / (int)sizeof(OT);
     const size_t s_bytes = (size_t)ROWS * stride * sizeof(CT);
     CT* S = reinterpret_cast<CT*>(smem_raw);
-    CT* Z = reinterpret_cast<CT*>(smem_raw + s_bytes);          // bwd only: the tile's own dZ rows (before aggregation)
-    OT* O = reinterpret_cast<OT*>(smem_raw + (BWD ? 2 : 1) * s_bytes);
-    int* meta = reinterpret_cast<int*>(smem_raw + (BWD ? 2 : 1) * s_bytes + (size_t)ROWS * ostride * sizeof(OT));
+    // bwd: Z (the tile's own dZ rows, before aggregation) is only read by the fragment-image emission, the out tile O only
+    // written from the epilogue on: they share one region, with a barrier between the two uses
+    const size_t o_bytes = (size_t)ROWS * ostride * sizeof(OT);
+    const size_t zo_bytes = BWD ? (s_bytes > o_bytes ? s_bytes : o_bytes) : o_bytes;
+    CT* Z = reinterpret_cast<CT*>(smem_raw + s_bytes);
+    OT* O = reinterpret_cast<OT*>(smem_raw + s_bytes);
+    int* meta = reinterpret_cast<int*>(smem_raw + s_bytes + zo_bytes);
     int* rell = meta;                         // [ROWS][8] ELL heads of the tile's rows (count, 7 sentence-local columns)
     float* rinv = reinterpret_cast<float*>(meta + 8 * ROWS);   // [ROWS] fwd: 1/(deg+1)   bwd: scale/(deg+1)
     float* rden = reinterpret_cast<float*>(meta + 9 * ROWS);   // [ROWS] deg+1
@@ -358,6 +362,9 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
             }
         }
     }
+    if constexpr (BWD) {
+        if (p.frag_out) __syncthreads();                         // every wave has read its share of Z: the region becomes O
+    }
     if (p.zero_a)
         for (int i = blockIdx.x * RT_THREADS + tid; i < p.zero_a_n; i += gridDim.x * RT_THREADS) p.zero_a[i] = 0.0f;
     if (p.zero_b)
@@ -504,7 +511,8 @@ static int launch_rowtile_cfg(hipStream_t s, const RowTileParams& p) {
     const int stride = lds_stride_dw(p.Kpad * (int)sizeof(CT) / 4) * 4 / (int)sizeof(CT);
     const int ncols_pass = RT_WAVES * NTW * 16;
     const int ostride = out_stride_dw(std::min(round_up(p.NOUT, 16), ncols_pass) * (int)sizeof(OT) / 4) * 4 / (int)sizeof(OT);
-    const size_t lds = (size_t)(BWD ? 2 : 1) * ROWS * stride * sizeof(CT) + (size_t)ROWS * ostride * sizeof(OT) +
+    const size_t s_bytes = (size_t)ROWS * stride * sizeof(CT), o_bytes = (size_t)ROWS * ostride * sizeof(OT);
+    const size_t lds = s_bytes + (BWD ? std::max(s_bytes, o_bytes) : o_bytes) +
                        (size_t)ROWS * 13 * sizeof(int) + (size_t)RT_THREADS * sizeof(float);
     if (lds > 160 * 1024) return fail(GCNPT_E_UNSUPPORTED, "layer: K=%d needs %zu B of LDS per workgroup", p.K, lds);
     auto kern = rowtile_kernel<CT, IT, OT, BWD, VEC, NTW, KSMAX>;

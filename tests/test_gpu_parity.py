@@ -312,6 +312,42 @@ def test_layers_odd_widths_bf16(api, dev, din, hid):
     _check_bf16_grads(r, adj, g)
 
 
+@pytest.mark.parametrize("B,T,din,hid,K", [(3, 5, 3, 2, 1),          # tiles span several sentences, widths below one MFMA tile
+                                            (7, 33, 8, 16, 0),         # rows not a multiple of the tile, K=0 trees
+                                            (2, 50, 1000, 40, 2),      # own rows take several batches, weights several k-chunks
+                                            (5, 17, 24, 520, 1),       # more than 512 output columns: second column pass
+                                            (4, 64, 416, 72, 3),       # 13 k-steps: the C-GCN input width's instantiation
+                                            (1, 200, 136, 136, 2)])
+def test_layers_corner_shapes(api, dev, B, T, din, hid, K):
+    """Shapes that take the kernels' rare paths, both precisions, against the oracle (gradients through the device's own
+    activations for bf16, see _check_bf16_grads)."""
+    from oracle import gcn_ref, prune_ref
+    from gcn_over_pruned_trees_amd.utils import synthetic
+    tb = synthetic.random_tree_batch(300 + B + T, B, T, "tacred" if T >= 8 else "full")
+    adj = prune_ref.batch_adj(tb["head"], tb["subj_pos"], tb["obj_pos"], tb["deprel"], tb["lens"], K)["adj"]
+    Ws, bs = synthetic.layer_params(5, [din, hid, hid])
+    g = dict(tb, x=synthetic.normal(6, (B, T, din)), gy=synthetic.normal(7, (B, T, hid)), Ws=Ws, bs=bs, prune_k=K)
+    h, mask = gcn_ref.gcn_forward(adj, g["x"], Ws, bs)
+    r = _run_stack(api, dev, g, torch.float32)
+    np.testing.assert_array_equal(r["mask"], mask)
+    assert max_rel(r["h"], h) <= FWD_RTOL
+    _check_fp32_grads_full_size(r, adj, g)
+    r = _run_stack(api, dev, g, torch.bfloat16)
+    assert max_rel(r["h"], h) <= 3e-2
+    _check_bf16_grads(r, adj, g)
+    # the whole-loop op with dropout between the layers takes the same kernels: equal to the chained layers
+    gcn, tree = api
+    trees = _prune(tree, g, K, dev)
+    x = _t(g["x"], dev).requires_grad_()
+    Wt = [_t(w, dev).requires_grad_() for w in Ws]
+    bt = [_t(b, dev).requires_grad_() for b in bs]
+    base = _run_stack(api, dev, g, torch.float32, drop=(0.3, 99))
+    hh = gcn.gcn_layers(x, Wt, bt, trees, [0.3, 0.0], [99, 0], torch.float32, torch.float32)
+    hh.backward(_t(g["gy"], dev))
+    np.testing.assert_array_equal(hh.detach().cpu().numpy(), base["h"])
+    assert max_rel(Wt[0].grad.cpu().numpy(), base["dW"][0]) <= 1e-5
+
+
 def test_dropout(api, dev):
     """In-kernel dropout: rate, 1/(1-p) scaling, determinism per seed, and a backward that uses the same mask."""
     from oracle import gcn_ref

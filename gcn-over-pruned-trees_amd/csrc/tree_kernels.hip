@@ -73,6 +73,27 @@ __device__ __forceinline__ int wave_exclusive_scan(int* a, int n, int lane) {
     return total;
 }
 
+// the same for three arrays at once: three independent shuffle chains share the latency of one
+__device__ __forceinline__ void wave_exclusive_scan3(int* a, int* b, int* c, int n, int lane, int& ta, int& tb, int& tc) {
+    const int seg = (n + WAVE - 1) / WAVE;
+    const int lo = min(n, lane * seg), hi = min(n, lo + seg);
+    int sa = 0, sb = 0, sc = 0;
+    for (int i = lo; i < hi; ++i) { sa += a[i]; sb += b[i]; sc += c[i]; }
+    int ia = sa, ib = sb, ic = sc;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const int ua = __shfl_up(ia, o), ub = __shfl_up(ib, o), uc = __shfl_up(ic, o);
+        if (lane >= o) { ia += ua; ib += ub; ic += uc; }
+    }
+    ta = __shfl(ia, WAVE - 1); tb = __shfl(ib, WAVE - 1); tc = __shfl(ic, WAVE - 1);
+    int ra = ia - sa, rb = ib - sb, rc = ic - sc;
+    for (int i = lo; i < hi; ++i) {
+        const int va = a[i], vb = b[i], vc = c[i];
+        a[i] = ra; b[i] = rb; c[i] = rc;
+        ra += va; rb += vb; rc += vc;
+    }
+}
+
 // One 32-bit word per token keeps its parent and its flags together, so that every step of a walk up the tree is
 // ONE LDS read:  bits 0..11 = parent + 2 (0 = head points past the sentence, 1 = root / none), bits 12.. = F_* flags.
 constexpr int PW_SHIFT = 12, PW_MASK = (1 << PW_SHIFT) - 1, PRUNE_MAX_T = PW_MASK - 3;
@@ -98,21 +119,32 @@ __device__ void prune_sentence(const int64_t* __restrict__ head, const int64_t* 
     const int lane = threadIdx.x & 63;
     const size_t base = (size_t)b * T;
 
-    // ---- stage the parse (tree.py:60-63, 82-83): every load is unconditional and issued before the first use
+    // ---- stage the parse (tree.py:60-63, 82-83).  Two tokens per lane per round, every load of the round issued before the
+    // first use (clamped addresses, no load behind a condition): a sentence of up to 128 tokens costs ONE memory round trip
     int npad = 0;
-    for (int i = lane; i < T; i += WAVE) {
-        const int64_t h = head[base + i];
-        const int64_t sp = subj_pos[base + i], op = obj_pos[base + i], d = deprel[base + i];
-        const bool pad = pad_mask ? pad_mask[base + i] != 0 : false;
-        npad += pad ? 1 : 0;
-        int f = 0;
-        if (sp == 0) f |= F_SUBJ;
-        if (op == 0) f |= F_OBJ;
-        if (d != 0) f |= F_FWD_NZ;                     // adj[p,c] = deprel[c]        survives `adj != 0`
-        if (d + FWD_BOUND != 0) f |= F_REV_NZ;         // adj[c,p] = deprel[c] + 42
-        const int p = h > 0 ? (int)min(h - 1, (int64_t)(PW_MASK - 2)) : -1;      // range-checked against len below
-        pw[i] = (p + 2) | (f << PW_SHIFT);
-        lab[i] = (int)d; cnt[i] = 0; deg[i] = 0; degT[i] = 0;
+    for (int i0 = 0; i0 < T; i0 += 2 * WAVE) {
+        int64_t h[2], sp[2], op[2], d[2];
+        bool pad[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const size_t j = base + min(i0 + u * WAVE + lane, T - 1);
+            h[u] = head[j]; sp[u] = subj_pos[j]; op[u] = obj_pos[j]; d[u] = deprel[j];
+            pad[u] = pad_mask ? pad_mask[j] != 0 : false;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = i0 + u * WAVE + lane;
+            if (i >= T) continue;
+            npad += pad[u] ? 1 : 0;
+            int f = 0;
+            if (sp[u] == 0) f |= F_SUBJ;
+            if (op[u] == 0) f |= F_OBJ;
+            if (d[u] != 0) f |= F_FWD_NZ;                  // adj[p,c] = deprel[c]        survives `adj != 0`
+            if (d[u] + FWD_BOUND != 0) f |= F_REV_NZ;      // adj[c,p] = deprel[c] + 42
+            const int p = h[u] > 0 ? (int)min(h[u] - 1, (int64_t)(PW_MASK - 2)) : -1;      // range-checked against len below
+            pw[i] = (p + 2) | (f << PW_SHIFT);
+            lab[i] = (int)d[u]; cnt[i] = 0; deg[i] = 0; degT[i] = 0;
+        }
     }
     // sentence length = number of non-pad slots (gcn.py:96)
     const int len = pad_mask ? T - wave_sum(npad) : min(max(len_in[b], 0), T);
@@ -216,9 +248,8 @@ __device__ void prune_sentence(const int64_t* __restrict__ head, const int64_t* 
             if (pool_mask) pool_mask[base + i] = (deg[i] + degT[i]) == 0;   // gcn.py:262
         }
         wave_lds_fence();
-        const int tot = wave_exclusive_scan(deg, T, lane);
-        const int totT = wave_exclusive_scan(degT, T, lane);
-        n_edge_rows = wave_exclusive_scan(rank, T, lane);
+        int tot, totT;
+        wave_exclusive_scan3(deg, degT, rank, T, lane, tot, totT, n_edge_rows);
         if (lane == 0) { deg[T] = tot; degT[T] = totT; }
         wave_lds_fence();
         if (tot > cap || totT > cap) err = GCNPT_E_CAPACITY;

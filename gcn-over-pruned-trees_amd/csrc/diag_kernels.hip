@@ -12,7 +12,7 @@
 //   uf[c]  = sum_{r: 0 < adj[r,c] < 42} dz[r]        ur[c] = sum_{r: 42 < adj[r,c] < 84} dz[r]
 //   dh[c]  = uf[c] * E[deprel[c]] + ur[c] * E[deprel[c]+42] + dz[c] * E[84]
 //   dE[deprel[c]] += uf[c] * h[c]   dE[deprel[c]+42] += ur[c] * h[c]   (fp32 atomics, only tokens that have such edges)
-//   dE[84] += sum_c dz[c] * h[c]    (reduced per block in registers + LDS, ONE atomic per column per block)
+//   dE[84] += sum_c dz[c] * h[c]    (its own column-reduction launch: 64 atomics per element instead of one per workgroup)
 // adj[r,c] for r in column c's transposed list is looked up in row r's (short) CSR segment.
 #include "layer_common.h"
 
@@ -20,7 +20,10 @@ namespace gcnpt {
 
 constexpr int DG_THREADS = 256;
 constexpr int DG_WAVES = DG_THREADS / 64;
-constexpr int DG_ROWS = 16;                 // rows per block
+constexpr int DG_ROWS = DG_WAVES;           // rows per block: one per wave, so the dependent index chains of different rows overlap
+constexpr int DG_SELF_BLOCKS = 32;          // workgroups of the dE[84] column reduction (= float atomics per element of that row:
+                                            // same-address device atomics cost ~0.1 us each, 128 of them were slower than 64)
+constexpr int DG_SELF_WAVES = 8;
 constexpr int DG_FWD = 42, DG_REV = 84, DG_SELF = 84, DG_NE = 85;   // utils/constant.py:14-17 and len(DEPREL_TO_ID)*2+1
 
 struct DiagParams {
@@ -37,32 +40,6 @@ struct DiagParams {
     unsigned drop_thresh16;
     uint64_t seed;
     const uint64_t* seed_dev;  // NULL or a device word added to seed
-};
-
-template <typename T, int CPL> struct dgio;
-template <> struct dgio<float, 4> {
-    static __device__ __forceinline__ void ld(const float* p, int, float (&v)[4]) {
-        const float4 a = *reinterpret_cast<const float4*>(p);
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-    }
-    static __device__ __forceinline__ void st(float* p, int, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
-};
-template <> struct dgio<bf16_t, 4> {
-    static __device__ __forceinline__ void ld(const bf16_t* p, int, float (&v)[4]) {
-        const uint2 u = *reinterpret_cast<const uint2*>(p);
-        v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
-        v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
-    }
-    static __device__ __forceinline__ void st(bf16_t* p, int, const float (&v)[4]) {
-        uint2 u;
-        u.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-        u.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-        *reinterpret_cast<uint2*>(p) = u;
-    }
-};
-template <typename T> struct dgio<T, 1> {    // any H / alignment: `n` = 1 when the column exists, 0 past the end (pointer clamped by the caller)
-    static __device__ __forceinline__ void ld(const T* p, int n, float (&v)[1]) { const float x = io<T>::load1(p); v[0] = n ? x : 0.0f; }
-    static __device__ __forceinline__ void st(T* p, int n, const float (&v)[1]) { if (n) io<T>::store1(p, v[0]); }
 };
 
 // embedding row picked by adj value `lab` for column token relation `rel`: -1 = the entry contributes nothing
@@ -120,7 +97,6 @@ __global__ __launch_bounds__(DG_THREADS) void diag_fwd_kernel(const DiagParams p
 
 template <typename T, int CPL>
 __global__ __launch_bounds__(DG_THREADS) void diag_bwd_kernel(const DiagParams p) {
-    __shared__ float red[DG_WAVES][64 * CPL];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const T* h = static_cast<const T*>(p.h);
     const T* Y = static_cast<const T*>(p.y);
@@ -129,9 +105,7 @@ __global__ __launch_bounds__(DG_THREADS) void diag_bwd_kernel(const DiagParams p
     const int H = p.H;
     for (int c0 = lane * CPL; c0 < round_up(H, 64 * CPL); c0 += 64 * CPL) {              // uniform trip count over the block
         const int cc = min(c0, H - CPL), live = c0 < H;
-        float se_acc[CPL], eself[CPL];
-#pragma unroll
-        for (int j = 0; j < CPL; ++j) se_acc[j] = 0.0f;
+        float eself[CPL];
         dgio<float, CPL>::ld(p.E + (size_t)DG_SELF * H + cc, live, eself);
         for (int rr = wave; rr < DG_ROWS; rr += DG_WAVES) {
             const int c = blockIdx.x * DG_ROWS + rr;                                      // this wave's token (a COLUMN of adj)
@@ -171,12 +145,9 @@ __global__ __launch_bounds__(DG_THREADS) void diag_bwd_kernel(const DiagParams p
                     for (int j = 0; j < CPL; ++j) ur[j] += yv[j] > 0.0f ? gv[j] * s : 0.0f;
                 }
             }
-            dgio<T, CPL>::ld(h + (size_t)c * H + cc, live, hv);
 #pragma unroll
-            for (int j = 0; j < CPL; ++j) {
-                out[j] = dz[j] * eself[j];
-                se_acc[j] = __builtin_fmaf(dz[j], hv[j], se_acc[j]);
-            }
+            for (int j = 0; j < CPL; ++j) { out[j] = dz[j] * eself[j]; hv[j] = 0.0f; }
+            if (any_f || any_r) dgio<T, CPL>::ld(h + (size_t)c * H + cc, live, hv);      // wave-uniform: only tokens with edges
             if (any_f) {
                 const int id = min(rel, DG_NE - 1);
                 float ev[CPL];
@@ -199,19 +170,55 @@ __global__ __launch_bounds__(DG_THREADS) void diag_bwd_kernel(const DiagParams p
             }
             if (live) dgio<T, CPL>::st(dh + (size_t)c * H + cc, live, out);
         }
-        // dE[84]: the block's rows summed over its waves, one atomic per column
-        __syncthreads();
+    }
+}
+
+// dE[84] += sum_c dz[c] * h[c]: a column reduction over all N rows on its own, so that one element of that row receives
+// DG_SELF_BLOCKS float atomics instead of one per workgroup of the kernel above (same-address atomics serialise)
+template <typename T, int CPL>
+__global__ __launch_bounds__(DG_SELF_WAVES * 64) void diag_selfgrad_kernel(const DiagParams p) {
+    __shared__ float red[DG_SELF_WAVES][64 * CPL];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const T* h = static_cast<const T*>(p.h);
+    const T* Y = static_cast<const T*>(p.y);
+    const T* dY = static_cast<const T*>(p.dy);
+    const int H = p.H;
+    const int per = ceil_div(p.N, (int)gridDim.x);
+    const int r_lo = blockIdx.x * per, r_hi = min(p.N, r_lo + per);
+    const int c0 = (blockIdx.y * 64 + lane) * CPL;
+    const int cc = min(c0, H - CPL), live = c0 < H;
+    float acc[CPL];
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) red[wave][lane * CPL + j] = se_acc[j];
-        __syncthreads();
-        if (wave == 0 && live) {
+    for (int j = 0; j < CPL; ++j) acc[j] = 0.0f;
+    constexpr int RU = 4;                                                  // rows per round: twelve loads in flight
+    for (int r0 = r_lo + wave; r0 < r_hi; r0 += RU * DG_SELF_WAVES) {
+        float yv[RU][CPL], gv[RU][CPL], hv[RU][CPL], s[RU];
 #pragma unroll
-            for (int j = 0; j < CPL; ++j) {
-                float s = 0.0f;
+        for (int u = 0; u < RU; ++u) {
+            const int r = min(r0 + u * DG_SELF_WAVES, r_hi - 1);
+            const int b = r / p.T, t = r - b * p.T;
+            dgio<T, CPL>::ld(Y + (size_t)r * H + cc, live, yv[u]);
+            dgio<T, CPL>::ld(dY + (size_t)r * H + cc, live, gv[u]);
+            dgio<T, CPL>::ld(h + (size_t)r * H + cc, live, hv[u]);
+            s[u] = p.scale / (float)(p.row_ptr[b * (p.T + 1) + t + 1] - p.row_ptr[b * (p.T + 1) + t] + 1);
+        }
 #pragma unroll
-                for (int w = 0; w < DG_WAVES; ++w) s += red[w][lane * CPL + j];
-                atomicAdd(p.dE + (size_t)DG_SELF * H + cc + j, s);
-            }
+        for (int u = 0; u < RU; ++u) {
+            const bool on = r0 + u * DG_SELF_WAVES < r_hi;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) acc[j] += (on && yv[u][j] > 0.0f) ? gv[u][j] * s[u] * hv[u][j] : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) red[wave][lane * CPL + j] = acc[j];
+    __syncthreads();
+    if (wave == 0 && live) {
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            float v = 0.0f;
+#pragma unroll
+            for (int w = 0; w < DG_SELF_WAVES; ++w) v += red[w][lane * CPL + j];
+            atomicAdd(p.dE + (size_t)DG_SELF * H + cc + j, v);
         }
     }
 }
@@ -221,8 +228,10 @@ static int launch_diag(hipStream_t s, const DiagParams& p, int dtype, bool vec) 
     const dim3 grid(ceil_div(p.N, DG_ROWS)), block(DG_THREADS);
 #define GCNPT_DIAG_LAUNCH(T, CPL)                                                             \
     do {                                                                                      \
-        if (BWD) hipLaunchKernelGGL((diag_bwd_kernel<T, CPL>), grid, block, 0, s, p);         \
-        else hipLaunchKernelGGL((diag_fwd_kernel<T, CPL>), grid, block, 0, s, p);             \
+        if (BWD) {                                                                            \
+            hipLaunchKernelGGL((diag_bwd_kernel<T, CPL>), grid, block, 0, s, p);              \
+            hipLaunchKernelGGL((diag_selfgrad_kernel<T, CPL>), dim3(std::min(DG_SELF_BLOCKS, p.N), ceil_div(p.H, 64 * CPL)), dim3(DG_SELF_WAVES * 64), 0, s, p); \
+        } else hipLaunchKernelGGL((diag_fwd_kernel<T, CPL>), grid, block, 0, s, p);           \
     } while (0)
     if (dtype == GCNPT_F32) {
         if (vec) GCNPT_DIAG_LAUNCH(float, 4); else GCNPT_DIAG_LAUNCH(float, 1);

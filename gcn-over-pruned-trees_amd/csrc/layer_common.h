@@ -149,6 +149,33 @@ __host__ __device__ inline int out_stride_dw(int payload_dw) {
     return s;
 }
 
+// CPL consecutive columns of a row <-> floats (the element-wise kernels: diag_kernels.hip, pool_kernels.hip)
+template <typename T, int CPL> struct dgio;
+template <> struct dgio<float, 4> {
+    static __device__ __forceinline__ void ld(const float* p, int, float (&v)[4]) {
+        const float4 a = *reinterpret_cast<const float4*>(p);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    }
+    static __device__ __forceinline__ void st(float* p, int, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct dgio<bf16_t, 4> {
+    static __device__ __forceinline__ void ld(const bf16_t* p, int, float (&v)[4]) {
+        const uint2 u = *reinterpret_cast<const uint2*>(p);
+        v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+        v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    }
+    static __device__ __forceinline__ void st(bf16_t* p, int, const float (&v)[4]) {
+        uint2 u;
+        u.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+        u.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+        *reinterpret_cast<uint2*>(p) = u;
+    }
+};
+template <typename T> struct dgio<T, 1> {    // any H / alignment: `n` = 1 when the column exists, 0 past the end (pointer clamped by the caller)
+    static __device__ __forceinline__ void ld(const T* p, int n, float (&v)[1]) { const float x = io<T>::load1(p); v[0] = n ? x : 0.0f; }
+    static __device__ __forceinline__ void st(T* p, int n, const float (&v)[1]) { if (n) io<T>::store1(p, v[0]); }
+};
+
 // host-side argument helpers of the C-ABI wrappers
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline int kstep_of(int dtype) { return dtype == GCNPT_BF16 ? 32 : 16; }

@@ -9,7 +9,8 @@
 
 namespace gcnpt {
 
-constexpr int POOL_THREADS = 256;
+constexpr int POOL_THREADS = 512;                       // 8 waves take every 8th token; a lane owns CPL consecutive columns
+constexpr int POOL_WAVES = POOL_THREADS / WAVE;
 constexpr float POOL_NEG = -1e12f;     // utils/constant.py:35 INFINITY_NUMBER
 
 // bit k of the result = token t is MASKED for pooling k (0: pool_mask, 1: not a subject token, 2: not an object token)
@@ -17,85 +18,142 @@ __device__ __forceinline__ int pool_mask_bits(const uint8_t* pm, const int64_t* 
     return (pm[i] ? 1 : 0) | (sp[i] != 0 ? 2 : 0) | (op[i] != 0 ? 4 : 0);
 }
 
-template <typename T>
+// Forward: every wave reduces its tokens for its columns with all loads of the pass in flight, the 8 partial results meet in
+// LDS.  max keeps the FIRST maximum (torch.max(dim) on the CPU reference): strict > inside a wave (tokens ascending), ties
+// between waves go to the smaller token.
+template <typename T, int CPL>
 __global__ __launch_bounds__(POOL_THREADS) void pool3_fwd_kernel(const T* __restrict__ h, const uint8_t* __restrict__ pool_mask,
                                                                 const int64_t* __restrict__ subj_pos, const int64_t* __restrict__ obj_pos,
                                                                 int Tn, int H, int type, float* __restrict__ out, int32_t* __restrict__ argmax) {
     extern __shared__ int mbits[];                       // [Tn]
-    const int b = blockIdx.x;
-    for (int t = threadIdx.x; t < Tn; t += POOL_THREADS) mbits[t] = pool_mask_bits(pool_mask, subj_pos, obj_pos, (size_t)b * Tn + t);
+    __shared__ float red[POOL_WAVES][3][WAVE * CPL];
+    __shared__ int redarg[POOL_WAVES][3][WAVE * CPL];
+    __shared__ int s_cnt[3];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c0 = (blockIdx.y * WAVE + lane) * CPL;
+    const int cc = min(c0, H - CPL), live = c0 < H;
+    // tokens per round: their loads are issued together (clamped, no condition).  The first round -- all of a sentence of up to
+    // 128 tokens -- goes out before the masks are even looked at, so the kernel is two memory round trips deep
+    constexpr int PU = 16;
+    float v[PU][CPL];
+#pragma unroll
+    for (int u = 0; u < PU; ++u)
+        dgio<T, CPL>::ld(h + ((size_t)b * Tn + min(wave + u * POOL_WAVES, Tn - 1)) * H + cc, live, v[u]);
+    if (tid < 3) s_cnt[tid] = 0;
     __syncthreads();
-    int unmasked[3] = {0, 0, 0};
-    if (type == 1)
-        for (int t = 0; t < Tn; ++t) {
+    for (int t = tid; t < Tn; t += POOL_THREADS) {
+        const int m = pool_mask_bits(pool_mask, subj_pos, obj_pos, (size_t)b * Tn + t);
+        mbits[t] = m;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) unmasked[k] += (mbits[t] >> k & 1) ? 0 : 1;
+        for (int k = 0; k < 3; ++k)
+            if (!(m >> k & 1)) atomicAdd(&s_cnt[k], 1);
+    }
+    __syncthreads();
+    float acc[3][CPL];
+    int arg[3][CPL];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) { acc[k][j] = type == 0 ? -INFINITY : 0.0f; arg[k][j] = 0; }
+    for (int t0 = wave; t0 < Tn; t0 += POOL_WAVES * PU) {
+        if (t0 != wave) {
+#pragma unroll
+            for (int u = 0; u < PU; ++u)
+                dgio<T, CPL>::ld(h + ((size_t)b * Tn + min(t0 + u * POOL_WAVES, Tn - 1)) * H + cc, live, v[u]);
         }
-    for (int c = blockIdx.y * POOL_THREADS + threadIdx.x; c < H; c += gridDim.y * POOL_THREADS) {
-        float acc[3];
-        int arg[3] = {0, 0, 0};
 #pragma unroll
-        for (int k = 0; k < 3; ++k) acc[k] = type == 0 ? -INFINITY : 0.0f;
-        for (int t = 0; t < Tn; ++t) {
-            const float v = io<T>::load1(h + ((size_t)b * Tn + t) * H + c);
+        for (int u = 0; u < PU; ++u) {
+            const int t = t0 + u * POOL_WAVES;
+            if (t >= Tn) break;                                              // wave-uniform
             const int m = mbits[t];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                if (type == 0) {
-                    const float x = (m >> k & 1) ? POOL_NEG : v;         // masked_fill(mask, -1e12), gcn.py:476
-                    if (x > acc[k]) { acc[k] = x; arg[k] = t; }           // strict: the FIRST maximum wins
-                } else {
-                    acc[k] += (m >> k & 1) ? 0.0f : v;
+                const bool masked = m >> k & 1;
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) {
+                    if (type == 0) {
+                        const float x = masked ? POOL_NEG : v[u][j];         // masked_fill(mask, -1e12), gcn.py:476
+                        if (x > acc[k][j]) { acc[k][j] = x; arg[k][j] = t; }
+                    } else {
+                        acc[k][j] += masked ? 0.0f : v[u][j];
+                    }
                 }
             }
         }
+    }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            float r = acc[k];
-            if (type == 1) r = r / (float)unmasked[k];                     // gcn.py:480 (0/0 = nan when everything is masked, as there)
-            out[(size_t)b * 3 * H + (size_t)k * H + c] = r;
-            if (argmax) argmax[((size_t)b * 3 + k) * H + c] = arg[k];
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) { red[wave][k][lane * CPL + j] = acc[k][j]; redarg[wave][k][lane * CPL + j] = arg[k][j]; }
+    __syncthreads();
+    for (int q = tid; q < 3 * WAVE * CPL; q += POOL_THREADS) {
+        const int k = q / (WAVE * CPL), cl = q - k * (WAVE * CPL);
+        const int c = blockIdx.y * WAVE * CPL + cl;
+        if (c >= H) continue;
+        float r = red[0][k][cl];
+        int a = redarg[0][k][cl];
+#pragma unroll
+        for (int w = 1; w < POOL_WAVES; ++w) {
+            const float x = red[w][k][cl];
+            const int ax = redarg[w][k][cl];
+            if (type == 0) {
+                if (x > r || (x == r && ax < a)) { r = x; a = ax; }
+            } else {
+                r += x;
+            }
         }
+        if (type == 1) r = r / (float)s_cnt[k];                       // gcn.py:480 (0/0 = nan when everything is masked, as there)
+        out[(size_t)b * 3 * H + (size_t)k * H + c] = r;
+        if (argmax) argmax[((size_t)b * 3 + k) * H + c] = a;
     }
 }
 
-template <typename T>
+// Backward: dh is written completely (masked tokens get 0, as masked_fill blocks their gradient), a wave per token.
+template <typename T, int CPL>
 __global__ __launch_bounds__(POOL_THREADS) void pool3_bwd_kernel(const float* __restrict__ g, const int32_t* __restrict__ argmax,
                                                                 const uint8_t* __restrict__ pool_mask, const int64_t* __restrict__ subj_pos,
                                                                 const int64_t* __restrict__ obj_pos, int Tn, int H, int type,
                                                                 T* __restrict__ dh) {
     extern __shared__ int mbits[];
-    const int b = blockIdx.x;
-    for (int t = threadIdx.x; t < Tn; t += POOL_THREADS) mbits[t] = pool_mask_bits(pool_mask, subj_pos, obj_pos, (size_t)b * Tn + t);
+    __shared__ int s_cnt[3];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 3) s_cnt[tid] = 0;
     __syncthreads();
-    float inv[3] = {1.0f, 1.0f, 1.0f};
-    if (type == 1) {
-        int unmasked[3] = {0, 0, 0};
-        for (int t = 0; t < Tn; ++t) {
+    for (int t = tid; t < Tn; t += POOL_THREADS) {
+        const int m = pool_mask_bits(pool_mask, subj_pos, obj_pos, (size_t)b * Tn + t);
+        mbits[t] = m;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) unmasked[k] += (mbits[t] >> k & 1) ? 0 : 1;
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) inv[k] = 1.0f / (float)unmasked[k];
+        for (int k = 0; k < 3; ++k)
+            if (!(m >> k & 1)) atomicAdd(&s_cnt[k], 1);
     }
-    for (int c = blockIdx.y * POOL_THREADS + threadIdx.x; c < H; c += gridDim.y * POOL_THREADS) {
-        float gk[3];
-        int ak[3] = {0, 0, 0};
+    __syncthreads();
+    const int c0 = (blockIdx.y * WAVE + lane) * CPL;
+    const int cc = min(c0, H - CPL), live = c0 < H;
+    float gk[3][CPL];
+    int ak[3][CPL];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            gk[k] = g[(size_t)b * 3 * H + (size_t)k * H + c] * inv[k];
-            if (type == 0) ak[k] = argmax[((size_t)b * 3 + k) * H + c];
+    for (int k = 0; k < 3; ++k) {
+        const float inv = type == 1 ? 1.0f / (float)s_cnt[k] : 1.0f;
+        dgio<float, CPL>::ld(g + (size_t)b * 3 * H + (size_t)k * H + cc, live, gk[k]);
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            gk[k][j] *= inv;
+            ak[k][j] = type == 0 ? argmax[((size_t)b * 3 + k) * H + min(cc + j, H - 1)] : 0;
         }
-        for (int t = 0; t < Tn; ++t) {
-            const int m = mbits[t];
-            float s = 0.0f;
+    }
+    for (int t = wave; t < Tn; t += POOL_WAVES) {
+        const int m = mbits[t];
+        float s[CPL];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            s[j] = 0.0f;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const bool on = !(m >> k & 1) && (type != 0 || ak[k] == t);     // masked positions never receive gradient
-                s += on ? gk[k] : 0.0f;
+                const bool on = !(m >> k & 1) && (type != 0 || ak[k][j] == t);     // masked positions never receive gradient
+                s[j] += on ? gk[k][j] : 0.0f;
             }
-            io<T>::store1(dh + ((size_t)b * Tn + t) * H + c, s);
         }
+        if (live) dgio<T, CPL>::st(dh + ((size_t)b * Tn + t) * H + cc, live, s);
     }
 }
 
@@ -108,12 +166,17 @@ extern "C" int gcnpt_pool3_fwd(void* stream, const void* h, int h_dtype, const u
     GCNPT_REQUIRE(h && pool_mask && subj_pos && obj_pos && out, "pool3_fwd: null pointer");
     GCNPT_REQUIRE(B > 0 && T > 0 && H > 0 && dtype_ok(h_dtype) && type >= 0 && type <= 2, "pool3_fwd: bad argument");
     GCNPT_REQUIRE(type != 0 || argmax, "pool3_fwd: max pooling needs the argmax buffer");
-    const dim3 grid(B, std::max(1, std::min(ceil_div(H, POOL_THREADS), 8)));
     hipStream_t s = (hipStream_t)stream;
-    if (h_dtype == GCNPT_F32)
-        hipLaunchKernelGGL(pool3_fwd_kernel<float>, grid, dim3(POOL_THREADS), sizeof(int) * T, s, (const float*)h, pool_mask, subj_pos, obj_pos, T, H, type, out, argmax);
-    else
-        hipLaunchKernelGGL(pool3_fwd_kernel<bf16_t>, grid, dim3(POOL_THREADS), sizeof(int) * T, s, (const bf16_t*)h, pool_mask, subj_pos, obj_pos, T, H, type, out, argmax);
+    const bool vec = H % 4 == 0 && aligned16(h);
+    const dim3 grid(B, ceil_div(H, WAVE * (vec ? 4 : 1)));
+    const size_t lds = sizeof(int) * T;
+    if (h_dtype == GCNPT_F32) {
+        if (vec) hipLaunchKernelGGL((pool3_fwd_kernel<float, 4>), grid, dim3(POOL_THREADS), lds, s, (const float*)h, pool_mask, subj_pos, obj_pos, T, H, type, out, argmax);
+        else hipLaunchKernelGGL((pool3_fwd_kernel<float, 1>), grid, dim3(POOL_THREADS), lds, s, (const float*)h, pool_mask, subj_pos, obj_pos, T, H, type, out, argmax);
+    } else {
+        if (vec) hipLaunchKernelGGL((pool3_fwd_kernel<bf16_t, 4>), grid, dim3(POOL_THREADS), lds, s, (const bf16_t*)h, pool_mask, subj_pos, obj_pos, T, H, type, out, argmax);
+        else hipLaunchKernelGGL((pool3_fwd_kernel<bf16_t, 1>), grid, dim3(POOL_THREADS), lds, s, (const bf16_t*)h, pool_mask, subj_pos, obj_pos, T, H, type, out, argmax);
+    }
     GCNPT_HIP_CHECK(hipGetLastError());
     return GCNPT_OK;
 }
@@ -123,12 +186,17 @@ extern "C" int gcnpt_pool3_bwd(void* stream, const float* g, const int32_t* argm
     GCNPT_REQUIRE(g && pool_mask && subj_pos && obj_pos && dh, "pool3_bwd: null pointer");
     GCNPT_REQUIRE(B > 0 && T > 0 && H > 0 && dtype_ok(dh_dtype) && type >= 0 && type <= 2, "pool3_bwd: bad argument");
     GCNPT_REQUIRE(type != 0 || argmax, "pool3_bwd: max pooling needs the argmax buffer");
-    const dim3 grid(B, std::max(1, std::min(ceil_div(H, POOL_THREADS), 8)));
     hipStream_t s = (hipStream_t)stream;
-    if (dh_dtype == GCNPT_F32)
-        hipLaunchKernelGGL(pool3_bwd_kernel<float>, grid, dim3(POOL_THREADS), sizeof(int) * T, s, g, argmax, pool_mask, subj_pos, obj_pos, T, H, type, (float*)dh);
-    else
-        hipLaunchKernelGGL(pool3_bwd_kernel<bf16_t>, grid, dim3(POOL_THREADS), sizeof(int) * T, s, g, argmax, pool_mask, subj_pos, obj_pos, T, H, type, (bf16_t*)dh);
+    const bool vec = H % 4 == 0 && aligned16(dh) && aligned16(g);
+    const dim3 grid(B, ceil_div(H, WAVE * (vec ? 4 : 1)));
+    const size_t lds = sizeof(int) * T;
+    if (dh_dtype == GCNPT_F32) {
+        if (vec) hipLaunchKernelGGL((pool3_bwd_kernel<float, 4>), grid, dim3(POOL_THREADS), lds, s, g, argmax, pool_mask, subj_pos, obj_pos, T, H, type, (float*)dh);
+        else hipLaunchKernelGGL((pool3_bwd_kernel<float, 1>), grid, dim3(POOL_THREADS), lds, s, g, argmax, pool_mask, subj_pos, obj_pos, T, H, type, (float*)dh);
+    } else {
+        if (vec) hipLaunchKernelGGL((pool3_bwd_kernel<bf16_t, 4>), grid, dim3(POOL_THREADS), lds, s, g, argmax, pool_mask, subj_pos, obj_pos, T, H, type, (bf16_t*)dh);
+        else hipLaunchKernelGGL((pool3_bwd_kernel<bf16_t, 1>), grid, dim3(POOL_THREADS), lds, s, g, argmax, pool_mask, subj_pos, obj_pos, T, H, type, (bf16_t*)dh);
+    }
     GCNPT_HIP_CHECK(hipGetLastError());
     return GCNPT_OK;
 }

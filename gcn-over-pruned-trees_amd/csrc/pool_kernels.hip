@@ -9,8 +9,10 @@
 
 namespace gcnpt {
 
-constexpr int POOL_THREADS = 512;                       // 8 waves take every 8th token; a lane owns CPL consecutive columns
+constexpr int POOL_THREADS = 512;
 constexpr int POOL_WAVES = POOL_THREADS / WAVE;
+constexpr int POOL_LANES = 16;                           // lanes across the columns of a workgroup (x CPL columns each)
+constexpr int POOL_STREAMS = POOL_THREADS / POOL_LANES;  // 32 token streams: stream s takes tokens s, s + 32, ...
 constexpr float POOL_NEG = -1e12f;     // utils/constant.py:35 INFINITY_NUMBER
 
 // bit k of the result = token t is MASKED for pooling k (0: pool_mask, 1: not a subject token, 2: not an object token)
@@ -18,27 +20,28 @@ __device__ __forceinline__ int pool_mask_bits(const uint8_t* pm, const int64_t* 
     return (pm[i] ? 1 : 0) | (sp[i] != 0 ? 2 : 0) | (op[i] != 0 ? 4 : 0);
 }
 
-// Forward: every wave reduces its tokens for its columns with all loads of the pass in flight, the 8 partial results meet in
-// LDS.  max keeps the FIRST maximum (torch.max(dim) on the CPU reference): strict > inside a wave (tokens ascending), ties
-// between waves go to the smaller token.
+// A workgroup owns 16 x CPL columns of one sentence (grid B x ceil(H / (16 CPL)): 200 workgroups at B=50, H=200, so that the
+// read of h is spread over the CUs -- one CU sustains only ~30 GB/s from HBM).  Its 512 threads form 32 token streams; all
+// loads of a sentence of up to 128 tokens are issued before the masks are read.  The streams of a wave meet by shuffles, the
+// waves in LDS.  max keeps the FIRST maximum (torch.max(dim) on the CPU reference): strict > along a stream (tokens
+// ascending), ties between streams go to the smaller token.
 template <typename T, int CPL>
 __global__ __launch_bounds__(POOL_THREADS) void pool3_fwd_kernel(const T* __restrict__ h, const uint8_t* __restrict__ pool_mask,
                                                                 const int64_t* __restrict__ subj_pos, const int64_t* __restrict__ obj_pos,
                                                                 int Tn, int H, int type, float* __restrict__ out, int32_t* __restrict__ argmax) {
     extern __shared__ int mbits[];                       // [Tn]
-    __shared__ float red[POOL_WAVES][3][WAVE * CPL];
-    __shared__ int redarg[POOL_WAVES][3][WAVE * CPL];
+    __shared__ float red[POOL_WAVES][3][POOL_LANES * CPL];
+    __shared__ int redarg[POOL_WAVES][3][POOL_LANES * CPL];
     __shared__ int s_cnt[3];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c0 = (blockIdx.y * WAVE + lane) * CPL;
+    const int cl = lane & (POOL_LANES - 1), stream = tid / POOL_LANES;
+    const int c0 = (blockIdx.y * POOL_LANES + cl) * CPL;
     const int cc = min(c0, H - CPL), live = c0 < H;
-    // tokens per round: their loads are issued together (clamped, no condition).  The first round -- all of a sentence of up to
-    // 128 tokens -- goes out before the masks are even looked at, so the kernel is two memory round trips deep
-    constexpr int PU = 16;
+    constexpr int PU = 4;                                // tokens per stream per round
     float v[PU][CPL];
 #pragma unroll
     for (int u = 0; u < PU; ++u)
-        dgio<T, CPL>::ld(h + ((size_t)b * Tn + min(wave + u * POOL_WAVES, Tn - 1)) * H + cc, live, v[u]);
+        dgio<T, CPL>::ld(h + ((size_t)b * Tn + min(stream + u * POOL_STREAMS, Tn - 1)) * H + cc, live, v[u]);
     if (tid < 3) s_cnt[tid] = 0;
     __syncthreads();
     for (int t = tid; t < Tn; t += POOL_THREADS) {
@@ -54,18 +57,18 @@ __global__ __launch_bounds__(POOL_THREADS) void pool3_fwd_kernel(const T* __rest
 #pragma unroll
     for (int k = 0; k < 3; ++k)
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) { acc[k][j] = type == 0 ? -INFINITY : 0.0f; arg[k][j] = 0; }
-    for (int t0 = wave; t0 < Tn; t0 += POOL_WAVES * PU) {
-        if (t0 != wave) {
+        for (int j = 0; j < CPL; ++j) { acc[k][j] = type == 0 ? -INFINITY : 0.0f; arg[k][j] = 0x7fffffff; }
+    for (int t0 = stream; t0 < Tn; t0 += POOL_STREAMS * PU) {
+        if (t0 != stream) {
 #pragma unroll
             for (int u = 0; u < PU; ++u)
-                dgio<T, CPL>::ld(h + ((size_t)b * Tn + min(t0 + u * POOL_WAVES, Tn - 1)) * H + cc, live, v[u]);
+                dgio<T, CPL>::ld(h + ((size_t)b * Tn + min(t0 + u * POOL_STREAMS, Tn - 1)) * H + cc, live, v[u]);
         }
 #pragma unroll
         for (int u = 0; u < PU; ++u) {
-            const int t = t0 + u * POOL_WAVES;
-            if (t >= Tn) break;                                              // wave-uniform
-            const int m = mbits[t];
+            const int t = t0 + u * POOL_STREAMS;
+            const bool have = t < Tn;
+            const int m = mbits[min(t, Tn - 1)];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const bool masked = m >> k & 1;
@@ -73,29 +76,42 @@ __global__ __launch_bounds__(POOL_THREADS) void pool3_fwd_kernel(const T* __rest
                 for (int j = 0; j < CPL; ++j) {
                     if (type == 0) {
                         const float x = masked ? POOL_NEG : v[u][j];         // masked_fill(mask, -1e12), gcn.py:476
-                        if (x > acc[k][j]) { acc[k][j] = x; arg[k][j] = t; }
+                        if (have && x > acc[k][j]) { acc[k][j] = x; arg[k][j] = t; }
                     } else {
-                        acc[k][j] += masked ? 0.0f : v[u][j];
+                        acc[k][j] += (have && !masked) ? v[u][j] : 0.0f;
                     }
                 }
             }
         }
     }
+    // the 4 streams of a wave (lanes 16 apart), then the 8 waves
 #pragma unroll
     for (int k = 0; k < 3; ++k)
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) { red[wave][k][lane * CPL + j] = acc[k][j]; redarg[wave][k][lane * CPL + j] = arg[k][j]; }
+        for (int j = 0; j < CPL; ++j) {
+#pragma unroll
+            for (int d = POOL_LANES; d < WAVE; d <<= 1) {
+                const float x = __shfl_xor(acc[k][j], d);
+                const int ax = __shfl_xor(arg[k][j], d);
+                if (type == 0) {
+                    if (x > acc[k][j] || (x == acc[k][j] && ax < arg[k][j])) { acc[k][j] = x; arg[k][j] = ax; }
+                } else {
+                    acc[k][j] += x;
+                }
+            }
+            if (lane < POOL_LANES) { red[wave][k][cl * CPL + j] = acc[k][j]; redarg[wave][k][cl * CPL + j] = arg[k][j]; }
+        }
     __syncthreads();
-    for (int q = tid; q < 3 * WAVE * CPL; q += POOL_THREADS) {
-        const int k = q / (WAVE * CPL), cl = q - k * (WAVE * CPL);
-        const int c = blockIdx.y * WAVE * CPL + cl;
+    for (int q = tid; q < 3 * POOL_LANES * CPL; q += POOL_THREADS) {
+        const int k = q / (POOL_LANES * CPL), cq = q - k * (POOL_LANES * CPL);
+        const int c = blockIdx.y * POOL_LANES * CPL + cq;
         if (c >= H) continue;
-        float r = red[0][k][cl];
-        int a = redarg[0][k][cl];
+        float r = red[0][k][cq];
+        int a = redarg[0][k][cq];
 #pragma unroll
         for (int w = 1; w < POOL_WAVES; ++w) {
-            const float x = red[w][k][cl];
-            const int ax = redarg[w][k][cl];
+            const float x = red[w][k][cq];
+            const int ax = redarg[w][k][cq];
             if (type == 0) {
                 if (x > r || (x == r && ax < a)) { r = x; a = ax; }
             } else {
@@ -104,11 +120,11 @@ __global__ __launch_bounds__(POOL_THREADS) void pool3_fwd_kernel(const T* __rest
         }
         if (type == 1) r = r / (float)s_cnt[k];                       // gcn.py:480 (0/0 = nan when everything is masked, as there)
         out[(size_t)b * 3 * H + (size_t)k * H + c] = r;
-        if (argmax) argmax[((size_t)b * 3 + k) * H + c] = a;
+        if (argmax) argmax[((size_t)b * 3 + k) * H + c] = a == 0x7fffffff ? 0 : a;
     }
 }
 
-// Backward: dh is written completely (masked tokens get 0, as masked_fill blocks their gradient), a wave per token.
+// Backward: dh is written completely (masked tokens get 0, as masked_fill blocks their gradient); same workgroup shape.
 template <typename T, int CPL>
 __global__ __launch_bounds__(POOL_THREADS) void pool3_bwd_kernel(const float* __restrict__ g, const int32_t* __restrict__ argmax,
                                                                 const uint8_t* __restrict__ pool_mask, const int64_t* __restrict__ subj_pos,
@@ -116,7 +132,18 @@ __global__ __launch_bounds__(POOL_THREADS) void pool3_bwd_kernel(const float* __
                                                                 T* __restrict__ dh) {
     extern __shared__ int mbits[];
     __shared__ int s_cnt[3];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int cl = lane & (POOL_LANES - 1), stream = tid / POOL_LANES;
+    const int c0 = (blockIdx.y * POOL_LANES + cl) * CPL;
+    const int cc = min(c0, H - CPL), live = c0 < H;
+    float gk[3][CPL];
+    int ak[3][CPL];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        dgio<float, CPL>::ld(g + (size_t)b * 3 * H + (size_t)k * H + cc, live, gk[k]);
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) ak[k][j] = type == 0 ? argmax[((size_t)b * 3 + k) * H + min(cc + j, H - 1)] : 0;
+    }
     if (tid < 3) s_cnt[tid] = 0;
     __syncthreads();
     for (int t = tid; t < Tn; t += POOL_THREADS) {
@@ -127,21 +154,15 @@ __global__ __launch_bounds__(POOL_THREADS) void pool3_bwd_kernel(const float* __
             if (!(m >> k & 1)) atomicAdd(&s_cnt[k], 1);
     }
     __syncthreads();
-    const int c0 = (blockIdx.y * WAVE + lane) * CPL;
-    const int cc = min(c0, H - CPL), live = c0 < H;
-    float gk[3][CPL];
-    int ak[3][CPL];
+    if (type == 1) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float inv = type == 1 ? 1.0f / (float)s_cnt[k] : 1.0f;
-        dgio<float, CPL>::ld(g + (size_t)b * 3 * H + (size_t)k * H + cc, live, gk[k]);
+        for (int k = 0; k < 3; ++k) {
+            const float inv = 1.0f / (float)s_cnt[k];
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) {
-            gk[k][j] *= inv;
-            ak[k][j] = type == 0 ? argmax[((size_t)b * 3 + k) * H + min(cc + j, H - 1)] : 0;
+            for (int j = 0; j < CPL; ++j) gk[k][j] *= inv;
         }
     }
-    for (int t = wave; t < Tn; t += POOL_WAVES) {
+    for (int t = stream; t < Tn; t += POOL_STREAMS) {
         const int m = mbits[t];
         float s[CPL];
 #pragma unroll
@@ -168,7 +189,7 @@ extern "C" int gcnpt_pool3_fwd(void* stream, const void* h, int h_dtype, const u
     GCNPT_REQUIRE(type != 0 || argmax, "pool3_fwd: max pooling needs the argmax buffer");
     hipStream_t s = (hipStream_t)stream;
     const bool vec = H % 4 == 0 && aligned16(h);
-    const dim3 grid(B, ceil_div(H, WAVE * (vec ? 4 : 1)));
+    const dim3 grid(B, ceil_div(H, POOL_LANES * (vec ? 4 : 1)));
     const size_t lds = sizeof(int) * T;
     if (h_dtype == GCNPT_F32) {
         if (vec) hipLaunchKernelGGL((pool3_fwd_kernel<float, 4>), grid, dim3(POOL_THREADS), lds, s, (const float*)h, pool_mask, subj_pos, obj_pos, T, H, type, out, argmax);
@@ -188,7 +209,7 @@ extern "C" int gcnpt_pool3_bwd(void* stream, const float* g, const int32_t* argm
     GCNPT_REQUIRE(type != 0 || argmax, "pool3_bwd: max pooling needs the argmax buffer");
     hipStream_t s = (hipStream_t)stream;
     const bool vec = H % 4 == 0 && aligned16(dh) && aligned16(g);
-    const dim3 grid(B, ceil_div(H, WAVE * (vec ? 4 : 1)));
+    const dim3 grid(B, ceil_div(H, POOL_LANES * (vec ? 4 : 1)));
     const size_t lds = sizeof(int) * T;
     if (dh_dtype == GCNPT_F32) {
         if (vec) hipLaunchKernelGGL((pool3_bwd_kernel<float, 4>), grid, dim3(POOL_THREADS), lds, s, g, argmax, pool_mask, subj_pos, obj_pos, T, H, type, (float*)dh);

@@ -33,6 +33,10 @@ SIGNATURES = {
     "gcnpt_diag_layer_fwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p, _f, _u64, _p]),
     "gcnpt_diag_layer_bwd": (_i, [_p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _f]),
     "gcnpt_gather_trees": (_i, [_p] * 11 + [_i, _i, _i, _p, _i, _i, _i] + [_p] * 9),
+    "gcnpt_bilinear_packed_bytes": (_sz, [_i, _i, _i]),
+    "gcnpt_bilinear_supported": (_i, [_i, _i, _i]),
+    "gcnpt_bilinear_pack": (_i, [_p, _p, _i, _i, _i, _p]),
+    "gcnpt_bilinear_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "gcnpt_stack_supported": (_i, [_i, _i, _i, _i, _i]),
     "gcnpt_stack_frag_bytes": (_sz, [_i, _i, _i]),
     "gcnpt_stack_fwd": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p]),

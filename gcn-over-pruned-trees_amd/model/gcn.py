@@ -504,7 +504,8 @@ class GCN(nn.Module):
         return x.float(), trees.pool_mask
 
     def _forward_full(self, adj, gcn_inputs, deprel):
-        """adj_type='full_deprel', gcn.py:296-388 + traverse_deprel / traverse_self_loop 400-434, fp32.
+        """adj_type='full_deprel', gcn.py:296-388 + traverse_deprel / traverse_self_loop 400-434; fp32, or with
+        opt['gcn_dtype']='bf16' the traversal's contraction on csrc/bilinear_kernels.hip (bf16 MFMA operands, fp32 accumulate).
         trav(x, e)[n] = sum_d e[n,d] (x[n] W3[d] + b3[d]) is only needed for tokens that sit in a pruned tree, so those are
         compacted (one host sync for their number), their outer products e (x) x meet W3 as [D*Tin, H] in ONE library GEMM per
         direction, and the results travel along the CSR entries of the device pruner (value ranges pick forward / reverse).
@@ -555,7 +556,10 @@ class GCN(nn.Module):
                     e = torch.where(kept, e, torch.ones_like(e))
                 if plain:
                     e = torch.ones_like(e)
-                y = torch.mm((e.unsqueeze(2) * xt.unsqueeze(1)).reshape(-1, D * Tin), Wk) + torch.mm(e, b3)     # gcn.py:408-414
+                if self.compute_dtype == torch.bfloat16 and bilinear_supported(D, Tin, H):
+                    y = bilinear_traverse(xt, e, self.W.weight, self.W.bias)                      # hand-written MFMA contraction
+                else:
+                    y = torch.mm((e.unsqueeze(2) * xt.unsqueeze(1)).reshape(-1, D * Tin), Wk) + torch.mm(e, b3)     # gcn.py:408-414
                 w = edges.to(torch.float32)
                 edge_keep = opt.get('edge_keep_prob', 1.0)
                 if self.training and edge_keep < 1.0:                                             # maybe_drop_edges, gcn.py:436-449
@@ -602,6 +606,61 @@ class GCN(nn.Module):
             return gcn_stack(x, Ws, bs, trees, ps, seeds, torch.float32, no_adj, seed_dev), trees.pool_mask
         x = gcn_layers(x, Ws, bs, trees, ps, seeds, self.compute_dtype, torch.float32, no_adj, seed_dev)
         return x, trees.pool_mask
+
+
+class _BilinearFn(torch.autograd.Function):
+    """y = sum_d e[:,d] * (x @ W3[d]) + e @ b3 (reference traverse_deprel, model/gcn.py:400-415) with the forward contraction on
+    csrc/bilinear_kernels.hip (bf16 MFMA operands, fp32 accumulate).  The op is linear in each argument, so the backward needs
+    nothing from the forward's result; it is three library GEMMs in fp32."""
+
+    @staticmethod
+    def forward(ctx, xt, e, weight, bias):
+        M, Tin = xt.shape
+        D = e.shape[1]
+        H = weight.shape[0] // D
+        lib, st, dev = _lib.lib(), _lib.stream(), xt.device
+        w32 = weight.detach().to(torch.float32).contiguous()
+        img = torch.empty((lib.gcnpt_bilinear_packed_bytes(D, Tin, H),), dtype=torch.uint8, device=dev)
+        _lib.check(lib.gcnpt_bilinear_pack(st, _lib.ptr(w32), D, Tin, H, _lib.ptr(img)))
+        Tpad = (Tin + 31) // 32 * 32
+        xb = torch.zeros((M, Tpad), dtype=torch.bfloat16, device=dev)
+        xb[:, :Tin] = xt.detach()
+        e32 = e.detach().to(torch.float32).contiguous()
+        y = torch.mm(e32, bias.detach().to(torch.float32).reshape(D, H))                  # gcn.py:413, the kernel adds the rest
+        _lib.check(lib.gcnpt_bilinear_fwd(st, _lib.ptr(xb), _lib.ptr(e32), _lib.ptr(img), M, D, Tin, H, _lib.ptr(y)))
+        ctx.save_for_backward(xt, e, weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xt, e, weight, bias = ctx.saved_tensors
+        M, Tin = xt.shape
+        D = e.shape[1]
+        H = weight.shape[0] // D
+        gy = gy.to(torch.float32).contiguous()
+        x32, e32 = xt.to(torch.float32), e.to(torch.float32)
+        Wk = weight.to(torch.float32).reshape(D * Tin, H)
+        G = torch.mm(gy, Wk.t()).view(M, D, Tin)
+        dx = (G * e32.unsqueeze(2)).sum(1) if ctx.needs_input_grad[0] else None
+        de = ((G * x32.unsqueeze(1)).sum(2) + torch.mm(gy, bias.to(torch.float32).reshape(D, H).t())) if ctx.needs_input_grad[1] else None
+        dW = db = None
+        if ctx.needs_input_grad[2]:
+            dW = torch.mm((e32.unsqueeze(2) * x32.unsqueeze(1)).reshape(M, D * Tin).t(), gy).reshape(weight.shape).to(weight.dtype)
+        if ctx.needs_input_grad[3]:
+            db = torch.mm(e32.t(), gy).reshape(-1).to(bias.dtype)
+        return dx, de, dW, db
+
+
+def bilinear_traverse(xt, e, weight, bias):
+    """traverse_deprel of the reference for M compacted token rows: xt [M,Tin], e [M,D] relation vectors, weight [D*H,Tin] and
+    bias [D*H] of the shared nn.Linear (read as W3 [D,Tin,H] / b3 [D,H], gcn.py:301-303).  float32 [M,H]."""
+    for t in (xt, e, weight, bias):
+        _lib.require_gpu(t)
+    return _BilinearFn.apply(xt, e, weight, bias)
+
+
+def bilinear_supported(D, Tin, H):
+    return bool(_lib.lib().gcnpt_bilinear_supported(int(D), int(Tin), int(H)))
 
 
 def _zero_pad_row(grad):

@@ -838,6 +838,34 @@ def _run_full(api, dev, g, c, trees_from="pruner"):
     return dict(h=f(h), mask=f(mask), dx=f(x.grad), dW=f(net.W.weight.grad), db=f(net.W.bias.grad), dE=dE)
 
 
+@pytest.mark.parametrize("M,D,Tin,H", [(1000, 50, 200, 200), (37, 6, 24, 24), (130, 16, 64, 72), (65, 9, 250, 40), (300, 200, 96, 200)])
+def test_bilinear_traverse_kernel(api, dev, M, D, Tin, H):
+    """gcnpt_bilinear_fwd (bf16 MFMA operands, fp32 accumulate) against the fp32 einsum of the reference's traverse_deprel
+    (gcn.py:408-414), and its library-GEMM backward against autograd of that einsum."""
+    gcn, _ = api
+    rng = np.random.RandomState(M + D)
+    mk = lambda *shape: torch.from_numpy(rng.uniform(-1, 1, size=shape).astype(np.float32)).to(dev).requires_grad_()  # noqa: E731
+    x, e, W, b = mk(M, Tin), mk(M, D), mk(D * H, Tin), mk(D * H)
+    gy = torch.from_numpy(rng.standard_normal((M, H)).astype(np.float32)).to(dev)
+
+    def ref(x, e, W, b):
+        W3, b3 = W.reshape(D, Tin, H), b.reshape(D, H)
+        return torch.einsum("md,mt,dth->mh", e, x, W3) + e @ b3
+    want = ref(x, e, W, b)
+    want.backward(gy)
+    grads = [t.grad.clone() for t in (x, e, W, b)]
+    for t in (x, e, W, b):
+        t.grad = None
+    got = gcn.bilinear_traverse(x, e, W, b)
+    got.backward(gy)
+    assert max_rel(got.detach().cpu().numpy(), want.detach().cpu().numpy()) <= 1e-2          # bf16 operands
+    # the same against the fp32 einsum of bf16-rounded operands: only the accumulation order is left
+    rb = lambda t: t.detach().to(torch.bfloat16).float()  # noqa: E731
+    assert max_rel(got.detach().cpu().numpy(), (ref(rb(x), e.detach(), rb(W), b.detach())).cpu().numpy()) <= 2e-5
+    for t, g in zip((x, e, W, b), grads):
+        assert max_rel(t.grad.cpu().numpy(), g.cpu().numpy()) <= 2e-5
+
+
 def test_full_deprel_golden(api, dev):
     """fp32 against outputs and gradients recorded from the reference's GCN(adj_type='full_deprel'), four option sets."""
     import json
@@ -962,6 +990,13 @@ def test_classifier_end_to_end_golden_variants(api, dev, tag):
         logits, pooled = model(inputs)
     assert max_rel(logits.cpu().numpy(), g["logits"]) <= 1e-4
     assert max_rel(pooled.cpu().numpy(), g["pooling_output"]) <= 1e-4
+    if tag == "full":               # the traversal's contraction on the hand-written MFMA kernel
+        m16 = gcn.GCNClassifier(dict(opt, gcn_dtype="bf16"))
+        m16.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd:")}, strict=True)
+        m16.to(dev).eval()
+        with torch.no_grad():
+            l16, _ = m16(inputs)
+        assert max_rel(l16.cpu().numpy(), g["logits"]) <= 3e-2
     model.train()
     logits, pooled = model(inputs)
     (logits.logsumexp(1).mean() + 0.003 * (pooled ** 2).sum(1).mean()).backward()

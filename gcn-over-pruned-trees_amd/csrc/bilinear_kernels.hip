@@ -9,6 +9,10 @@
 //     the whole kernel, its 4 waves take every 4th relation of the slice, weight fragments of the next relation are in
 //     flight while the current one is multiplied; waves meet in LDS, slices with fp32 atomics (y is accumulated: the caller
 //     initialises it, e.g. with the bias term e @ b3).
+// (Measured and dropped: 256-token workgroups whose 4 waves share each relation's weight fragments through LDS, fetched with
+// direct global-to-LDS loads one relation ahead -- a quarter of the L2 traffic, but 95 us instead of 69 at M=1200, D=200: with a
+// single relation in flight per workgroup the MFMAs of a relation (0.6 us) are shorter than the fetch of the next one, while
+// here the 4 waves keep 4 independent streams in flight.  A 3-4 deep LDS ring with counted waits is the next step.)
 // Weights are packed once per step into MFMA fragment order: image[n_tile][d * TS + ts][lane] x 16 bytes, TS = ceil(Tin / 32),
 // every relation padded to TS k-steps, lane l of a fragment = 8 values W3[d][32 ts + 8 (l >> 4) + j][16 n_tile + (l & 15)].
 #include "layer_common.h"

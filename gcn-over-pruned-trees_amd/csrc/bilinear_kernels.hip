@@ -191,8 +191,11 @@ extern "C" int gcnpt_bilinear_fwd(void* stream, const void* x, const float* e, c
     p.x = static_cast<const bf16_t*>(x); p.e = e; p.img = static_cast<const uint4*>(w_img); p.y = y;
     p.M = M; p.D = D; p.H = H; p.TS = ceil_div(Tin, 32); p.n_tiles = ceil_div(H, 16);
     p.mb = ceil_div(M, 16 * BL_MT); p.nb = ceil_div(p.n_tiles, BL_NT);
-    // relation slices: ~2 workgroups per CU in flight is the most that helps (one is resident per CU), each wave at least 2 relations
-    int slices = std::max(1, std::min(512 / std::max(1, p.mb * p.nb), D / (2 * BL_WAVES)));
+    // relation slices: about one workgroup per CU, each wave at least 2 relations
+#ifndef GCNPT_BL_TARGET_WGS
+#define GCNPT_BL_TARGET_WGS 256     // measured: 256 beats 512 (56 vs 70 us at M=1200, D=200), 1024 and 2048 are far worse (float atomics + per-workgroup setup)
+#endif
+    int slices = std::max(1, std::min(GCNPT_BL_TARGET_WGS / std::max(1, p.mb * p.nb), D / (2 * BL_WAVES)));
     slices = std::max(1, std::min(slices, D));
     p.d_per_slice = ceil_div(D, slices);
     p.slices = ceil_div(D, p.d_per_slice);

@@ -35,6 +35,7 @@ SIGNATURES = {
     "gcnpt_gather_trees": (_i, [_p] * 11 + [_i, _i, _i, _p, _i, _i, _i] + [_p] * 9),
     "gcnpt_bilinear_packed_bytes": (_sz, [_i, _i, _i]),
     "gcnpt_bilinear_supported": (_i, [_i, _i, _i]),
+    "gcnpt_bilinear_planes": (_i, [_i, _i, _i, _i]),
     "gcnpt_bilinear_pack": (_i, [_p, _p, _i, _i, _i, _p]),
     "gcnpt_bilinear_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "gcnpt_stack_supported": (_i, [_i, _i, _i, _i, _i]),

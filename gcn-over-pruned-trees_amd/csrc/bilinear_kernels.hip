@@ -1,18 +1,13 @@
 // The relation-conditioned traversal of adj_type == 'full_deprel' (SURVEY.md 8f row N3): reference model/gcn.py:400-415
-//   y[m,:] += sum_d e[m,d] * (x[m,:] @ W3[d])          W3 = Linear.weight.reshape(D, Tin, H)   (gcn.py:301)
+//   y[m,:] = sum_d e[m,d] * (x[m,:] @ W3[d])           W3 = Linear.weight.reshape(D, Tin, H)   (gcn.py:301)
 // for the M tokens that sit in a pruned tree (compacted by the caller).  The reference materialises the outer product
 // e (x) x as [B,T,D,Tin] and contracts it with two einsums.  Here the per-relation products P_d = x @ W3[d] run on the
 // matrix cores (bf16 operands, fp32 accumulate) and are folded into the result with one fp32 FMA per accumulator register:
 //   * the MFMAs run with swapped operands (weights as A), so a lane holds ONE token row and 4 consecutive output columns:
 //     the scale e[m,d] is a single scalar per lane and tile;
-//   * a workgroup owns 64 tokens x 48 output columns and one slice of the relations; its x fragments stay in registers for
-//     the whole kernel, its 4 waves take every 4th relation of the slice, weight fragments of the next relation are in
-//     flight while the current one is multiplied; waves meet in LDS, slices with fp32 atomics (y is accumulated: the caller
-//     initialises it, e.g. with the bias term e @ b3).
-// (Measured and dropped: 256-token workgroups whose 4 waves share each relation's weight fragments through LDS, fetched with
-// direct global-to-LDS loads one relation ahead -- a quarter of the L2 traffic, but 95 us instead of 69 at M=1200, D=200: with a
-// single relation in flight per workgroup the MFMAs of a relation (0.6 us) are shorter than the fetch of the next one, while
-// here the 4 waves keep 4 independent streams in flight.  A 3-4 deep LDS ring with counted waits is the next step.)
+//   * a workgroup owns 256 tokens x 48 output columns and one slice of the relations; each wave keeps the x fragments of its 64
+//     tokens in registers for the whole kernel; the weight fragments of a relation come through a 4-deep LDS ring once per
+//     workgroup; every relation slice writes its own plane of the result, the caller sums the planes (and adds e @ b3).
 // Weights are packed once per step into MFMA fragment order: image[n_tile][d * TS + ts][lane] x 16 bytes, TS = ceil(Tin / 32),
 // every relation padded to TS k-steps, lane l of a fragment = 8 values W3[d][32 ts + 8 (l >> 4) + j][16 n_tile + (l & 15)].
 #include "layer_common.h"
@@ -50,26 +45,41 @@ struct BilinearParams {
     const bf16_t* x;        // [M, TS*32] bf16, zero padded
     const float* e;         // [M, D]
     const uint4* img;       // packed W3
-    float* y;               // [M, H], accumulated
+    float* y;               // [slices][M, H]: one plane per relation slice, written completely
     int M, D, H, TS, n_tiles, mb, nb, slices, d_per_slice;
 };
 
+// A workgroup owns 256 tokens (its 4 waves take 64 each: 4 token tiles whose x fragments stay in registers), 48 output columns
+// and one slice of the relations.  All waves walk the SAME relations: the 3 x TS weight fragments of a relation come from L2 ONCE
+// per workgroup, straight into LDS (global_load_lds, one 1-KiB fragment per wave-instruction, lane-linear on both sides), and feed
+// 16 MFMAs each.  The LDS ring holds 4 relations; three are in flight while one is multiplied: the wait at the top of a round is a
+// COUNTED s_waitcnt (two relations' loads of this wave may stay outstanding) and the barrier a raw s_barrier -- __syncthreads()
+// would drain the direct-to-LDS loads (they count as pending LDS writes) and with it the pipeline.
+constexpr int BL_ROWS = 16 * BL_MT * BL_WAVES;       // 256 token rows per workgroup
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+constexpr int BL_RING = 4;                           // relations in the LDS ring
+constexpr int BL_GL = (BL_NT * BL_TSMAX + BL_WAVES - 1) / BL_WAVES;      // direct-to-LDS loads per wave and relation: always 6
+constexpr int BL_FRAGS = BL_GL * BL_WAVES;           // fragment slots per ring entry (24 KiB), TS < 8 leaves some unused
+
 __global__ __launch_bounds__(BL_THREADS, 1) void bilinear_fwd_kernel(const BilinearParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char bl_smem[];
-    typedef f32x4_t RedTile[BL_MT * BL_NT][WAVE];
-    RedTile* red = reinterpret_cast<RedTile*>(bl_smem);                                  // [BL_WAVES], 12 KiB each
-    float* es = reinterpret_cast<float*>(bl_smem + sizeof(RedTile) * BL_WAVES);         // [d_per_slice][65]: e of the tile, transposed
+    extern __shared__ __attribute__((aligned(16))) unsigned char bl_smem[];              // ONE LDS object: ring | dummy | e tile
+    const int TS = p.TS, Tpad = TS * 32;
+    const int n_frag = BL_NT * TS;
+    uint4* wl = reinterpret_cast<uint4*>(bl_smem);                                       // [BL_RING][BL_FRAGS][64]
+    uint4* dummy = wl + (size_t)BL_RING * BL_FRAGS * 64;                                 // [BL_WAVES][64]: where unused slots' loads land
+    float* es = reinterpret_cast<float*>(dummy + BL_WAVES * 64);                         // [d_per_slice][BL_ROWS + 1]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int id = blockIdx.x;
     const int slice = id % p.slices, rest = id / p.slices;
     const int bm = rest % p.mb, bn = rest / p.mb;
-    const int m0 = bm * 16 * BL_MT, nt0 = bn * BL_NT;
+    const int m0 = bm * BL_ROWS + wave * 16 * BL_MT, nt0 = bn * BL_NT;
     const int d_lo = slice * p.d_per_slice, d_hi = min(p.D, d_lo + p.d_per_slice);
     const int nd = d_hi - d_lo;
-    const int TS = p.TS, Tpad = TS * 32;
-    const size_t d_stride = (size_t)p.D * TS;            // fragments (of 64 lanes) per output tile
+    const size_t d_stride = (size_t)p.D * TS;            // fragments per output tile in the image
 
-    // the tile's x fragments: lane (l & 15) = token row, 8 consecutive k per lane -- registers for the whole kernel
+    // this wave's x fragments: lane (l & 15) = token row, 8 consecutive k per lane -- registers for the whole kernel
     uint4 xf[BL_MT][BL_TSMAX];
 #pragma unroll
     for (int mt = 0; mt < BL_MT; ++mt) {
@@ -78,23 +88,42 @@ __global__ __launch_bounds__(BL_THREADS, 1) void bilinear_fwd_kernel(const Bilin
         for (int ts = 0; ts < BL_TSMAX; ++ts)
             xf[mt][ts] = *reinterpret_cast<const uint4*>(p.x + row * Tpad + min(ts, TS - 1) * 32 + 8 * (lane >> 4));
     }
-    // this wave's first relation: its weight fragments
-    uint4 wa[BL_TSMAX][BL_NT], wb[BL_TSMAX][BL_NT];
-    auto load_w = [&](int dd, uint4 (&w)[BL_TSMAX][BL_NT]) {
+    // relation dd -> ring entry: exactly BL_GL loads per wave (fragments wave, wave + 4, ...; slots past 3 TS go to the dummy)
+    auto fetch_w = [&](int dd) {
         const int d = d_lo + min(dd, nd - 1);
+        uint4* ring = wl + (size_t)(dd & (BL_RING - 1)) * BL_FRAGS * 64;
 #pragma unroll
-        for (int ts = 0; ts < BL_TSMAX; ++ts)
-#pragma unroll
-            for (int j = 0; j < BL_NT; ++j)
-                w[ts][j] = p.img[((size_t)min(nt0 + j, p.n_tiles - 1) * d_stride + (size_t)d * TS + min(ts, TS - 1)) * 64 + lane];
+        for (int u = 0; u < BL_GL; ++u) {
+            const int f = wave + u * BL_WAVES;
+            const int fc = min(f, n_frag - 1);
+            const int j = fc / TS, ts = fc - j * TS;
+            const uint4* src = p.img + ((size_t)min(nt0 + j, p.n_tiles - 1) * d_stride + (size_t)d * TS + ts) * 64 + lane;
+            uint4* dst = f < n_frag ? ring + (size_t)f * 64 : dummy + wave * 64;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
     };
-    load_w(wave, wa);
-    // e of the tile -> LDS, relation-major (a lane then reads its row's scalar without bank conflicts)
-    for (int q = tid; q < nd * 64; q += BL_THREADS) {
-        const int row = q / nd, dl = q - row * nd;
-        es[dl * 65 + row] = p.e[(size_t)min(m0 + row, p.M - 1) * p.D + d_lo + dl];
+    fetch_w(0);
+    fetch_w(1);
+    fetch_w(2);
+    // e of the workgroup's rows -> LDS, relation-major
+    const int rows0 = bm * BL_ROWS;
+    constexpr int BL_EU = 8;                                 // loads in flight per thread and round (a load per round would be ~20 round trips)
+    for (int q0 = tid; q0 < nd * BL_ROWS; q0 += BL_THREADS * BL_EU) {
+        float v[BL_EU];
+#pragma unroll
+        for (int u = 0; u < BL_EU; ++u) {
+            const int q = min(q0 + u * BL_THREADS, nd * BL_ROWS - 1);
+            const int row = q / nd, dl = q - row * nd;
+            v[u] = p.e[(size_t)min(rows0 + row, p.M - 1) * p.D + d_lo + dl];
+        }
+#pragma unroll
+        for (int u = 0; u < BL_EU; ++u) {
+            const int q = q0 + u * BL_THREADS;
+            const int row = q / nd, dl = q - row * nd;
+            if (q < nd * BL_ROWS) es[dl * (BL_ROWS + 1) + row] = v[u];
+        }
     }
-    __syncthreads();
+    __syncthreads();                                         // (one full drain before the loop: e tile and the first three relations)
 
     f32x4_t acc[BL_MT][BL_NT];
 #pragma unroll
@@ -102,7 +131,24 @@ __global__ __launch_bounds__(BL_THREADS, 1) void bilinear_fwd_kernel(const Bilin
 #pragma unroll
         for (int j = 0; j < BL_NT; ++j) acc[mt][j] = (f32x4_t){0, 0, 0, 0};
 
-    auto relation = [&](int dd, const uint4 (&w)[BL_TSMAX][BL_NT]) {
+    for (int dd = 0; dd < nd; ++dd) {
+        // relation dd has landed when at most the loads of dd+1 and dd+2 (2 x BL_GL = 12 of this wave) are outstanding
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // ... in every wave; and every wave is done reading relation dd-1
+        fetch_w(dd + 3);                                     // into the ring entry relation dd-1 has just left
+        // Every LDS read of the loop is inline asm: hipcc cannot tell a ds_read from the ring apart from the direct-to-LDS loads in
+        // flight and would put an s_waitcnt vmcnt(0) in front of each (seen in the ISA), which is the drain the counted wait avoids.
+        const unsigned ring = lds_addr(wl) + (unsigned)((dd & (BL_RING - 1)) * BL_FRAGS * 1024) + (unsigned)lane * 16u;
+        const unsigned eaddr = lds_addr(es) + (unsigned)((dd * (BL_ROWS + 1) + wave * 16 * BL_MT + (lane & 15)) * 4);
+        float ev[BL_MT];
+#pragma unroll
+        for (int mt = 0; mt < BL_MT; ++mt) asm volatile("ds_read_b32 %0, %1" : "=v"(ev[mt]) : "v"(eaddr + (unsigned)(mt * 64)));
+        uint4 wc[2][BL_NT];
+        auto read_w = [&](int ts, uint4 (&w)[BL_NT]) {
+#pragma unroll
+            for (int j = 0; j < BL_NT; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(w[j]) : "v"(ring + (unsigned)((j * TS + ts) * 1024)));
+        };
+        read_w(0, wc[0]);
         f32x4_t P[BL_MT][BL_NT];
 #pragma unroll
         for (int mt = 0; mt < BL_MT; ++mt)
@@ -110,48 +156,44 @@ __global__ __launch_bounds__(BL_THREADS, 1) void bilinear_fwd_kernel(const Bilin
             for (int j = 0; j < BL_NT; ++j) P[mt][j] = (f32x4_t){0, 0, 0, 0};
 #pragma unroll
         for (int ts = 0; ts < BL_TSMAX; ++ts) {
-            if (ts < TS) {                                      // workgroup-uniform, no load inside
+            if (ts < TS) {                                   // workgroup-uniform
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // this k-step's fragments (requested one k-step ago)
+                if (ts + 1 < TS) read_w(ts + 1, wc[(ts + 1) & 1]);                  // the next one's, behind this k-step's MFMAs
 #pragma unroll
                 for (int j = 0; j < BL_NT; ++j)
 #pragma unroll
                     for (int mt = 0; mt < BL_MT; ++mt)
-                        P[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[ts][j]),
+                        P[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wc[ts & 1][j]),
                                                                            __builtin_bit_cast(bf16x8_t, xf[mt][ts]), P[mt][j], 0, 0, 0);
             }
         }
-        const bool live = dd < nd;                              // past the slice: contributes zeros
 #pragma unroll
-        for (int mt = 0; mt < BL_MT; ++mt) {
-            const float ev = live ? es[min(dd, nd - 1) * 65 + 16 * mt + (lane & 15)] : 0.0f;
+        for (int mt = 0; mt < BL_MT; ++mt)
 #pragma unroll
-            for (int j = 0; j < BL_NT; ++j) acc[mt][j] += ev * P[mt][j];
-        }
-    };
-    // two relations per round: the fragments of the next one are requested before the current one is multiplied
-    for (int dd = wave; dd < nd; dd += 2 * BL_WAVES) {
-        load_w(dd + BL_WAVES, wb);
-        relation(dd, wa);
-        load_w(dd + 2 * BL_WAVES, wa);
-        relation(dd + BL_WAVES, wb);
+            for (int j = 0; j < BL_NT; ++j) acc[mt][j] += ev[mt] * P[mt][j];
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the clamped re-fetches past the slice's end
 
-    // waves meet in LDS; slices of the relation range are combined with float atomics
+    // every wave owns its rows: plain 16-byte stores into this relation slice's own plane of y (the caller sums the planes: ten
+    // float atomics per element cost more than the whole contraction -- ~50 G atomics/s device-wide -- a plane costs one store)
+    float* plane = p.y + (size_t)slice * p.M * p.H;
+    const bool vec = (p.H & 3) == 0;
 #pragma unroll
-    for (int mt = 0; mt < BL_MT; ++mt)
-#pragma unroll
-        for (int j = 0; j < BL_NT; ++j) red[wave][mt * BL_NT + j][lane] = acc[mt][j];
-    __syncthreads();
-    for (int tt = wave; tt < BL_MT * BL_NT; tt += BL_WAVES) {
-        const int mt = tt / BL_NT, j = tt - mt * BL_NT;
-        f32x4_t v = red[0][tt][lane];
-#pragma unroll
-        for (int w = 1; w < BL_WAVES; ++w) v += red[w][tt][lane];
+    for (int mt = 0; mt < BL_MT; ++mt) {
         const int m = m0 + 16 * mt + (lane & 15);
-        const int n = (nt0 + j) * 16 + 4 * (lane >> 4);
-        if (m < p.M && nt0 + j < p.n_tiles) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                if (n + g < p.H) atomicAdd(p.y + (size_t)m * p.H + n + g, v[g]);
+        for (int j = 0; j < BL_NT; ++j) {
+            const int n = (nt0 + j) * 16 + 4 * (lane >> 4);
+            if (m < p.M && nt0 + j < p.n_tiles) {
+                float* dst = plane + (size_t)m * p.H + n;
+                if (vec && n + 4 <= p.H) {
+                    *reinterpret_cast<float4*>(dst) = make_float4(acc[mt][j][0], acc[mt][j][1], acc[mt][j][2], acc[mt][j][3]);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        if (n + g < p.H) dst[g] = acc[mt][j][g];
+                }
+            }
         }
     }
 }
@@ -180,26 +222,33 @@ extern "C" int gcnpt_bilinear_pack(void* stream, const float* W, int D, int Tin,
     return GCNPT_OK;
 }
 
+static void bilinear_plan(BilinearParams& p, int M, int D, int Tin, int H) {
+    p.M = M; p.D = D; p.H = H; p.TS = ceil_div(Tin, 32); p.n_tiles = ceil_div(H, 16);
+    p.mb = ceil_div(M, BL_ROWS); p.nb = ceil_div(p.n_tiles, BL_NT);
+    // relation slices: about one workgroup per CU (each holds ~120 KB of LDS and all registers), at least 4 relations each
+    int slices = std::max(1, std::min(256 / std::max(1, p.mb * p.nb), D / 4));
+    p.d_per_slice = ceil_div(D, slices);
+    p.slices = ceil_div(D, p.d_per_slice);
+}
+
+extern "C" int gcnpt_bilinear_planes(int M, int D, int Tin, int H) {
+    if (M <= 0 || !gcnpt_bilinear_supported(D, Tin, H)) return 0;
+    BilinearParams p{};
+    bilinear_plan(p, M, D, Tin, H);
+    return p.slices;
+}
+
 extern "C" int gcnpt_bilinear_fwd(void* stream, const void* x, const float* e, const void* w_img, int M, int D, int Tin, int H,
-                                  float* y) {
-    GCNPT_REQUIRE(x && e && w_img && y, "bilinear_fwd: null pointer");
+                                  float* y_planes) {
+    GCNPT_REQUIRE(x && e && w_img && y_planes, "bilinear_fwd: null pointer");
     GCNPT_REQUIRE(M > 0 && D > 0 && Tin > 0 && H > 0, "bilinear_fwd: sizes must be positive");
-    GCNPT_REQUIRE(aligned16(x) && aligned16(w_img), "bilinear_fwd: x and w_img must be 16-byte aligned");
+    GCNPT_REQUIRE(aligned16(x) && aligned16(w_img) && aligned16(y_planes), "bilinear_fwd: x, w_img and y_planes must be 16-byte aligned");
     if (!gcnpt_bilinear_supported(D, Tin, H))
         return fail(GCNPT_E_UNSUPPORTED, "bilinear_fwd: Tin=%d needs more than %d k-steps per relation", Tin, BL_TSMAX);
     BilinearParams p{};
-    p.x = static_cast<const bf16_t*>(x); p.e = e; p.img = static_cast<const uint4*>(w_img); p.y = y;
-    p.M = M; p.D = D; p.H = H; p.TS = ceil_div(Tin, 32); p.n_tiles = ceil_div(H, 16);
-    p.mb = ceil_div(M, 16 * BL_MT); p.nb = ceil_div(p.n_tiles, BL_NT);
-    // relation slices: about one workgroup per CU, each wave at least 2 relations
-#ifndef GCNPT_BL_TARGET_WGS
-#define GCNPT_BL_TARGET_WGS 256     // measured: 256 beats 512 (56 vs 70 us at M=1200, D=200), 1024 and 2048 are far worse (float atomics + per-workgroup setup)
-#endif
-    int slices = std::max(1, std::min(GCNPT_BL_TARGET_WGS / std::max(1, p.mb * p.nb), D / (2 * BL_WAVES)));
-    slices = std::max(1, std::min(slices, D));
-    p.d_per_slice = ceil_div(D, slices);
-    p.slices = ceil_div(D, p.d_per_slice);
-    const size_t lds = sizeof(f32x4_t) * BL_MT * BL_NT * WAVE * BL_WAVES + sizeof(float) * 65 * (size_t)p.d_per_slice;
+    p.x = static_cast<const bf16_t*>(x); p.e = e; p.img = static_cast<const uint4*>(w_img); p.y = y_planes;
+    bilinear_plan(p, M, D, Tin, H);
+    const size_t lds = ((size_t)BL_RING * BL_FRAGS + BL_WAVES) * 64 * sizeof(uint4) + sizeof(float) * (BL_ROWS + 1) * (size_t)p.d_per_slice;
     if (lds > 160 * 1024) return fail(GCNPT_E_UNSUPPORTED, "bilinear_fwd: %zu B of LDS", lds);
     static bool big_lds = false;
     if (lds > 64 * 1024 && !big_lds) {

@@ -626,8 +626,9 @@ class _BilinearFn(torch.autograd.Function):
         xb = torch.zeros((M, Tpad), dtype=torch.bfloat16, device=dev)
         xb[:, :Tin] = xt.detach()
         e32 = e.detach().to(torch.float32).contiguous()
-        y = torch.mm(e32, bias.detach().to(torch.float32).reshape(D, H))                  # gcn.py:413, the kernel adds the rest
-        _lib.check(lib.gcnpt_bilinear_fwd(st, _lib.ptr(xb), _lib.ptr(e32), _lib.ptr(img), M, D, Tin, H, _lib.ptr(y)))
+        planes = torch.empty((lib.gcnpt_bilinear_planes(M, D, Tin, H), M, H), dtype=torch.float32, device=dev)
+        _lib.check(lib.gcnpt_bilinear_fwd(st, _lib.ptr(xb), _lib.ptr(e32), _lib.ptr(img), M, D, Tin, H, _lib.ptr(planes)))
+        y = torch.addmm(planes.sum(0), e32, bias.detach().to(torch.float32).reshape(D, H))      # + e @ b3, gcn.py:413
         ctx.save_for_backward(xt, e, weight, bias)
         return y
 

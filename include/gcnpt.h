@@ -225,18 +225,21 @@ int gcnpt_gather_trees(void* stream, const int32_t* src_row_ptr, const int32_t* 
                        int32_t* ell, int32_t* ellT, uint8_t* pool_mask, int32_t* status);
 
 /* ---- N3: the relation-conditioned traversal of adj_type == 'full_deprel', model/gcn.py:400-415 (traverse_deprel) ------------
- *   y[m,:] += sum_d e[m,d] * (x[m,:] @ W3[d]),   W3 = Linear.weight.reshape(D, Tin, H) (gcn.py:301: a reinterpretation of the
+ *   y[m,:] = sum_d e[m,d] * (x[m,:] @ W3[d]),   W3 = Linear.weight.reshape(D, Tin, H) (gcn.py:301: a reinterpretation of the
  *   [D*H, Tin] weight's memory, no transpose), for M token rows (the caller compacts the tokens that sit in a pruned tree).
  * bf16 MFMA operands, fp32 accumulation.  gcnpt_bilinear_pack: W [dev] float32, the Linear weight as it lies in memory ->
  * w_img, gcnpt_bilinear_packed_bytes(D, Tin, H) bytes of MFMA fragment order (once per optimizer step).
  * gcnpt_bilinear_fwd: x [dev] bf16 [M, 32*ceil(Tin/32)] zero padded, 16-byte aligned; e [dev] float32 [M, D] (relation vectors:
- * embeddings, or ones past deprel_max_depth); y [dev] float32 [M, H] is ACCUMULATED with float atomics -- initialise it with the
- * bias term e @ b3 (gcn.py:413) or zeros.  gcnpt_bilinear_supported: 0 when Tin needs more k-steps than the kernel keeps in
- * registers (Tin > 256). */
+ * embeddings, or ones past deprel_max_depth); y_planes [dev] float32 [gcnpt_bilinear_planes(M,D,Tin,H)][M, H], written
+ * completely: the relations are split into that many slices (so that ~256 workgroups exist) and each slice leaves its partial
+ * sums in its own plane -- the result is the sum of the planes (plus the bias term e @ b3, gcn.py:413).  No float atomics.
+ * gcnpt_bilinear_supported: 0 when Tin needs more k-steps than the kernel keeps in registers (Tin > 256). */
 size_t gcnpt_bilinear_packed_bytes(int D, int Tin, int H);
 int gcnpt_bilinear_supported(int D, int Tin, int H);
 int gcnpt_bilinear_pack(void* stream, const float* W, int D, int Tin, int H, void* w_img);
-int gcnpt_bilinear_fwd(void* stream, const void* x, const float* e, const void* w_img, int M, int D, int Tin, int H, float* y);
+int gcnpt_bilinear_planes(int M, int D, int Tin, int H);
+int gcnpt_bilinear_fwd(void* stream, const void* x, const float* e, const void* w_img, int M, int D, int Tin, int H,
+                       float* y_planes);
 
 #ifdef __cplusplus
 }

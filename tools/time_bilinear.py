@@ -35,7 +35,7 @@ def main():
         img = torch.empty((lib.gcnpt_bilinear_packed_bytes(D, Tin, H),), dtype=torch.uint8, device=dev)
         xb = torch.zeros((M, (Tin + 31) // 32 * 32), dtype=torch.bfloat16, device=dev)
         xb[:, :Tin] = x
-        y = torch.zeros((M, H), device=dev)
+        y = torch.empty((lib.gcnpt_bilinear_planes(M, D, Tin, H), M, H), device=dev)
         st = _lib.stream()
         pack = lambda: _lib.check(lib.gcnpt_bilinear_pack(st, _lib.ptr(W), D, Tin, H, _lib.ptr(img)))  # noqa: E731
         fwd = lambda: _lib.check(lib.gcnpt_bilinear_fwd(st, _lib.ptr(xb), _lib.ptr(e), _lib.ptr(img), M, D, Tin, H, _lib.ptr(y)))  # noqa: E731
@@ -44,7 +44,8 @@ def main():
         lib16 = lambda: torch.mm((e16.unsqueeze(2) * x16.unsqueeze(1)).reshape(M, D * Tin), Wk16)  # noqa: E731
         flops = 2.0 * M * D * Tin * H
         t_pack, t_fwd, t32, t16 = timed(pack), timed(fwd), timed(lib32), timed(lib16)
-        out["M%d_D%d" % (M, D)] = dict(pack_us=round(t_pack, 1), kernel_us=round(t_fwd, 1), kernel_TFLOPs=round(flops / t_fwd / 1e6, 1),
+        t_sum = timed(lambda: y.sum(0))
+        out["M%d_D%d" % (M, D)] = dict(pack_us=round(t_pack, 1), kernel_us=round(t_fwd, 1), kernel_TFLOPs=round(flops / t_fwd / 1e6, 1), planes=int(y.shape[0]), plane_sum_us=round(t_sum, 1),
                                        library_fp32_us=round(t32, 1), library_bf16_us=round(t16, 1))
     print(json.dumps(out))
 

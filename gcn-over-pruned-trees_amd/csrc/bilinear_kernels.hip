@@ -18,19 +18,23 @@ constexpr int BL_THREADS = 256, BL_WAVES = BL_THREADS / WAVE;
 constexpr int BL_MT = 4, BL_NT = 3;          // 16-row token tiles and 16-column output tiles per workgroup
 constexpr int BL_TSMAX = 8;                  // k-steps per relation the registers are sized for: Tin <= 256
 
+// transposed = 0: contraction over Tin, output columns H (forward);  1: contraction over H, output columns Tin (the same kernel
+// then computes dx = sum_d e_d (gy @ W3[d]^T))
 __global__ void bilinear_pack_kernel(const float* __restrict__ W, int D, int Tin, int H, int TS, long long n_frag_lanes,
-                                     uint4* __restrict__ img) {
+                                     uint4* __restrict__ img, int transposed) {
     for (long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x; gid < n_frag_lanes; gid += (long long)gridDim.x * blockDim.x) {
         const int lane = (int)(gid & 63);
         const long long f = gid >> 6;
         const int ks = (int)(f % ((long long)D * TS)), tl = (int)(f / ((long long)D * TS));
         const int d = ks / TS, ts = ks - d * TS;
-        const int n = tl * 16 + (lane & 15), t0 = ts * 32 + 8 * (lane >> 4);
+        const int n = tl * 16 + (lane & 15), k0 = ts * 32 + 8 * (lane >> 4);
+        const int Kd = transposed ? H : Tin, Nd = transposed ? Tin : H;
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {                       // unconditional clamped loads, dropped with a select
-            const float x = W[((size_t)d * Tin + min(t0 + j, Tin - 1)) * H + min(n, H - 1)];
-            v[j] = (t0 + j < Tin && n < H) ? x : 0.0f;
+            const int kc = min(k0 + j, Kd - 1), nc = min(n, Nd - 1);
+            const float x = transposed ? W[((size_t)d * Tin + nc) * H + kc] : W[((size_t)d * Tin + kc) * H + nc];
+            v[j] = (k0 + j < Kd && n < Nd) ? x : 0.0f;
         }
         uint4 u;
         u.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
@@ -45,7 +49,8 @@ struct BilinearParams {
     const bf16_t* x;        // [M, TS*32] bf16, zero padded
     const float* e;         // [M, D]
     const uint4* img;       // packed W3
-    float* y;               // [slices][M, H]: one plane per relation slice, written completely
+    float* y;               // MODE 0: [slices][M, H], one plane per relation slice; MODE 1: [nb][M, D], one plane per column block
+    const float* gy;        // MODE 1: [M, H] upstream gradient
     int M, D, H, TS, n_tiles, mb, nb, slices, d_per_slice;
 };
 
@@ -63,6 +68,9 @@ constexpr int BL_RING = 4;                           // relations in the LDS rin
 constexpr int BL_GL = (BL_NT * BL_TSMAX + BL_WAVES - 1) / BL_WAVES;      // direct-to-LDS loads per wave and relation: always 6
 constexpr int BL_FRAGS = BL_GL * BL_WAVES;           // fragment slots per ring entry (24 KiB), TS < 8 leaves some unused
 
+// MODE 0: y planes = sum_d e_d P_d.   MODE 1: de[m,d] = P_d[m,:] . gy[m,:] (the gradient of the relation vectors: the same per-relation
+// products, dotted with the upstream gradient instead of scaled and summed), one plane per block of 48 columns.
+template <int MODE>
 __global__ __launch_bounds__(BL_THREADS, 1) void bilinear_fwd_kernel(const BilinearParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bl_smem[];              // ONE LDS object: ring | dummy | e tile
     const int TS = p.TS, Tpad = TS * 32;
@@ -108,7 +116,7 @@ __global__ __launch_bounds__(BL_THREADS, 1) void bilinear_fwd_kernel(const Bilin
     // e of the workgroup's rows -> LDS, relation-major
     const int rows0 = bm * BL_ROWS;
     constexpr int BL_EU = 8;                                 // loads in flight per thread and round (a load per round would be ~20 round trips)
-    for (int q0 = tid; q0 < nd * BL_ROWS; q0 += BL_THREADS * BL_EU) {
+    for (int q0 = tid; MODE == 0 && q0 < nd * BL_ROWS; q0 += BL_THREADS * BL_EU) {
         float v[BL_EU];
 #pragma unroll
         for (int u = 0; u < BL_EU; ++u) {
@@ -125,11 +133,23 @@ __global__ __launch_bounds__(BL_THREADS, 1) void bilinear_fwd_kernel(const Bilin
     }
     __syncthreads();                                         // (one full drain before the loop: e tile and the first three relations)
 
-    f32x4_t acc[BL_MT][BL_NT];
+    f32x4_t acc[BL_MT][BL_NT];             // MODE 0: the result tile; MODE 1: the upstream gradient's values at the tile's positions
 #pragma unroll
     for (int mt = 0; mt < BL_MT; ++mt)
 #pragma unroll
-        for (int j = 0; j < BL_NT; ++j) acc[mt][j] = (f32x4_t){0, 0, 0, 0};
+        for (int j = 0; j < BL_NT; ++j) {
+            acc[mt][j] = (f32x4_t){0, 0, 0, 0};
+            if constexpr (MODE == 1) {
+                const size_t row = (size_t)min(m0 + 16 * mt + (lane & 15), p.M - 1);
+                const int n = (nt0 + j) * 16 + 4 * (lane >> 4);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float v = p.gy[row * p.H + min(n + g, p.H - 1)];
+                    acc[mt][j][g] = (n + g < p.H && nt0 + j < p.n_tiles) ? v : 0.0f;
+                }
+            }
+        }
+    if constexpr (MODE == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // those loads are not part of the loop's counted queue
 
     for (int dd = 0; dd < nd; ++dd) {
         // relation dd has landed when at most the loads of dd+1 and dd+2 (2 x BL_GL = 12 of this wave) are outstanding
@@ -140,9 +160,11 @@ __global__ __launch_bounds__(BL_THREADS, 1) void bilinear_fwd_kernel(const Bilin
         // flight and would put an s_waitcnt vmcnt(0) in front of each (seen in the ISA), which is the drain the counted wait avoids.
         const unsigned ring = lds_addr(wl) + (unsigned)((dd & (BL_RING - 1)) * BL_FRAGS * 1024) + (unsigned)lane * 16u;
         const unsigned eaddr = lds_addr(es) + (unsigned)((dd * (BL_ROWS + 1) + wave * 16 * BL_MT + (lane & 15)) * 4);
-        float ev[BL_MT];
+        float ev[BL_MT] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (MODE == 0) {
 #pragma unroll
-        for (int mt = 0; mt < BL_MT; ++mt) asm volatile("ds_read_b32 %0, %1" : "=v"(ev[mt]) : "v"(eaddr + (unsigned)(mt * 64)));
+            for (int mt = 0; mt < BL_MT; ++mt) asm volatile("ds_read_b32 %0, %1" : "=v"(ev[mt]) : "v"(eaddr + (unsigned)(mt * 64)));
+        }
         uint4 wc[2][BL_NT];
         auto read_w = [&](int ts, uint4 (&w)[BL_NT]) {
 #pragma unroll
@@ -167,13 +189,30 @@ __global__ __launch_bounds__(BL_THREADS, 1) void bilinear_fwd_kernel(const Bilin
                                                                            __builtin_bit_cast(bf16x8_t, xf[mt][ts]), P[mt][j], 0, 0, 0);
             }
         }
+        if constexpr (MODE == 0) {
 #pragma unroll
-        for (int mt = 0; mt < BL_MT; ++mt)
+            for (int mt = 0; mt < BL_MT; ++mt)
 #pragma unroll
-            for (int j = 0; j < BL_NT; ++j) acc[mt][j] += ev[mt] * P[mt][j];
+                for (int j = 0; j < BL_NT; ++j) acc[mt][j] += ev[mt] * P[mt][j];
+        } else {
+            float* plane = p.y + (size_t)bn * p.M * p.D;
+#pragma unroll
+            for (int mt = 0; mt < BL_MT; ++mt) {
+                float sdot = 0.0f;
+#pragma unroll
+                for (int j = 0; j < BL_NT; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) sdot += P[mt][j][g] * acc[mt][j][g];
+                sdot += __shfl_xor(sdot, 16);
+                sdot += __shfl_xor(sdot, 32);
+                const int m = m0 + 16 * mt + (lane & 15);
+                if (lane < 16 && m < p.M) plane[(size_t)m * p.D + d_lo + dd] = sdot;
+            }
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the clamped re-fetches past the slice's end
 
+    if constexpr (MODE == 1) return;
     // every wave owns its rows: plain 16-byte stores into this relation slice's own plane of y (the caller sums the planes: ten
     // float atomics per element cost more than the whole contraction -- ~50 G atomics/s device-wide -- a plane costs one store)
     float* plane = p.y + (size_t)slice * p.M * p.H;
@@ -211,13 +250,13 @@ extern "C" int gcnpt_bilinear_supported(int D, int Tin, int H) {
     return D > 0 && H > 0 && Tin > 0 && ceil_div(Tin, 32) <= BL_TSMAX;
 }
 
-extern "C" int gcnpt_bilinear_pack(void* stream, const float* W, int D, int Tin, int H, void* w_img) {
+extern "C" int gcnpt_bilinear_pack(void* stream, const float* W, int D, int Tin, int H, void* w_img, int transposed) {
     GCNPT_REQUIRE(W && w_img, "bilinear_pack: null pointer");
     GCNPT_REQUIRE(D > 0 && Tin > 0 && H > 0, "bilinear_pack: sizes must be positive");
-    const int TS = ceil_div(Tin, 32);
-    const long long n = (long long)ceil_div(H, 16) * D * TS * 64;
+    const int TS = ceil_div(transposed ? H : Tin, 32);
+    const long long n = (long long)ceil_div(transposed ? Tin : H, 16) * D * TS * 64;
     const int grid = (int)std::min<long long>((n + 255) / 256, 1 << 16);
-    hipLaunchKernelGGL(bilinear_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, D, Tin, H, TS, n, static_cast<uint4*>(w_img));
+    hipLaunchKernelGGL(bilinear_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, D, Tin, H, TS, n, static_cast<uint4*>(w_img), transposed);
     GCNPT_HIP_CHECK(hipGetLastError());
     return GCNPT_OK;
 }
@@ -238,6 +277,20 @@ extern "C" int gcnpt_bilinear_planes(int M, int D, int Tin, int H) {
     return p.slices;
 }
 
+template <int MODE>
+static int bilinear_launch(hipStream_t s, BilinearParams& p) {
+    const size_t lds = ((size_t)BL_RING * BL_FRAGS + BL_WAVES) * 64 * sizeof(uint4) + sizeof(float) * (BL_ROWS + 1) * (size_t)p.d_per_slice;
+    if (lds > 160 * 1024) return fail(GCNPT_E_UNSUPPORTED, "bilinear: %zu B of LDS", lds);
+    static bool big_lds = false;
+    if (lds > 64 * 1024 && !big_lds) {
+        GCNPT_HIP_CHECK(hipFuncSetAttribute((const void*)bilinear_fwd_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        big_lds = true;
+    }
+    hipLaunchKernelGGL(bilinear_fwd_kernel<MODE>, dim3(p.mb * p.nb * p.slices), dim3(BL_THREADS), lds, s, p);
+    GCNPT_HIP_CHECK(hipGetLastError());
+    return GCNPT_OK;
+}
+
 extern "C" int gcnpt_bilinear_fwd(void* stream, const void* x, const float* e, const void* w_img, int M, int D, int Tin, int H,
                                   float* y_planes) {
     GCNPT_REQUIRE(x && e && w_img && y_planes, "bilinear_fwd: null pointer");
@@ -248,14 +301,24 @@ extern "C" int gcnpt_bilinear_fwd(void* stream, const void* x, const float* e, c
     BilinearParams p{};
     p.x = static_cast<const bf16_t*>(x); p.e = e; p.img = static_cast<const uint4*>(w_img); p.y = y_planes;
     bilinear_plan(p, M, D, Tin, H);
-    const size_t lds = ((size_t)BL_RING * BL_FRAGS + BL_WAVES) * 64 * sizeof(uint4) + sizeof(float) * (BL_ROWS + 1) * (size_t)p.d_per_slice;
-    if (lds > 160 * 1024) return fail(GCNPT_E_UNSUPPORTED, "bilinear_fwd: %zu B of LDS", lds);
-    static bool big_lds = false;
-    if (lds > 64 * 1024 && !big_lds) {
-        GCNPT_HIP_CHECK(hipFuncSetAttribute((const void*)bilinear_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        big_lds = true;
-    }
-    hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(p.mb * p.nb * p.slices), dim3(BL_THREADS), lds, (hipStream_t)stream, p);
-    GCNPT_HIP_CHECK(hipGetLastError());
-    return GCNPT_OK;
+    return bilinear_launch<0>((hipStream_t)stream, p);
+}
+
+extern "C" int gcnpt_bilinear_de_planes(int M, int D, int Tin, int H) {
+    if (M <= 0 || !gcnpt_bilinear_supported(D, Tin, H)) return 0;
+    return ceil_div(ceil_div(H, 16), BL_NT);
+}
+
+extern "C" int gcnpt_bilinear_bwd_e(void* stream, const void* x, const float* gy, const void* w_img, int M, int D, int Tin, int H,
+                                    float* de_planes) {
+    GCNPT_REQUIRE(x && gy && w_img && de_planes, "bilinear_bwd_e: null pointer");
+    GCNPT_REQUIRE(M > 0 && D > 0 && Tin > 0 && H > 0, "bilinear_bwd_e: sizes must be positive");
+    GCNPT_REQUIRE(aligned16(x) && aligned16(w_img), "bilinear_bwd_e: x and w_img must be 16-byte aligned");
+    if (!gcnpt_bilinear_supported(D, Tin, H))
+        return fail(GCNPT_E_UNSUPPORTED, "bilinear_bwd_e: Tin=%d needs more than %d k-steps per relation", Tin, BL_TSMAX);
+    BilinearParams p{};
+    p.x = static_cast<const bf16_t*>(x); p.e = nullptr; p.gy = gy;
+    p.img = static_cast<const uint4*>(w_img); p.y = de_planes;
+    bilinear_plan(p, M, D, Tin, H);
+    return bilinear_launch<1>((hipStream_t)stream, p);
 }

@@ -610,8 +610,9 @@ class GCN(nn.Module):
 
 class _BilinearFn(torch.autograd.Function):
     """y = sum_d e[:,d] * (x @ W3[d]) + e @ b3 (reference traverse_deprel, model/gcn.py:400-415) with the forward contraction on
-    csrc/bilinear_kernels.hip (bf16 MFMA operands, fp32 accumulate).  The op is linear in each argument, so the backward needs
-    nothing from the forward's result; it is three library GEMMs in fp32."""
+    csrc/bilinear_kernels.hip (bf16 MFMA operands, fp32 accumulate).  The op is linear in each argument: dx is the same kernel on
+    the transposed weight image, de the same per-relation products dotted with the upstream gradient; dW (the outer product
+    contracted over the tokens) is still a library GEMM."""
 
     @staticmethod
     def forward(ctx, xt, e, weight, bias):
@@ -621,7 +622,7 @@ class _BilinearFn(torch.autograd.Function):
         lib, st, dev = _lib.lib(), _lib.stream(), xt.device
         w32 = weight.detach().to(torch.float32).contiguous()
         img = torch.empty((lib.gcnpt_bilinear_packed_bytes(D, Tin, H),), dtype=torch.uint8, device=dev)
-        _lib.check(lib.gcnpt_bilinear_pack(st, _lib.ptr(w32), D, Tin, H, _lib.ptr(img)))
+        _lib.check(lib.gcnpt_bilinear_pack(st, _lib.ptr(w32), D, Tin, H, _lib.ptr(img), 0))
         Tpad = (Tin + 31) // 32 * 32
         xb = torch.zeros((M, Tpad), dtype=torch.bfloat16, device=dev)
         xb[:, :Tin] = xt.detach()
@@ -629,23 +630,39 @@ class _BilinearFn(torch.autograd.Function):
         planes = torch.empty((lib.gcnpt_bilinear_planes(M, D, Tin, H), M, H), dtype=torch.float32, device=dev)
         _lib.check(lib.gcnpt_bilinear_fwd(st, _lib.ptr(xb), _lib.ptr(e32), _lib.ptr(img), M, D, Tin, H, _lib.ptr(planes)))
         y = torch.addmm(planes.sum(0), e32, bias.detach().to(torch.float32).reshape(D, H))      # + e @ b3, gcn.py:413
-        ctx.save_for_backward(xt, e, weight, bias)
+        ctx.save_for_backward(xt, e, weight, bias, xb, img)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        xt, e, weight, bias = ctx.saved_tensors
+        xt, e, weight, bias, xb, img = ctx.saved_tensors
         M, Tin = xt.shape
         D = e.shape[1]
         H = weight.shape[0] // D
+        lib, st, dev = _lib.lib(), _lib.stream(), xt.device
         gy = gy.to(torch.float32).contiguous()
-        x32, e32 = xt.to(torch.float32), e.to(torch.float32)
-        Wk = weight.to(torch.float32).reshape(D * Tin, H)
-        G = torch.mm(gy, Wk.t()).view(M, D, Tin)
-        dx = (G * e32.unsqueeze(2)).sum(1) if ctx.needs_input_grad[0] else None
-        de = ((G * x32.unsqueeze(1)).sum(2) + torch.mm(gy, bias.to(torch.float32).reshape(D, H).t())) if ctx.needs_input_grad[1] else None
-        dW = db = None
-        if ctx.needs_input_grad[2]:
+        x32, e32 = xt.to(torch.float32), e.to(torch.float32).contiguous()
+        w32 = weight.detach().to(torch.float32).contiguous()
+        b3 = bias.to(torch.float32).reshape(D, H)
+        dx = de = dW = db = None
+        on_kernel = bool(lib.gcnpt_bilinear_supported(D, H, Tin))         # the transposed problem contracts over H
+        if ctx.needs_input_grad[0]:
+            if on_kernel:       # dx = sum_d e_d (gy @ W3[d]^T): the forward kernel on the transposed weight image
+                imgT = torch.empty((lib.gcnpt_bilinear_packed_bytes(D, H, Tin),), dtype=torch.uint8, device=dev)
+                _lib.check(lib.gcnpt_bilinear_pack(st, _lib.ptr(w32), D, Tin, H, _lib.ptr(imgT), 1))
+                gyb = torch.zeros((M, (H + 31) // 32 * 32), dtype=torch.bfloat16, device=dev)
+                gyb[:, :H] = gy
+                planes = torch.empty((lib.gcnpt_bilinear_planes(M, D, H, Tin), M, Tin), dtype=torch.float32, device=dev)
+                _lib.check(lib.gcnpt_bilinear_fwd(st, _lib.ptr(gyb), _lib.ptr(e32), _lib.ptr(imgT), M, D, H, Tin, _lib.ptr(planes)))
+                dx = planes.sum(0)
+            else:
+                dx = (torch.mm(gy, w32.reshape(D * Tin, H).t()).view(M, D, Tin) * e32.unsqueeze(2)).sum(1)
+        if ctx.needs_input_grad[1]:
+            # de[m,d] = (x[m] @ W3[d]) . gy[m] + gy[m] . b3[d]: the forward's per-relation products, dotted instead of summed
+            planes = torch.empty((lib.gcnpt_bilinear_de_planes(M, D, Tin, H), M, D), dtype=torch.float32, device=dev)
+            _lib.check(lib.gcnpt_bilinear_bwd_e(st, _lib.ptr(xb), _lib.ptr(gy), _lib.ptr(img), M, D, Tin, H, _lib.ptr(planes)))
+            de = torch.addmm(planes.sum(0), gy, b3.t())
+        if ctx.needs_input_grad[2]:                                       # dW3[d] = (e_d * x)^T gy: library GEMM on the outer product
             dW = torch.mm((e32.unsqueeze(2) * x32.unsqueeze(1)).reshape(M, D * Tin).t(), gy).reshape(weight.shape).to(weight.dtype)
         if ctx.needs_input_grad[3]:
             db = torch.mm(e32.t(), gy).reshape(-1).to(bias.dtype)

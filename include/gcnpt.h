@@ -236,10 +236,20 @@ int gcnpt_gather_trees(void* stream, const int32_t* src_row_ptr, const int32_t* 
  * gcnpt_bilinear_supported: 0 when Tin needs more k-steps than the kernel keeps in registers (Tin > 256). */
 size_t gcnpt_bilinear_packed_bytes(int D, int Tin, int H);
 int gcnpt_bilinear_supported(int D, int Tin, int H);
-int gcnpt_bilinear_pack(void* stream, const float* W, int D, int Tin, int H, void* w_img);
+int gcnpt_bilinear_pack(void* stream, const float* W, int D, int Tin, int H, void* w_img, int transposed);
 int gcnpt_bilinear_planes(int M, int D, int Tin, int H);
 int gcnpt_bilinear_fwd(void* stream, const void* x, const float* e, const void* w_img, int M, int D, int Tin, int H,
                        float* y_planes);
+/* Gradients of the traversal that reuse the same kernel (the op is linear in each argument):
+ *   dx = sum_d e_d * (gy @ W3[d]^T)        -> gcnpt_bilinear_fwd on (gy as x, the image packed with transposed = 1, widths swapped:
+ *                                             gcnpt_bilinear_pack(.., transposed=1) fills gcnpt_bilinear_packed_bytes(D, H, Tin) bytes;
+ *                                             gcnpt_bilinear_fwd(stream, gy_bf16 [M, 32*ceil(H/32)], e, imgT, M, D, H, Tin, dx_planes))
+ *   de[m,d] = (x[m] @ W3[d]) . gy[m]       -> gcnpt_bilinear_bwd_e: gy [dev] float32 [M,H]; de_planes [dev] float32
+ *                                             [gcnpt_bilinear_de_planes(M,D,Tin,H)][M, D] written completely, summed by the caller. */
+int gcnpt_bilinear_de_planes(int M, int D, int Tin, int H);
+int gcnpt_bilinear_bwd_e(void* stream, const void* x, const float* gy, const void* w_img, int M, int D, int Tin, int H,
+                         float* de_planes);
+
 
 #ifdef __cplusplus
 }

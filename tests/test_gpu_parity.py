@@ -862,8 +862,15 @@ def test_bilinear_traverse_kernel(api, dev, M, D, Tin, H):
     # the same against the fp32 einsum of bf16-rounded operands: only the accumulation order is left
     rb = lambda t: t.detach().to(torch.bfloat16).float()  # noqa: E731
     assert max_rel(got.detach().cpu().numpy(), (ref(rb(x), e.detach(), rb(W), b.detach())).cpu().numpy()) <= 2e-5
-    for t, g in zip((x, e, W, b), grads):
-        assert max_rel(t.grad.cpu().numpy(), g.cpu().numpy()) <= 2e-5
+    # dW, db: library GEMMs in fp32; dx, de: the kernel again (bf16 operands), exact against bf16-rounded operands
+    assert max_rel(W.grad.cpu().numpy(), grads[2].cpu().numpy()) <= 2e-5 and max_rel(b.grad.cpu().numpy(), grads[3].cpu().numpy()) <= 2e-5
+    assert max_rel(x.grad.cpu().numpy(), grads[0].cpu().numpy()) <= 1e-2 and max_rel(e.grad.cpu().numpy(), grads[1].cpu().numpy()) <= 1e-2
+    xr, er, Wr, gr = rb(x).requires_grad_(), e.detach().clone().requires_grad_(), rb(W).requires_grad_(), rb(gy)
+    ref(xr, er, Wr, b.detach()).backward(gr)            # dx sees bf16(gy), bf16(W), fp32 e
+    assert max_rel(x.grad.cpu().numpy(), xr.grad.cpu().numpy()) <= 2e-5
+    er.grad = None
+    ref(xr, er, Wr, b.detach()).backward(gy)            # de sees bf16(x), bf16(W), fp32 gy
+    assert max_rel(e.grad.cpu().numpy(), er.grad.cpu().numpy()) <= 2e-5
 
 
 def test_full_deprel_golden(api, dev):

@@ -37,6 +37,9 @@ SIGNATURES = {
     "gcnpt_bilinear_supported": (_i, [_i, _i, _i]),
     "gcnpt_bilinear_planes": (_i, [_i, _i, _i, _i]),
     "gcnpt_bilinear_pack": (_i, [_p, _p, _i, _i, _i, _p, _i]),
+    "gcnpt_rows_image_bytes": (_sz, [_i, _i]),
+    "gcnpt_rows_pack": (_i, [_p, _p, _i, _i, _p]),
+    "gcnpt_bilinear_bwd_w": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "gcnpt_bilinear_de_planes": (_i, [_i, _i, _i, _i]),
     "gcnpt_bilinear_bwd_e": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "gcnpt_bilinear_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),

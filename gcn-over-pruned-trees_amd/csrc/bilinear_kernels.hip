@@ -237,6 +237,118 @@ __global__ __launch_bounds__(BL_THREADS, 1) void bilinear_fwd_kernel(const Bilin
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// dW3[d][t][h] = sum_m e[m,d] * x[m,t] * gy[m,h]      (the weight gradient of the traversal: the outer product e (x) x contracted
+// with the upstream gradient over the M tokens; the reference's autograd materialises [M, D*Tin] for it)
+// Both token-side operands come as "row-contraction" fragment images (lane = column, 8 consecutive TOKENS per lane, as the
+// saved operands of the layer kernels): xI[t_tile][m_step][lane], gI[h_tile][m_step][lane].  A workgroup owns a (4 x 3)-tile block
+// of dW3 for BW_ND relations; per m-step it loads the 4 + 3 fragments once and, for each of its relations, scales the three gy
+// fragments by e[m, d] along the tokens (fp32 multiply, repacked to bf16) and issues the 12 MFMAs.  Its 4 waves take every 4th
+// m-step and meet in LDS; every element of dW3 is written once (no atomics).
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int BW_MT = 4, BW_NT = 3, BW_ND = 4;
+
+__global__ void rows_pack_kernel(const float* __restrict__ src, int M, int W, int m_steps, long long n_lanes, uint4* __restrict__ img) {
+    for (long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x; gid < n_lanes; gid += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(gid & 63);
+        const long long f = gid >> 6;
+        const int ms = (int)(f % m_steps), wt = (int)(f / m_steps);
+        const int c = wt * 16 + (lane & 15), m0 = ms * 32 + 8 * (lane >> 4);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = src[(size_t)min(m0 + j, M - 1) * W + min(c, W - 1)];
+            v[j] = (m0 + j < M && c < W) ? x : 0.0f;
+        }
+        uint4 u;
+        u.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+        u.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+        u.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+        u.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+        img[gid] = u;
+    }
+}
+
+struct BilinearDwParams {
+    const uint4* xI;        // [t_tiles][m_steps][64]
+    const uint4* gI;        // [h_tiles][m_steps][64]
+    const float* eT;        // [D][m_steps * 32]: e transposed, zero padded along the tokens
+    float* dW;              // [D][Tin][H] == the Linear weight's [D*H, Tin] memory
+    int D, Tin, H, t_tiles, h_tiles, m_steps, tb, hb, dgroups;
+};
+
+__global__ __launch_bounds__(BL_THREADS, 1) void bilinear_dw_kernel(const BilinearDwParams p) {
+    __shared__ f32x4_t red[BL_WAVES][BW_MT * BW_NT][WAVE];                  // 48 KiB: one relation's tiles at a time
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int id = blockIdx.x;
+    const int bt = id % p.tb, rest = id / p.tb;
+    const int bh = rest % p.hb, dg = rest / p.hb;
+    const int t0 = bt * BW_MT, h0 = bh * BW_NT, d0 = dg * BW_ND;
+    f32x4_t acc[BW_ND][BW_MT][BW_NT];
+#pragma unroll
+    for (int q = 0; q < BW_ND; ++q)
+#pragma unroll
+        for (int i = 0; i < BW_MT; ++i)
+#pragma unroll
+            for (int j = 0; j < BW_NT; ++j) acc[q][i][j] = (f32x4_t){0, 0, 0, 0};
+    const size_t Mpad = (size_t)p.m_steps * 32;
+    for (int ms = wave; ms < p.m_steps; ms += BL_WAVES) {
+        uint4 xa[BW_MT], gb[BW_NT];
+        float4 ea[BW_ND][2];
+#pragma unroll
+        for (int i = 0; i < BW_MT; ++i) xa[i] = p.xI[((size_t)min(t0 + i, p.t_tiles - 1) * p.m_steps + ms) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < BW_NT; ++j) gb[j] = p.gI[((size_t)min(h0 + j, p.h_tiles - 1) * p.m_steps + ms) * 64 + lane];
+#pragma unroll
+        for (int q = 0; q < BW_ND; ++q) {
+            const float* ep = p.eT + (size_t)min(d0 + q, p.D - 1) * Mpad + (size_t)ms * 32 + 8 * (lane >> 4);
+            ea[q][0] = *reinterpret_cast<const float4*>(ep);
+            ea[q][1] = *reinterpret_cast<const float4*>(ep + 4);
+        }
+#pragma unroll
+        for (int q = 0; q < BW_ND; ++q) {
+#pragma unroll
+            for (int j = 0; j < BW_NT; ++j) {
+                // gy fragment scaled along the tokens by e[., d]: 8 bf16 -> fp32, multiply, back to bf16
+                const uint4 g = gb[j];
+                uint4 sg;
+                sg.x = (unsigned)f32_to_bf16(__uint_as_float(g.x << 16) * ea[q][0].x) | ((unsigned)f32_to_bf16(__uint_as_float(g.x & 0xffff0000u) * ea[q][0].y) << 16);
+                sg.y = (unsigned)f32_to_bf16(__uint_as_float(g.y << 16) * ea[q][0].z) | ((unsigned)f32_to_bf16(__uint_as_float(g.y & 0xffff0000u) * ea[q][0].w) << 16);
+                sg.z = (unsigned)f32_to_bf16(__uint_as_float(g.z << 16) * ea[q][1].x) | ((unsigned)f32_to_bf16(__uint_as_float(g.z & 0xffff0000u) * ea[q][1].y) << 16);
+                sg.w = (unsigned)f32_to_bf16(__uint_as_float(g.w << 16) * ea[q][1].z) | ((unsigned)f32_to_bf16(__uint_as_float(g.w & 0xffff0000u) * ea[q][1].w) << 16);
+#pragma unroll
+                for (int i = 0; i < BW_MT; ++i)       // swapped operands: rows = h (scaled gy), columns = t (x): a lane ends with 4 consecutive h of one t
+                    acc[q][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, sg), __builtin_bit_cast(bf16x8_t, xa[i]),
+                                                                          acc[q][i][j], 0, 0, 0);
+            }
+        }
+    }
+    // waves meet in LDS, one relation at a time (12 tiles x 4 waves = 48 KiB)
+    for (int q = 0; q < BW_ND; ++q) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < BW_MT; ++i)
+#pragma unroll
+            for (int j = 0; j < BW_NT; ++j) red[wave][i * BW_NT + j][lane] = acc[q][i][j];
+        __syncthreads();
+        const int d = d0 + q;
+        for (int tt = wave; tt < BW_MT * BW_NT; tt += BL_WAVES) {
+            const int i = tt / BW_NT, j = tt - i * BW_NT;
+            f32x4_t v = red[0][tt][lane];
+#pragma unroll
+            for (int w = 1; w < BL_WAVES; ++w) v += red[w][tt][lane];
+            const int t = (t0 + i) * 16 + (lane & 15);
+            const int h = (h0 + j) * 16 + 4 * (lane >> 4);
+            if (d < p.D && t < p.Tin && t0 + i < p.t_tiles && h0 + j < p.h_tiles) {
+                float* dst = p.dW + ((size_t)d * p.Tin + t) * p.H + h;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (h + g < p.H) dst[g] = v[g];
+            }
+        }
+    }
+}
+
 }  // namespace gcnpt
 
 using namespace gcnpt;
@@ -321,4 +433,36 @@ extern "C" int gcnpt_bilinear_bwd_e(void* stream, const void* x, const float* gy
     p.img = static_cast<const uint4*>(w_img); p.y = de_planes;
     bilinear_plan(p, M, D, Tin, H);
     return bilinear_launch<1>((hipStream_t)stream, p);
+}
+
+extern "C" size_t gcnpt_rows_image_bytes(int M, int W) {
+    if (M <= 0 || W <= 0) return 0;
+    return (size_t)ceil_div(W, 16) * ceil_div(M, 32) * 64 * 16;
+}
+
+extern "C" int gcnpt_rows_pack(void* stream, const float* src, int M, int W, void* img) {
+    GCNPT_REQUIRE(src && img, "rows_pack: null pointer");
+    GCNPT_REQUIRE(M > 0 && W > 0, "rows_pack: sizes must be positive");
+    const int m_steps = ceil_div(M, 32);
+    const long long n = (long long)ceil_div(W, 16) * m_steps * 64;
+    const int grid = (int)std::min<long long>((n + 255) / 256, 1 << 16);
+    hipLaunchKernelGGL(rows_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, M, W, m_steps, n, static_cast<uint4*>(img));
+    GCNPT_HIP_CHECK(hipGetLastError());
+    return GCNPT_OK;
+}
+
+extern "C" int gcnpt_bilinear_bwd_w(void* stream, const void* x_img, const void* gy_img, const float* eT, int M, int D, int Tin, int H,
+                                    float* dW) {
+    GCNPT_REQUIRE(x_img && gy_img && eT && dW, "bilinear_bwd_w: null pointer");
+    GCNPT_REQUIRE(M > 0 && D > 0 && Tin > 0 && H > 0, "bilinear_bwd_w: sizes must be positive");
+    GCNPT_REQUIRE(aligned16(x_img) && aligned16(gy_img) && aligned16(eT), "bilinear_bwd_w: images and eT must be 16-byte aligned");
+    BilinearDwParams p{};
+    p.xI = static_cast<const uint4*>(x_img); p.gI = static_cast<const uint4*>(gy_img); p.eT = eT; p.dW = dW;
+    p.D = D; p.Tin = Tin; p.H = H; p.t_tiles = ceil_div(Tin, 16); p.h_tiles = ceil_div(H, 16); p.m_steps = ceil_div(M, 32);
+    p.tb = ceil_div(p.t_tiles, BW_MT); p.hb = ceil_div(p.h_tiles, BW_NT); p.dgroups = ceil_div(D, BW_ND);
+    const long long blocks = (long long)p.tb * p.hb * p.dgroups;
+    if (blocks > 0x7fffffffLL) return fail(GCNPT_E_UNSUPPORTED, "bilinear_bwd_w: too many blocks");
+    hipLaunchKernelGGL(bilinear_dw_kernel, dim3((unsigned)blocks), dim3(BL_THREADS), 0, (hipStream_t)stream, p);
+    GCNPT_HIP_CHECK(hipGetLastError());
+    return GCNPT_OK;
 }

@@ -611,8 +611,8 @@ class GCN(nn.Module):
 class _BilinearFn(torch.autograd.Function):
     """y = sum_d e[:,d] * (x @ W3[d]) + e @ b3 (reference traverse_deprel, model/gcn.py:400-415) with the forward contraction on
     csrc/bilinear_kernels.hip (bf16 MFMA operands, fp32 accumulate).  The op is linear in each argument: dx is the same kernel on
-    the transposed weight image, de the same per-relation products dotted with the upstream gradient; dW (the outer product
-    contracted over the tokens) is still a library GEMM."""
+    the transposed weight image, de the same per-relation products dotted with the upstream gradient, dW the token contraction
+    of row-contraction fragment images with the gy fragments scaled by e in registers (gcnpt_bilinear_bwd_w)."""
 
     @staticmethod
     def forward(ctx, xt, e, weight, bias):
@@ -662,8 +662,18 @@ class _BilinearFn(torch.autograd.Function):
             planes = torch.empty((lib.gcnpt_bilinear_de_planes(M, D, Tin, H), M, D), dtype=torch.float32, device=dev)
             _lib.check(lib.gcnpt_bilinear_bwd_e(st, _lib.ptr(xb), _lib.ptr(gy), _lib.ptr(img), M, D, Tin, H, _lib.ptr(planes)))
             de = torch.addmm(planes.sum(0), gy, b3.t())
-        if ctx.needs_input_grad[2]:                                       # dW3[d] = (e_d * x)^T gy: library GEMM on the outer product
-            dW = torch.mm((e32.unsqueeze(2) * x32.unsqueeze(1)).reshape(M, D * Tin).t(), gy).reshape(weight.shape).to(weight.dtype)
+        if ctx.needs_input_grad[2]:                                       # dW3[d] = (e_d * x)^T gy without the [M, D*Tin] outer product
+            u8 = dict(dtype=torch.uint8, device=dev)
+            xI = torch.empty((lib.gcnpt_rows_image_bytes(M, Tin),), **u8)
+            gI = torch.empty((lib.gcnpt_rows_image_bytes(M, H),), **u8)
+            x32c = x32.contiguous()
+            _lib.check(lib.gcnpt_rows_pack(st, _lib.ptr(x32c), M, Tin, _lib.ptr(xI)))
+            _lib.check(lib.gcnpt_rows_pack(st, _lib.ptr(gy), M, H, _lib.ptr(gI)))
+            eT = torch.zeros((D, (M + 31) // 32 * 32), dtype=torch.float32, device=dev)
+            eT[:, :M] = e32.t()
+            dW32 = torch.empty(weight.shape, dtype=torch.float32, device=dev)
+            _lib.check(lib.gcnpt_bilinear_bwd_w(st, _lib.ptr(xI), _lib.ptr(gI), _lib.ptr(eT), M, D, Tin, H, _lib.ptr(dW32)))
+            dW = dW32.to(weight.dtype)
         if ctx.needs_input_grad[3]:
             db = torch.mm(e32.t(), gy).reshape(-1).to(bias.dtype)
         return dx, de, dW, db

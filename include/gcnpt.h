@@ -246,6 +246,15 @@ int gcnpt_bilinear_fwd(void* stream, const void* x, const float* e, const void* 
  *                                             gcnpt_bilinear_fwd(stream, gy_bf16 [M, 32*ceil(H/32)], e, imgT, M, D, H, Tin, dx_planes))
  *   de[m,d] = (x[m] @ W3[d]) . gy[m]       -> gcnpt_bilinear_bwd_e: gy [dev] float32 [M,H]; de_planes [dev] float32
  *                                             [gcnpt_bilinear_de_planes(M,D,Tin,H)][M, D] written completely, summed by the caller. */
+/*   dW3[d][t][h] = sum_m e[m,d] x[m,t] gy[m,h] -> gcnpt_bilinear_bwd_w: x_img / gy_img = gcnpt_rows_pack of x [M,Tin] / gy [M,H]
+ *                                             (float32 in, bf16 fragment images out, gcnpt_rows_image_bytes(M, width) bytes: lane =
+ *                                             column, 8 consecutive rows per lane); eT [dev] float32 [D, 32*ceil(M/32)] = e
+ *                                             transposed, zero padded; dW [dev] float32 in the Linear weight's own layout
+ *                                             ([D*H, Tin] memory read as [D,Tin,H]), written completely, no atomics. */
+size_t gcnpt_rows_image_bytes(int M, int W);
+int gcnpt_rows_pack(void* stream, const float* src, int M, int W, void* img);
+int gcnpt_bilinear_bwd_w(void* stream, const void* x_img, const void* gy_img, const float* eT, int M, int D, int Tin, int H,
+                         float* dW);
 int gcnpt_bilinear_de_planes(int M, int D, int Tin, int H);
 int gcnpt_bilinear_bwd_e(void* stream, const void* x, const float* gy, const void* w_img, int M, int D, int Tin, int H,
                          float* de_planes);

@@ -246,7 +246,8 @@ __global__ __launch_bounds__(BL_THREADS, 1) void bilinear_fwd_kernel(const Bilin
 // fragments by e[m, d] along the tokens (fp32 multiply, repacked to bf16) and issues the 12 MFMAs.  Its 4 waves take every 4th
 // m-step and meet in LDS; every element of dW3 is written once (no atomics).
 // ---------------------------------------------------------------------------------------------------------------------------
-constexpr int BW_MT = 4, BW_NT = 3, BW_ND = 4;
+constexpr int BW_MT = 8, BW_NT = 3, BW_ND = 2;       // 8 x 3 tiles x 2 relations: a scaled gy fragment feeds 8 MFMAs (4 x 3 x 4 was VALU-bound)
+constexpr int BW_RH = 4;                             // tile rows reduced per LDS round (12 tiles x 4 waves = 48 KiB)
 
 __global__ void rows_pack_kernel(const float* __restrict__ src, int M, int W, int m_steps, long long n_lanes, uint4* __restrict__ img) {
     for (long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x; gid < n_lanes; gid += (long long)gridDim.x * blockDim.x) {
@@ -278,7 +279,7 @@ struct BilinearDwParams {
 };
 
 __global__ __launch_bounds__(BL_THREADS, 1) void bilinear_dw_kernel(const BilinearDwParams p) {
-    __shared__ f32x4_t red[BL_WAVES][BW_MT * BW_NT][WAVE];                  // 48 KiB: one relation's tiles at a time
+    __shared__ f32x4_t red[BL_WAVES][BW_RH * BW_NT][WAVE];                  // 48 KiB: half of one relation's tiles at a time
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int id = blockIdx.x;
     const int bt = id % p.tb, rest = id / p.tb;
@@ -292,58 +293,74 @@ __global__ __launch_bounds__(BL_THREADS, 1) void bilinear_dw_kernel(const Biline
 #pragma unroll
             for (int j = 0; j < BW_NT; ++j) acc[q][i][j] = (f32x4_t){0, 0, 0, 0};
     const size_t Mpad = (size_t)p.m_steps * 32;
-    for (int ms = wave; ms < p.m_steps; ms += BL_WAVES) {
-        uint4 xa[BW_MT], gb[BW_NT];
-        float4 ea[BW_ND][2];
+    struct Operands { uint4 xa[BW_MT], gb[BW_NT]; float4 ea[BW_ND][2]; };
+    auto fetch = [&](int ms_raw, Operands& o) {              // clamped: the step past the end re-reads the last one and is not used
+        const int ms = min(ms_raw, p.m_steps - 1);
 #pragma unroll
-        for (int i = 0; i < BW_MT; ++i) xa[i] = p.xI[((size_t)min(t0 + i, p.t_tiles - 1) * p.m_steps + ms) * 64 + lane];
+        for (int i = 0; i < BW_MT; ++i) o.xa[i] = p.xI[((size_t)min(t0 + i, p.t_tiles - 1) * p.m_steps + ms) * 64 + lane];
 #pragma unroll
-        for (int j = 0; j < BW_NT; ++j) gb[j] = p.gI[((size_t)min(h0 + j, p.h_tiles - 1) * p.m_steps + ms) * 64 + lane];
+        for (int j = 0; j < BW_NT; ++j) o.gb[j] = p.gI[((size_t)min(h0 + j, p.h_tiles - 1) * p.m_steps + ms) * 64 + lane];
 #pragma unroll
         for (int q = 0; q < BW_ND; ++q) {
             const float* ep = p.eT + (size_t)min(d0 + q, p.D - 1) * Mpad + (size_t)ms * 32 + 8 * (lane >> 4);
-            ea[q][0] = *reinterpret_cast<const float4*>(ep);
-            ea[q][1] = *reinterpret_cast<const float4*>(ep + 4);
+            o.ea[q][0] = *reinterpret_cast<const float4*>(ep);
+            o.ea[q][1] = *reinterpret_cast<const float4*>(ep + 4);
         }
+    };
+    auto consume = [&](const Operands& o) {
 #pragma unroll
         for (int q = 0; q < BW_ND; ++q) {
 #pragma unroll
             for (int j = 0; j < BW_NT; ++j) {
                 // gy fragment scaled along the tokens by e[., d]: 8 bf16 -> fp32, multiply, back to bf16
-                const uint4 g = gb[j];
+                const uint4 g = o.gb[j];
                 uint4 sg;
-                sg.x = (unsigned)f32_to_bf16(__uint_as_float(g.x << 16) * ea[q][0].x) | ((unsigned)f32_to_bf16(__uint_as_float(g.x & 0xffff0000u) * ea[q][0].y) << 16);
-                sg.y = (unsigned)f32_to_bf16(__uint_as_float(g.y << 16) * ea[q][0].z) | ((unsigned)f32_to_bf16(__uint_as_float(g.y & 0xffff0000u) * ea[q][0].w) << 16);
-                sg.z = (unsigned)f32_to_bf16(__uint_as_float(g.z << 16) * ea[q][1].x) | ((unsigned)f32_to_bf16(__uint_as_float(g.z & 0xffff0000u) * ea[q][1].y) << 16);
-                sg.w = (unsigned)f32_to_bf16(__uint_as_float(g.w << 16) * ea[q][1].z) | ((unsigned)f32_to_bf16(__uint_as_float(g.w & 0xffff0000u) * ea[q][1].w) << 16);
+                sg.x = (unsigned)f32_to_bf16(__uint_as_float(g.x << 16) * o.ea[q][0].x) | ((unsigned)f32_to_bf16(__uint_as_float(g.x & 0xffff0000u) * o.ea[q][0].y) << 16);
+                sg.y = (unsigned)f32_to_bf16(__uint_as_float(g.y << 16) * o.ea[q][0].z) | ((unsigned)f32_to_bf16(__uint_as_float(g.y & 0xffff0000u) * o.ea[q][0].w) << 16);
+                sg.z = (unsigned)f32_to_bf16(__uint_as_float(g.z << 16) * o.ea[q][1].x) | ((unsigned)f32_to_bf16(__uint_as_float(g.z & 0xffff0000u) * o.ea[q][1].y) << 16);
+                sg.w = (unsigned)f32_to_bf16(__uint_as_float(g.w << 16) * o.ea[q][1].z) | ((unsigned)f32_to_bf16(__uint_as_float(g.w & 0xffff0000u) * o.ea[q][1].w) << 16);
 #pragma unroll
                 for (int i = 0; i < BW_MT; ++i)       // swapped operands: rows = h (scaled gy), columns = t (x): a lane ends with 4 consecutive h of one t
-                    acc[q][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, sg), __builtin_bit_cast(bf16x8_t, xa[i]),
+                    acc[q][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, sg), __builtin_bit_cast(bf16x8_t, o.xa[i]),
                                                                           acc[q][i][j], 0, 0, 0);
             }
         }
+    };
+    // two m-steps per round: the operands of the next one are in flight while the current one is multiplied
+    Operands oa, ob;
+    fetch(wave, oa);
+    for (int ms = wave; ms < p.m_steps; ms += 2 * BL_WAVES) {
+        fetch(ms + BL_WAVES, ob);
+        consume(oa);
+        fetch(ms + 2 * BL_WAVES, oa);
+        if (ms + BL_WAVES < p.m_steps) consume(ob);          // wave-uniform, no load inside
     }
-    // waves meet in LDS, one relation at a time (12 tiles x 4 waves = 48 KiB)
+    // waves meet in LDS, BW_RH tile rows of one relation at a time
     for (int q = 0; q < BW_ND; ++q) {
-        __syncthreads();
+        for (int ih = 0; ih < BW_MT; ih += BW_RH) {
+            __syncthreads();
 #pragma unroll
-        for (int i = 0; i < BW_MT; ++i)
+            for (int q2 = 0; q2 < BW_ND; ++q2)
 #pragma unroll
-            for (int j = 0; j < BW_NT; ++j) red[wave][i * BW_NT + j][lane] = acc[q][i][j];
-        __syncthreads();
-        const int d = d0 + q;
-        for (int tt = wave; tt < BW_MT * BW_NT; tt += BL_WAVES) {
-            const int i = tt / BW_NT, j = tt - i * BW_NT;
-            f32x4_t v = red[0][tt][lane];
+                for (int i = 0; i < BW_MT; ++i)
 #pragma unroll
-            for (int w = 1; w < BL_WAVES; ++w) v += red[w][tt][lane];
-            const int t = (t0 + i) * 16 + (lane & 15);
-            const int h = (h0 + j) * 16 + 4 * (lane >> 4);
-            if (d < p.D && t < p.Tin && t0 + i < p.t_tiles && h0 + j < p.h_tiles) {
-                float* dst = p.dW + ((size_t)d * p.Tin + t) * p.H + h;
+                    for (int j = 0; j < BW_NT; ++j)
+                        if (q2 == q && i >= ih && i < ih + BW_RH) red[wave][(i - ih) * BW_NT + j][lane] = acc[q2][i][j];      // static register indices
+            __syncthreads();
+            const int d = d0 + q;
+            for (int tt = wave; tt < BW_RH * BW_NT; tt += BL_WAVES) {
+                const int i = ih + tt / BW_NT, j = tt % BW_NT;
+                f32x4_t v = red[0][tt][lane];
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    if (h + g < p.H) dst[g] = v[g];
+                for (int w = 1; w < BL_WAVES; ++w) v += red[w][tt][lane];
+                const int t = (t0 + i) * 16 + (lane & 15);
+                const int h = (h0 + j) * 16 + 4 * (lane >> 4);
+                if (d < p.D && t < p.Tin && t0 + i < p.t_tiles && h0 + j < p.h_tiles) {
+                    float* dst = p.dW + ((size_t)d * p.Tin + t) * p.H + h;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        if (h + g < p.H) dst[g] = v[g];
+                }
             }
         }
     }

@@ -391,9 +391,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    force_dist = bool(os.environ.get("GCNPT_BENCH_FORCE_DIST"))      # rehearsal: the N > 1 code path (RCCL init, overlapped all-reduce) with one rank
+    saved_stdout = None
+    if world > 1 or force_dist:
+        # RCCL prints a version banner on stdout (C stdio) when the communicator is created; the contract is ONE JSON line on
+        # rank 0's stdout, so everything but that line goes to stderr: fd 1 points at fd 2 until the result is printed
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if os.environ.get("GCNPT_BENCH_ONE_DEVICE"):          # rehearsal of the N > 1 code path on a 1-GPU box (with --dist-backend gloo)
             local = 0
         torch.cuda.set_device(local)
@@ -412,13 +422,14 @@ def main():
     from gcn_over_pruned_trees_amd.shard import OverlappedAllReduce
 
     # ---- the timed step: layer stack fwd+bwd (+ overlapped gradient all-reduce when N > 1)
-    replays = [capture(lambda k=k: stack.step(k), use_graph) for k in range(2 if world > 1 else 1)]
+    multi = world > 1 or force_dist
+    replays = [capture(lambda k=k: stack.step(k), use_graph) for k in range(2 if multi else 1)]
     graphed = replays[0][1]
     # SUM, not AVG: the 1/world factor belongs to the optimizer's learning rate, and SUM is supported by every backend
-    reducer = OverlappedAllReduce(stack.buckets, dist, average=False) if world > 1 else None
+    reducer = OverlappedAllReduce(stack.buckets, dist, average=False) if multi else None
 
     def run(i):
-        k = i & 1 if world > 1 else 0
+        k = i & 1 if multi else 0
         if reducer:
             reducer.before_write(k)
         replays[k][0]()
@@ -429,7 +440,7 @@ def main():
     if reducer:
         reducer.finish()
         torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         wall = float(tmax.item())
@@ -491,8 +502,13 @@ def main():
                                                "weight pack); survey_8d_bytes = SURVEY.md 8(d)'s formula for the layer math alone, over the whole step time"}
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
-        print(json.dumps(result))
-    if world > 1:
+        sys.stdout.flush()
+        if saved_stdout is not None:
+            os.dup2(saved_stdout, 1)
+        print(json.dumps(result), flush=True)
+        if saved_stdout is not None:
+            os.dup2(2, 1)                                  # teardown messages of the process group: not on stdout either
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     return result

@@ -33,6 +33,7 @@ SIGNATURES = {
     "gcnpt_diag_layer_fwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p, _f, _u64, _p]),
     "gcnpt_diag_layer_bwd": (_i, [_p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _f]),
     "gcnpt_gather_trees": (_i, [_p] * 11 + [_i, _i, _i, _p, _i, _i, _i] + [_p] * 9),
+    "gcnpt_compact_trees": (_i, [_p] * 10 + [_i] * 5 + [_p] * 11),
     "gcnpt_bilinear_packed_bytes": (_sz, [_i, _i, _i]),
     "gcnpt_bilinear_supported": (_i, [_i, _i, _i]),
     "gcnpt_bilinear_planes": (_i, [_i, _i, _i, _i]),

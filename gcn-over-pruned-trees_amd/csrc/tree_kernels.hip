@@ -557,6 +557,95 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_trees_kernel(const Tree
     }
 }
 
+// ---- N1: "pooled-only" rows (gcn.py:116-121 pools h over the tokens of the pruned tree only, and a tree token's row of
+// every layer depends on tree tokens only -- the adjacency has no entry outside the tree).  The kept tokens of a sentence
+// are renumbered 0..kept-1 in token order and the pattern is rewritten in those numbers for a [B, Tc] batch: the layer
+// kernels then run on B*Tc rows instead of B*T (a pruned tree keeps ~1 token in 4-8), with identical values in every
+// kept row.  One workgroup per sentence; slot numbers of the sentence's tokens live in LDS.
+constexpr int COMPACT_THREADS = 256;
+__global__ __launch_bounds__(COMPACT_THREADS) void compact_trees_kernel(const TreeArrays src, int B, int T, int cap, int Tc, int cap_c,
+                                                                       const TreeArrays dst, int64_t* __restrict__ tok,
+                                                                       int32_t* __restrict__ kept_out) {
+    extern __shared__ int c_slot[];                      // [T] slot of token i, or -1
+    __shared__ int s_wave[COMPACT_THREADS / WAVE];
+    __shared__ int s_base;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) s_base = 0;
+    __syncthreads();
+    // exclusive scan of the in-tree flags, 256 tokens per round
+    for (int i0 = 0; i0 < T; i0 += COMPACT_THREADS) {
+        const int i = i0 + t;
+        const bool in = i < T && src.pool_mask[(size_t)b * T + i] == 0;
+        const unsigned long long m = __ballot(in);
+        if (lane == 0) s_wave[wave] = __popcll(m);
+        __syncthreads();
+        int before = s_base;
+        for (int w = 0; w < wave; ++w) before += s_wave[w];
+        if (i < T) c_slot[i] = in ? before + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+        __syncthreads();
+        if (t == 0) {
+            int tot = s_base;
+            for (int w = 0; w < COMPACT_THREADS / WAVE; ++w) tot += s_wave[w];
+            s_base = tot;
+        }
+        __syncthreads();
+    }
+    const int kept = s_base;
+    const int nnz = src.row_ptr[(size_t)b * (T + 1) + T] - b * cap;
+    const int nnzT = src.rowT_ptr ? src.rowT_ptr[(size_t)b * (T + 1) + T] - b * cap : 0;
+    int code = src.status[b];
+    if (code == 0 && kept > Tc) code = GCNPT_E_LENGTH;
+    if (code == 0 && (nnz > cap_c || nnzT > cap_c)) code = GCNPT_E_CAPACITY;
+    const bool ok = code == 0;
+    if (t == 0) {
+        dst.status[b] = code;
+        kept_out[b] = ok ? kept : 0;
+        if (ok) atomicMax(&dst.status[B], kept);
+    }
+    // slots past the kept tokens (or the whole sentence when it failed): no entries, excluded from pooling
+    const int first_free = ok ? kept : 0;
+    for (int j = first_free + t; j <= Tc; j += COMPACT_THREADS) {
+        dst.row_ptr[(size_t)b * (Tc + 1) + j] = b * cap_c + (ok ? nnz : 0);
+        if (dst.rowT_ptr) dst.rowT_ptr[(size_t)b * (Tc + 1) + j] = b * cap_c + (ok ? nnzT : 0);
+        if (j < Tc) {
+            tok[(size_t)b * Tc + j] = -1;
+            dst.pool_mask[(size_t)b * Tc + j] = 1;
+            int4* e = reinterpret_cast<int4*>(dst.ell + ((size_t)b * Tc + j) * 8);
+            e[0] = make_int4(0, 0, 0, 0); e[1] = make_int4(0, 0, 0, 0);
+            if (dst.ellT) {
+                int4* eT = reinterpret_cast<int4*>(dst.ellT + ((size_t)b * Tc + j) * 8);
+                eT[0] = make_int4(0, 0, 0, 0); eT[1] = make_int4(0, 0, 0, 0);
+            }
+        }
+    }
+    if (!ok) return;
+    auto renumber_head = [&](const int32_t* in, int32_t* out) {       // [count, 7 columns] -> the same in slot numbers
+        const int n = in[0];
+        out[0] = n;
+#pragma unroll
+        for (int k = 1; k < 8; ++k) out[k] = k <= n ? c_slot[min(max(in[k], 0), T - 1)] : 0;
+    };
+    for (int i = t; i < T; i += COMPACT_THREADS) {
+        const int j = c_slot[i];
+        if (j < 0) continue;
+        tok[(size_t)b * Tc + j] = i;
+        dst.pool_mask[(size_t)b * Tc + j] = 0;
+        dst.row_ptr[(size_t)b * (Tc + 1) + j] = b * cap_c + src.row_ptr[(size_t)b * (T + 1) + i] - b * cap;
+        renumber_head(src.ell + ((size_t)b * T + i) * 8, dst.ell + ((size_t)b * Tc + j) * 8);
+        if (dst.rowT_ptr) {
+            dst.rowT_ptr[(size_t)b * (Tc + 1) + j] = b * cap_c + src.rowT_ptr[(size_t)b * (T + 1) + i] - b * cap;
+            renumber_head(src.ellT + ((size_t)b * T + i) * 8, dst.ellT + ((size_t)b * Tc + j) * 8);
+        }
+    }
+    for (int k = t; k < nnz; k += COMPACT_THREADS) {
+        dst.col_idx[(size_t)b * cap_c + k] = c_slot[min(max(src.col_idx[(size_t)b * cap + k], 0), T - 1)];
+        if (dst.label) dst.label[(size_t)b * cap_c + k] = src.label[(size_t)b * cap + k];
+    }
+    if (dst.colT_idx)
+        for (int k = t; k < nnzT; k += COMPACT_THREADS)
+            dst.colT_idx[(size_t)b * cap_c + k] = c_slot[min(max(src.colT_idx[(size_t)b * cap + k], 0), T - 1)];
+}
+
 }  // namespace gcnpt
 
 using namespace gcnpt;
@@ -643,6 +732,34 @@ extern "C" int gcnpt_gather_trees(void* stream, const int32_t* src_row_ptr, cons
     const TreeArrays dst{row_ptr, col_idx, label, rowT_ptr, colT_idx, ell, ellT, pool_mask, status};
     hipLaunchKernelGGL(gather_trees_kernel, dim3(B), dim3(GATHER_THREADS), 0, (hipStream_t)stream, src, src_len, S, Ts, cap_s, idx, B, T,
                        cap, dst);
+    GCNPT_HIP_CHECK(hipGetLastError());
+    return GCNPT_OK;
+}
+
+extern "C" int gcnpt_compact_trees(void* stream, const int32_t* src_row_ptr, const int32_t* src_col_idx, const int32_t* src_label,
+                                   const int32_t* src_rowT_ptr, const int32_t* src_colT_idx, const int32_t* src_ell,
+                                   const int32_t* src_ellT, const uint8_t* src_pool_mask, const int32_t* src_status, int B, int T,
+                                   int cap, int Tc, int cap_c, int32_t* row_ptr, int32_t* col_idx, int32_t* label,
+                                   int32_t* rowT_ptr, int32_t* colT_idx, int32_t* ell, int32_t* ellT, uint8_t* pool_mask,
+                                   int32_t* status, int64_t* tok, int32_t* kept) {
+    GCNPT_REQUIRE(src_row_ptr && src_col_idx && src_ell && src_pool_mask && src_status, "compact_trees: null source pointer");
+    GCNPT_REQUIRE(row_ptr && col_idx && ell && pool_mask && status && tok && kept, "compact_trees: null output pointer");
+    GCNPT_REQUIRE(B > 0 && T > 0 && cap > 0 && Tc > 0 && cap_c > 0, "compact_trees: sizes must be positive");
+    GCNPT_REQUIRE(!label || src_label, "compact_trees: labels wanted but the source holds none");
+    GCNPT_REQUIRE((rowT_ptr == nullptr) == (colT_idx == nullptr) && (rowT_ptr == nullptr) == (ellT == nullptr),
+                  "compact_trees: rowT_ptr, colT_idx and ellT go together");
+    GCNPT_REQUIRE(!rowT_ptr || (src_rowT_ptr && src_colT_idx && src_ellT), "compact_trees: transposed pattern wanted but the source holds none");
+    if ((long long)B * cap_c > 0x7fffffffLL) return fail(GCNPT_E_UNSUPPORTED, "compact_trees: B*cap_c overflows int32");
+    const size_t lds = sizeof(int) * (size_t)T;
+    if (lds > 60 * 1024) return fail(GCNPT_E_UNSUPPORTED, "compact_trees: T=%d exceeds the %d tokens a sentence may have", T, 60 * 1024 / 4);
+    const TreeArrays src{const_cast<int32_t*>(src_row_ptr), const_cast<int32_t*>(src_col_idx), const_cast<int32_t*>(src_label),
+                         const_cast<int32_t*>(rowT_ptr ? src_rowT_ptr : nullptr), const_cast<int32_t*>(src_colT_idx),
+                         const_cast<int32_t*>(src_ell), const_cast<int32_t*>(src_ellT), const_cast<uint8_t*>(src_pool_mask),
+                         const_cast<int32_t*>(src_status)};
+    const TreeArrays dst{row_ptr, col_idx, label, rowT_ptr, colT_idx, ell, ellT, pool_mask, status};
+    hipStream_t s = (hipStream_t)stream;
+    GCNPT_HIP_CHECK(hipMemsetAsync(status + B, 0, sizeof(int32_t), s));         // status[B] = most kept tokens in a sentence (atomicMax)
+    hipLaunchKernelGGL(compact_trees_kernel, dim3(B), dim3(COMPACT_THREADS), lds, s, src, B, T, cap, Tc, cap_c, dst, tok, kept);
     GCNPT_HIP_CHECK(hipGetLastError());
     return GCNPT_OK;
 }

@@ -30,7 +30,7 @@ import torch.nn as nn
 
 from .. import _lib
 from ..utils import constant
-from .tree import PrunedTrees, adj_to_csr, prune_to_csr
+from .tree import CompactTrees, PrunedTrees, adj_to_csr, prune_to_csr
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -400,11 +400,20 @@ class GCNRelationModel(nn.Module):
             # lengths, head_to_tree, tree_to_adj and the upload (gcn.py:96-112) in one launch, no host round trip
             trees = prune_to_csr(head, subj_pos, obj_pos, deprel, self.opt['prune_k'], masks=masks,
                                  want_label=self.adj_type != 'regular')
-        elif (trees.B, trees.T) != tuple(head.shape):
-            raise ValueError("trees are for a [%d,%d] batch, the inputs are %s" % (trees.B, trees.T, tuple(head.shape)))
-        if self.opt.get('gcn_check_trees', True):
-            trees.check(expect_maxlen=head.shape[1])
+            if self.opt.get('gcn_check_trees', True):
+                trees.check(expect_maxlen=head.shape[1])
+            if self.opt.get('gcn_pooled_only', False):
+                trees = trees.compact()                    # one host sync for the width; a TreeCache avoids it
+        else:
+            if (trees.B, trees.T) != tuple(head.shape):
+                raise ValueError("trees are for a [%d,%d] batch, the inputs are %s" % (trees.B, trees.T, tuple(head.shape)))
+            if self.opt.get('gcn_check_trees', True):
+                trees.check(expect_maxlen=head.shape[1])
         h, pool_mask = self.gcn(trees, inputs)
+        if isinstance(trees, CompactTrees):
+            # only the tokens of the pruned trees were computed ([B,Tc,H]); the three poolings never look at any other
+            # (entity tokens are always kept, model/tree.py:96-128), so the pooled vectors are the full batch's
+            subj_pos, obj_pos = trees.take(subj_pos, fill=150), trees.take(obj_pos, fill=150)      # 150: the loader's pad value (loader.py:120-121)
         # gcn.py:116-121: three masked poolings and the concat, one pass over h (masks straight from the position tensors)
         pooled = pool3(h, pool_mask, subj_pos, obj_pos, type=self.opt['pooling'])
         h_out = pooled[:, :self.opt['hidden_dim']]
@@ -579,14 +588,25 @@ class GCN(nn.Module):
         else:
             words, masks, pos, deprel, head, subj_pos, obj_pos = inputs
             ner = None
+        ct = adj if isinstance(adj, CompactTrees) else None
+        use_rnn = bool(self.opt.get('rnn', False))
+        if ct is not None:
+            # "pooled-only" rows: the layers run on the kept tokens.  Without an LSTM in front the lookups themselves are
+            # done for those tokens only; with one, its outputs are gathered
+            adj, deprel = ct.trees, ct.take(deprel)
+            if not use_rnn:
+                words, pos = ct.take(words), ct.take(pos)
+                ner = ct.take(ner) if ner is not None else None
         parts = [words if words.dim() > 2 else self._word_embeddings(words)]    # gcn.py:235-239
         if self.opt['pos_dim'] > 0:
             parts.append(self.pos_emb(pos))
         if self.opt['ner_dim'] > 0 and ner is not None:
             parts.append(self.ner_emb(ner))
         embs = self.in_drop(torch.cat(parts, dim=2))
-        if self.opt.get('rnn', False):
+        if use_rnn:
             gcn_inputs = self.rnn_drop(self.encode_with_rnn(embs, masks, words.size(0)))
+            if ct is not None:
+                gcn_inputs = ct.take(gcn_inputs)
         else:
             gcn_inputs = embs
 

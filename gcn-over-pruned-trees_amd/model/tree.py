@@ -86,12 +86,79 @@ class PrunedTrees(object):
         rp = self.row_ptr.view(self.B, self.T + 1)
         return (rp[:, -1] - rp[:, 0]).to(torch.int64)
 
+    def compact(self, Tc=None):
+        """
+        "Pooled-only" rows: the same pattern for a [B, Tc] batch that holds only the tokens of the pruned
+        trees (pool_mask False), renumbered in token order -- see gcnpt_compact_trees in include/gcnpt.h.  Tc=None takes the
+        most tokens any sentence keeps (ONE host sync; pass a fixed Tc, e.g. a TreeCache's, to stay asynchronous: a sentence
+        that keeps more gets status E_LENGTH).  Returns a CompactTrees.
+        """
+        if Tc is None:
+            Tc = max(int((~self.pool_mask.view(self.B, self.T)).sum(1).max()), 1)
+        Tc = int(Tc)
+        cap_c = 3 * Tc if self.cap == 3 * self.T else min(self.cap, Tc * Tc)
+        bufs = _alloc(self.B, Tc, cap_c, self.device, self.label is not None, self.rowT_ptr is not None)
+        row_ptr, col_idx, label, rowT_ptr, colT_idx, ell, ellT, pool_mask, status = bufs
+        tok = torch.empty((self.B, Tc), dtype=torch.int64, device=self.device)
+        kept = torch.empty((self.B,), dtype=torch.int32, device=self.device)
+        P = _lib.ptr
+        _lib.check(_lib.lib().gcnpt_compact_trees(
+            _lib.stream(), P(self.row_ptr), P(self.col_idx), P(self.label), P(self.rowT_ptr), P(self.colT_idx), P(self.ell), P(self.ellT),
+            P(self.pool_mask), P(self.status), self.B, self.T, self.cap, Tc, cap_c, P(row_ptr), P(col_idx), P(label), P(rowT_ptr),
+            P(colT_idx), P(ell), P(ellT), P(pool_mask), P(status), P(tok), P(kept)))
+        return CompactTrees(PrunedTrees(self.B, Tc, cap_c, *bufs), tok, kept, self.T)
+
     def to_dense(self):
         """float32 [B,T,T] with the labels tree_to_adj writes (deprel id, +42 for the reverse edge, 84 on the diagonal)."""
         adj = torch.empty((self.B, self.T, self.T), dtype=torch.float32, device=self.device)
         _lib.check(_lib.lib().gcnpt_csr_to_adj(_lib.stream(), _lib.ptr(self.row_ptr), _lib.ptr(self.col_idx),
                                                _lib.ptr(self.label), self.B, self.T, _lib.ptr(adj)))
         return adj
+
+
+class CompactTrees(object):
+    """
+    PrunedTrees over the kept tokens only (PrunedTrees.compact / TreeCache.batch(compact=True)).
+
+    trees  PrunedTrees for [B, Tc]       tok  int64 [B,Tc] token position of each slot (-1 = empty slot)
+    kept   int32 [B] tokens per sentence  T    width of the batch the token positions refer to
+
+    GCNRelationModel / GCNClassifier.forward(inputs, trees=<CompactTrees>) run the layers on [B,Tc] rows and pool them;
+    logits are the ones of the full batch (the reference pools over exactly these tokens, gcn.py:116-121).
+    GCN.forward(<CompactTrees>, inputs) returns ([B,Tc,H], mask [B,Tc,1]).
+    """
+
+    def __init__(self, trees, tok, kept, T):
+        self.trees, self.tok, self.kept, self.T = trees, tok, kept, int(T)
+        self.B, self.Tc = trees.B, trees.T
+        self._index = None
+
+    @property
+    def device(self):
+        return self.trees.device
+
+    @property
+    def valid(self):
+        return self.tok >= 0
+
+    def check(self, expect_maxlen=None):
+        self.trees.check()
+        return self
+
+    def take(self, t, fill=None):
+        """Rows of t [B,T,...] (or [B,T]) at the kept tokens -> [B,Tc,...]; empty slots read token 0, or `fill` if given."""
+        if t.shape[0] != self.B or t.shape[1] != self.T:
+            raise ValueError("take: tensor is %s, the trees are for a [%d,%d] batch" % (tuple(t.shape), self.B, self.T))
+        if self._index is None:
+            self._index = self.tok.clamp(min=0)
+        idx = self._index
+        if t.dim() > 2:
+            idx = idx.view(self.B, self.Tc, *([1] * (t.dim() - 2))).expand(-1, -1, *t.shape[2:])
+        out = torch.gather(t, 1, idx)
+        if fill is not None:
+            v = self.valid
+            out = torch.where(v.view(self.B, self.Tc, *([1] * (t.dim() - 2))) if t.dim() > 2 else v, out, torch.full_like(out, fill))
+        return out
 
 
 def _alloc(B, T, cap, device, want_label, want_transpose):
@@ -167,29 +234,45 @@ class TreeCache(object):
     PrunedTrees of a batch from the cached rows (one small copy kernel), bit-identical to pruning that batch directly.
     """
 
-    def __init__(self, trees, lens, prune_k):
+    def __init__(self, trees, lens, prune_k, compact=None):
         self.trees, self.lens, self.prune_k = trees, lens, int(prune_k)
+        self.compact = compact            # CompactTrees of the whole dataset, or None
 
     def __len__(self):
         return self.trees.B
 
     @classmethod
-    def build(cls, head, subj_pos, obj_pos, deprel, prune_k, masks=None, lens=None, want_label=True):
+    def build(cls, head, subj_pos, obj_pos, deprel, prune_k, masks=None, lens=None, want_label=True, compact=False):
         """head/subj_pos/obj_pos/deprel: int64 [S,Ts] CUDA tensors of the WHOLE dataset padded to its longest sentence;
         masks (True = pad) or lens as in prune_to_csr.  Per-sentence errors stay in the cache and surface in the
-        batches that contain the sentence (PrunedTrees.check)."""
+        batches that contain the sentence (PrunedTrees.check).  compact=True also keeps the kept-token form of every
+        sentence (PrunedTrees.compact; one host sync here for the dataset's widest tree), for batch(..., compact=True)."""
         trees = prune_to_csr(head, subj_pos, obj_pos, deprel, prune_k, masks=masks, lens=lens, want_label=want_label)
         if lens is None:
             lens = (masks == 0).sum(1)
         lens = lens.to(device=head.device, dtype=torch.int32).contiguous()
-        return cls(trees, lens, prune_k)
+        return cls(trees, lens, prune_k, trees.compact() if compact else None)
 
-    def batch(self, idx, T, want_label=None):
+    def batch(self, idx, T, want_label=None, compact=False, Tc=None):
         """idx: int64 [B] sentence numbers (CUDA tensor; repeats allowed); T: the width the batch tensors are padded to
-        (the reference pads to the longest sentence of the batch, gcn.py:97)."""
-        src = self.trees
+        (the reference pads to the longest sentence of the batch, gcn.py:97).  compact=True: a CompactTrees of width Tc
+        (default: the widest tree of the dataset) whose token positions refer to the [B,T] batch."""
         idx = _lib.require_gpu(idx).to(torch.int64).contiguous()
-        B, T = int(idx.numel()), int(T)
+        if compact:
+            if self.compact is None:
+                raise ValueError("the cache was built without compact=True")
+            width = int(Tc) if Tc is not None else self.compact.Tc
+            ct = self._gather(self.compact.trees, self.compact.kept, idx, width, want_label)
+            n = min(width, self.compact.Tc)
+            tok = torch.full((idx.numel(), width), -1, dtype=torch.int64, device=idx.device)
+            tok[:, :n] = self.compact.tok.index_select(0, idx.clamp(0, len(self) - 1))[:, :n]
+            tok = torch.where((ct.status[:-1] == 0).unsqueeze(1), tok, torch.full_like(tok, -1))
+            return CompactTrees(ct, tok, self.compact.kept.index_select(0, idx.clamp(0, len(self) - 1)), int(T))
+        return self._gather(self.trees, self.lens, idx, int(T), want_label)
+
+    @staticmethod
+    def _gather(src, lens, idx, T, want_label):
+        B = int(idx.numel())
         want_label = (src.label is not None) if want_label is None else want_label
         if want_label and src.label is None:
             raise ValueError("the cache was built without labels")
@@ -199,7 +282,7 @@ class TreeCache(object):
         P = _lib.ptr
         _lib.check(_lib.lib().gcnpt_gather_trees(
             _lib.stream(), P(src.row_ptr), P(src.col_idx), P(src.label), P(src.rowT_ptr), P(src.colT_idx), P(src.ell), P(src.ellT),
-            P(src.pool_mask), P(src.status), P(self.lens), src.B, src.T, src.cap, P(idx), B, T, cap,
+            P(src.pool_mask), P(src.status), P(lens), src.B, src.T, src.cap, P(idx), B, T, cap,
             P(row_ptr), P(col_idx), P(label), P(rowT_ptr), P(colT_idx), P(ell), P(ellT), P(pool_mask), P(status)))
         return PrunedTrees(B, T, cap, *bufs)
 

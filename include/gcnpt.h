@@ -58,7 +58,7 @@ extern "C" {
 #define GCNPT_E_CAPACITY -8       /* a sentence needs more than `cap` adjacency entries */
 #define GCNPT_E_HIP -9            /* a HIP runtime call failed */
 #define GCNPT_E_UNSUPPORTED -10   /* shape outside what the kernels are built for */
-#define GCNPT_E_LENGTH -11        /* gcnpt_gather_trees: a cached sentence is longer than the batch's T */
+#define GCNPT_E_LENGTH -11        /* gcnpt_gather_trees / gcnpt_compact_trees: a sentence does not fit the width asked for */
 
 int gcnpt_abi_version(void);
 const char* gcnpt_last_error(void);
@@ -223,6 +223,24 @@ int gcnpt_gather_trees(void* stream, const int32_t* src_row_ptr, const int32_t* 
                        const int32_t* src_len, int S, int Ts, int cap_s, const int64_t* idx, int B, int T, int cap,
                        int32_t* row_ptr, int32_t* col_idx, int32_t* label, int32_t* rowT_ptr, int32_t* colT_idx,
                        int32_t* ell, int32_t* ellT, uint8_t* pool_mask, int32_t* status);
+
+/* ---- N1, second half: "pooled-only" rows (model/gcn.py:116-121 pools over the tokens of the pruned tree only; a tree token's
+ * row of every layer depends on tree tokens only, the adjacency has no entry outside the tree, model/tree.py:167-204) ----
+ * Rewrites the arrays of a [B, T] batch (src_*, as gcnpt_prune_to_csr / gcnpt_gather_trees / gcnpt_adj_to_csr wrote them) for a
+ * [B, Tc] batch that holds only the tokens with pool_mask == 0, renumbered 0..kept-1 in token order: same entries, same
+ * order, columns in slot numbers; slots kept..Tc-1 are empty and carry pool_mask 1.  The layer kernels run unchanged on the
+ * result and give, in slot j of sentence b, exactly the row they give for token tok[b*Tc+j] of the full batch.
+ *   tok  [dev] int64 [B*Tc]  token position of each slot, -1 for an empty slot (the caller gathers its layer inputs with it)
+ *   kept [dev] int32 [B]     tokens kept per sentence
+ *   status[b] = the source's code, GCNPT_E_LENGTH when a sentence keeps more than Tc tokens, GCNPT_E_CAPACITY when it has
+ *   more than cap_c entries (the sentence is then empty); status[B] = most tokens kept by a sentence of the batch.
+ * label / rowT_ptr+colT_idx+ellT may be NULL. */
+int gcnpt_compact_trees(void* stream, const int32_t* src_row_ptr, const int32_t* src_col_idx, const int32_t* src_label,
+                        const int32_t* src_rowT_ptr, const int32_t* src_colT_idx, const int32_t* src_ell,
+                        const int32_t* src_ellT, const uint8_t* src_pool_mask, const int32_t* src_status, int B, int T,
+                        int cap, int Tc, int cap_c, int32_t* row_ptr, int32_t* col_idx, int32_t* label, int32_t* rowT_ptr,
+                        int32_t* colT_idx, int32_t* ell, int32_t* ellT, uint8_t* pool_mask, int32_t* status, int64_t* tok,
+                        int32_t* kept);
 
 /* ---- N3: the relation-conditioned traversal of adj_type == 'full_deprel', model/gcn.py:400-415 (traverse_deprel) ------------
  *   y[m,:] = sum_d e[m,d] * (x[m,:] @ W3[d]),   W3 = Linear.weight.reshape(D, Tin, H) (gcn.py:301: a reinterpretation of the

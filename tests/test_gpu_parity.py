@@ -679,6 +679,147 @@ def test_tree_cache_errors_and_model_hook(api, dev):
 
 
 # ---------------------------------------------------------------------------------------------------
+# N1, second half: "pooled-only" rows (gcnpt_compact_trees)
+# ---------------------------------------------------------------------------------------------------
+def test_compact_trees_structure(api, dev):
+    """The kept-token form is the SAME adjacency restricted to the tokens of the tree: its dense matrix is the reference's
+    matrix with the empty rows and columns struck out; ELL heads, transposed pattern, masks and the token map are exact."""
+    gcn, tree = api
+    from gcn_over_pruned_trees_amd import _lib
+    g = load_golden("trees_random.npz")
+    S, Ts = g["head"].shape
+    for K in (0, 1, 2):
+        full = _prune(tree, g, K, dev).check()
+        ref = dense_from_coo(g["coo_k%d" % K], S, Ts)
+        in_tree = (ref != 0).any(2)
+        kept = in_tree.sum(1)
+        ct = full.compact()
+        assert ct.Tc == kept.max() and ct.T == Ts and ct.B == S
+        ct.check()
+        np.testing.assert_array_equal(ct.kept.cpu().numpy(), kept)
+        assert int(ct.trees.status[-1]) == kept.max()
+        tok = ct.tok.cpu().numpy()
+        dense_c = ct.trees.to_dense().cpu().numpy()
+        want = np.zeros_like(dense_c)
+        for b in range(S):
+            t = np.nonzero(in_tree[b])[0]
+            np.testing.assert_array_equal(tok[b, :len(t)], t)
+            assert (tok[b, len(t):] == -1).all()
+            want[b, :len(t), :len(t)] = ref[b][np.ix_(t, t)]
+        np.testing.assert_array_equal(dense_c, want)
+        _check_ell(ct.trees, want)
+        np.testing.assert_array_equal(ct.trees.pool_mask.cpu().numpy()[:, :, 0], tok < 0)
+        # transposed entries: the same set as the forward pattern of the transposed matrix
+        wide = full.compact(Tc=int(kept.max()) + 5)                     # any width that fits gives the same trees, padded
+        np.testing.assert_array_equal(wide.trees.to_dense().cpu().numpy()[:, :ct.Tc, :ct.Tc], want)
+        assert (wide.tok[:, ct.Tc:] == -1).all()
+        narrow = full.compact(Tc=int(kept.max()) - 1)                   # the widest sentences do not fit: flagged, left empty
+        st = narrow.trees.status.cpu().numpy()[:-1]
+        np.testing.assert_array_equal(st != 0, kept == kept.max())
+        assert (st[kept == kept.max()] == _lib.E_LENGTH).all()
+        assert narrow.trees.pool_mask.cpu().numpy()[kept == kept.max()].all()
+        with pytest.raises(tree.TreeError):
+            narrow.check()
+        # a cache hands out the same thing for any batch composition
+        lens = g["lens"].astype(np.int32)
+        cache = tree.TreeCache.build(_t(g["head"], dev), _t(g["subj_pos"], dev), _t(g["obj_pos"], dev), _t(g["deprel"], dev), K,
+                                     lens=_t(lens, dev), compact=True)
+        idx = np.random.RandomState(K).randint(0, S, size=40)
+        got = cache.batch(_t(idx.astype(np.int64), dev), Ts, compact=True).check()
+        np.testing.assert_array_equal(got.tok.cpu().numpy(), tok[idx])
+        np.testing.assert_array_equal(got.trees.to_dense().cpu().numpy(), want[idx])
+        np.testing.assert_array_equal(got.trees.ellT.cpu().numpy().reshape(40, -1), ct.trees.ellT.cpu().numpy().reshape(S, -1)[idx])
+        np.testing.assert_array_equal(got.kept.cpu().numpy(), kept[idx])
+
+
+@pytest.mark.parametrize("compute", [torch.float32, torch.bfloat16])
+def test_pooled_only_rows_equal_full_batch_rows(api, dev, compute):
+    """Layers on the kept tokens give, row for row, what the full batch gives for those tokens (forward and dx exactly:
+    a row never sees a token outside the tree); weight gradients agree when the upstream gradient is zero off the tree,
+    which is what the pooling hands back."""
+    gcn, tree = api
+    from gcn_over_pruned_trees_amd.utils import synthetic
+    B, T, din, hid, K = 50, 100, 360, 200, 1
+    tb = synthetic.random_tree_batch(77, B, T, "tacred")
+    masks = np.arange(T)[None, :] >= tb["lens"][:, None]
+    full = tree.prune_to_csr(_t(tb["head"], dev), _t(tb["subj_pos"], dev), _t(tb["obj_pos"], dev), _t(tb["deprel"], dev), K,
+                             masks=_t(masks, dev)).check()
+    ct = full.compact()
+    assert ct.Tc < T // 2
+    Ws, bs = synthetic.layer_params(78, [din, hid, hid])
+    x = _t(synthetic.normal(79, (B, T, din)), dev).to(compute)
+    in_tree = ~full.pool_mask
+    gy = _t(synthetic.normal(80, (B, T, hid)), dev) * in_tree
+
+    def run(xin, trees, g):
+        xin = xin.clone().requires_grad_()
+        W = [_t(w, dev).requires_grad_() for w in Ws]
+        b = [_t(v, dev).requires_grad_() for v in bs]
+        out = gcn.gcn_layers(xin, W, b, trees, [0.0, 0.0], [0, 0], compute, torch.float32)
+        out.backward(g)
+        return out.detach(), xin.grad, [w.grad for w in W], [v.grad for v in b]
+
+    o_f, dx_f, dW_f, db_f = run(x, full, gy)
+    o_c, dx_c, dW_c, db_c = run(ct.take(x), ct.trees, ct.take(gy) * ct.valid.unsqueeze(-1))
+    v = ct.valid
+    assert torch.equal(o_c[v], ct.take(o_f)[v])
+    assert torch.equal(dx_c[v], ct.take(dx_f)[v])
+    assert not dx_f[full.pool_mask.expand_as(dx_f)].any()                # nothing flows into tokens outside the tree
+    tol = 1e-5 if compute == torch.float32 else 2e-2
+    for a, b_ in zip(dW_c + db_c, dW_f + db_f):
+        assert max_rel(a.cpu().numpy(), b_.cpu().numpy()) <= tol
+
+
+@pytest.mark.parametrize("tag", ["gcn", "cgcn", "diag", "full", "semeval", "avgpool"])
+def test_classifier_pooled_only_matches_golden_logits(api, dev, tag):
+    """GCNClassifier on CompactTrees (from a cache, and through opt['gcn_pooled_only']) gives the reference's recorded logits,
+    and the parameter gradients of the full-batch forward."""
+    import json
+    gcn, tree = api
+    g = load_golden("e2e_%s.npz" % tag)
+    opt = json.loads(str(g["opt"]))
+    opt["cuda"] = True
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd:")}
+    model = gcn.GCNClassifier(opt)
+    model.load_state_dict(sd, strict=True)
+    model.to(dev).eval()
+    keys = ("words", "masks", "pos", "ner", "deprel", "head", "subj_pos", "obj_pos")
+    if opt["dataset"] != "tacred":
+        keys = keys[:3] + keys[4:]
+    inputs = tuple(_t(g[k], dev) for k in keys)
+    masks, deprel, head, subj_pos, obj_pos = inputs[1], inputs[-4], inputs[-3], inputs[-2], inputs[-1]
+    cache = tree.TreeCache.build(head, subj_pos, obj_pos, deprel, opt["prune_k"], masks=masks, compact=True)
+    B, T = head.shape
+    ct = cache.batch(torch.arange(B, device=dev), T, compact=True)
+    assert ct.Tc < T
+    logits, pooled = model(inputs, trees=ct)
+    assert max_rel(logits.detach().cpu().numpy(), g["logits"]) <= 1e-4
+    assert max_rel(pooled.detach().cpu().numpy(), g["pooling_output"]) <= 1e-4
+    # gradients in training mode (MIOpen's LSTM backward insists on it) with every source of noise switched off
+    quiet = dict(opt, input_dropout=0.0, gcn_dropout=0.0, rnn_dropout=0.0, emb_dropout=0.0, edge_keep_prob=1.0, deprel_keep_prop=1.0)
+    model = gcn.GCNClassifier(quiet)
+    model.load_state_dict(sd, strict=True)
+    model.to(dev).train()
+    loss = lambda lo, po: lo.logsumexp(1).mean() + 0.003 * (po ** 2).sum(1).mean()      # noqa: E731
+    logits, pooled = model(inputs, trees=ct)
+    loss(logits, pooled).backward()
+    got = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad(set_to_none=True)
+    lf, pf = model(inputs)
+    loss(lf, pf).backward()
+    want = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    assert set(got) == set(want) and len(got) > 3
+    for n in want:
+        assert max_rel(got[n].cpu().numpy(), want[n].cpu().numpy()) <= 2e-4, n
+    m2 = gcn.GCNClassifier(dict(opt, gcn_pooled_only=True))
+    m2.load_state_dict(sd, strict=True)
+    m2.to(dev).eval()
+    with torch.no_grad():
+        l2, _ = m2(inputs)
+    assert max_rel(l2.cpu().numpy(), g["logits"]) <= 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------
 # N2: adj_type == 'diagonal_deprel' (gcnpt_diag_layer_fwd / bwd)
 # ---------------------------------------------------------------------------------------------------
 def _run_diag(api, dev, g, L, dtype=torch.float32, trees=None, drop=None):

@@ -70,7 +70,7 @@ def parse():
 class Stack(object):
     """Device buffers of one rank's shard and the C-ABI calls of one step."""
 
-    def __init__(self, args, dev, seed):
+    def __init__(self, args, dev, seed, pooled_only=False):
         from gcn_over_pruned_trees_amd import _lib
         from gcn_over_pruned_trees_amd.model import tree
         from gcn_over_pruned_trees_amd.utils import synthetic
@@ -90,6 +90,16 @@ class Stack(object):
         self.b = [t(b) for b in bs]
         self.x = t(synthetic.normal(seed + 2, (B, T, Din))).to(act)
         self.gy = t(synthetic.normal(seed + 3, (B, T, H))).to(act)
+        self.trees = tree.prune_to_csr(self.head, self.subj, self.obj, self.deprel, args.prune_k, masks=self.masks, want_label=False)
+        self.trees.check(expect_maxlen=T)
+        self.nnz = int(self.trees.nnz().sum())
+        self.rows_full = B * T
+        if pooled_only:
+            # N1 "pooled-only" rows: the same step on the tokens of the pruned trees only (what a pooling consumer needs,
+            # gcn.py:116-121): every buffer below is [B, Tc, *]
+            ct = self.trees.compact()
+            self.trees, self.x, self.gy = ct.trees, ct.take(self.x).contiguous(), ct.take(self.gy).contiguous()
+            self.T = T = ct.Tc
         self.h1 = torch.empty((B, T, H), dtype=act, device=dev)
         self.h2 = torch.empty((B, T, H), dtype=act, device=dev)
         self.dh1 = torch.empty((B, T, H), dtype=act, device=dev)
@@ -103,9 +113,6 @@ class Stack(object):
         # two flat gradient buckets [dW0, db0, dW1, db1] so that the all-reduce of step i overlaps step i+1
         self.n_grad = H * Din + H + H * H + H
         self.buckets = [torch.zeros((self.n_grad,), dtype=torch.float32, device=dev) for _ in range(2)]
-        self.trees = tree.prune_to_csr(self.head, self.subj, self.obj, self.deprel, args.prune_k, masks=self.masks, want_label=False)
-        self.trees.check(expect_maxlen=T)
-        self.nnz = int(self.trees.nnz().sum())
         # loader-side pre-pruning (N4): a "dataset" of 20 batches pruned once; a step then only gathers its batch's rows
         reps = 20
         rep = lambda a: a.repeat(reps, 1)  # noqa: E731
@@ -114,7 +121,7 @@ class Stack(object):
         self.cache_idx = (torch.arange(B, device=dev) + B * (reps // 2)).to(torch.int64)
         self.scale = 1.0 / (1.0 - args.drop) if args.drop > 0 else 1.0
         self.side = torch.cuda.Stream(device=dev)
-        self.fused = args.fused and args.dtype == "bf16" and bool(self.L.gcnpt_stack_supported(T, Din, H, 2, self.compute))
+        self.fused = args.fused and args.dtype == "bf16" and not pooled_only and bool(self.L.gcnpt_stack_supported(T, Din, H, 2, self.compute))
         if self.fused:       # fragment images with per-sentence k-steps: layer inputs h_l (fwd) and G_l = (A+I)^T dZ_l (bwd)
             fb = self.L.gcnpt_stack_frag_bytes
             self.hf = [torch.empty((fb(B, T, d),), dtype=torch.uint8, device=dev) for h, d in dims]
@@ -350,7 +357,8 @@ def kernel_breakdown(stack, use_graph, rounds=300):
         t = timed_replay(prefix)
         out[calls[k - 1][0]] = max(t - prev, 1e-9)
         prev = t
-    out["prune"] = max(timed_replay(lambda: stack.step(0, with_prune=True)) - prev, 1e-9)
+    if stack.B * stack.T == stack.rows_full:      # (a pooled-only stack holds [B, Tc] trees: the pruner's arrays do not fit them)
+        out["prune"] = max(timed_replay(lambda: stack.step(0, with_prune=True)) - prev, 1e-9)
     stack.step()          # leave consistent buffers behind
     torch.cuda.synchronize()
     return out
@@ -471,6 +479,17 @@ def main():
             "with_cached_trees": {"value": args.batch * args.steps / wall_c, "unit": "sentences/s", "ms_per_step": wall_c / args.steps * 1e3,
                                   "note": "rank 0, dataset pruned once; every step assembles its batch's adjacency with gcnpt_gather_trees"},
         }
+        if not stack.fused:
+            sc = Stack(args, dev, seed=1234 + 17 * rank, pooled_only=True)
+            run_k, _ = capture(lambda: sc.step(0), use_graph)
+            wall_k, _ = timed(lambda i: run_k(), args.steps, min(args.warmup, 50), lambda: None)
+            result["pooled_only_rows"] = {
+                "value": args.batch * args.steps / wall_k, "unit": "sentences/s", "ms_per_step": wall_k / args.steps * 1e3,
+                "rows": sc.B * sc.T, "rows_full": sc.rows_full,
+                "note": "rank 0, NOT the headline workload: the same step on the tokens of the pruned trees only (gcnpt_compact_trees, "
+                        "[B, %d] instead of [B, %d]) -- what the step costs when the consumer is the reference's pooling (gcn.py:116-121), "
+                        "which never reads another row; kept rows are bit-identical to the full batch's" % (sc.T, args.seq)}
+            del sc
         alg = stack.algorithmic_bytes()
         if not args.no_kernel_breakdown:
             kt = kernel_breakdown(stack, use_graph)

@@ -283,6 +283,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
     GItem g0;
     g_issue(tid, g0);
     load_w(0, 0, KS_EARLY, KSMAX);                              // 156 KB per workgroup at Din=360, H=200
+    GCNPT_STAMP(p.stamps, 3);
 
     // (2b)
     const int n_batches = ceil_div(n_items, ITEMS * RT_THREADS);
@@ -312,6 +313,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
         }
     };
     copy_batch(0);
+    GCNPT_STAMP(p.stamps, 4);
     // (2a) -- only the waves that own an item: the sums cost a wave ~120 VALU instructions whether its lanes are live or not
     if (wave * WAVE < n_g) g_finish(tid, g0);
     for (int base = RT_THREADS; base < n_g; base += RT_THREADS) {      // tiles with more than 512 / (K/8) aggregating rows
@@ -323,9 +325,9 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
         issue_self(batch);
         copy_batch(batch);
     }
-    GCNPT_STAMP(p.stamps, 3);
+    GCNPT_STAMP(p.stamps, 5);
     __syncthreads();
-    GCNPT_STAMP(p.stamps, 4);
+    GCNPT_STAMP(p.stamps, 6);
 
     // side outputs: the tile in MFMA fragment order for the weight gradient (rows are its contraction index),
     // and cleared accumulators for the kernel that follows
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
         for (int i = blockIdx.x * RT_THREADS + tid; i < p.zero_a_n; i += gridDim.x * RT_THREADS) p.zero_a[i] = 0.0f;
     if (p.zero_b)
         for (int i = blockIdx.x * RT_THREADS + tid; i < p.zero_b_n; i += gridDim.x * RT_THREADS) p.zero_b[i] = 0.0f;
-    GCNPT_STAMP(p.stamps, 5);
+    GCNPT_STAMP(p.stamps, 7);
     if (!p.out) return;
 
     // (3) + (4)
@@ -418,7 +420,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
             }
         }
 
-        GCNPT_STAMP(p.stamps, 6);
+        GCNPT_STAMP(p.stamps, 8);
         // epilogue on the accumulators -> LDS out tile (tiles past the last real one hold duplicates: not stored).
         // Lane (i = lane & 15, q = lane >> 4) holds, per 16x16 tile, row i and the 4 consecutive columns 4q..4q+3.
         if (pass > 0) {
@@ -475,7 +477,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
             }
         }
         __syncthreads();
-        GCNPT_STAMP(p.stamps, 7);
+        GCNPT_STAMP(p.stamps, 9);
 
         // whole rows leave in 16-byte pieces
         const int c_lo = pass * ncols_pass, c_hi = min(p.NOUT, c_lo + ncols_pass);
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
             }
         }
     }
-    GCNPT_STAMP(p.stamps, 8);
+    GCNPT_STAMP(p.stamps, 10);
 }
 
 }  // namespace gcnpt

@@ -216,6 +216,9 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 2) void weight_grad_kernel(const W
         for (int g = 0; g < 4; ++g) {
             const int m = (m0 + i) * 16 + (lane >> 4) * 4 + g;
             const int n = (n0 + j) * 16 + (lane & 15);
+#ifdef GCNPT_STAMPS
+            if (p.knob & 4) { if (m < p.H && n < p.Din) p.dW[(size_t)m * p.Din + n] = v[g]; continue; }     // experiment: stores for atomics
+#endif
             if (m < p.H && n < p.Din) atomicAdd(p.dW + (size_t)m * p.Din + n, v[g]);
         }
     }

@@ -64,6 +64,8 @@ def parse():
                     help="BLAS threads of the CPU baseline (4 measured fastest on the bench box: 1169 sentences/s vs 701 at 16 and 749 at 128; "
                          "the matrices are small)")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
+    ap.add_argument("--no-pooled-only", action="store_true", help="skip the secondary pooled-only-rows measurement (profiling runs: its launches "
+                                                                  "would mix into the per-kernel statistics of the headline step)")
     return ap.parse_args()
 
 
@@ -479,7 +481,7 @@ def main():
             "with_cached_trees": {"value": args.batch * args.steps / wall_c, "unit": "sentences/s", "ms_per_step": wall_c / args.steps * 1e3,
                                   "note": "rank 0, dataset pruned once; every step assembles its batch's adjacency with gcnpt_gather_trees"},
         }
-        if not stack.fused:
+        if not stack.fused and not args.no_pooled_only:
             sc = Stack(args, dev, seed=1234 + 17 * rank, pooled_only=True)
             run_k, _ = capture(lambda: sc.step(0), use_graph)
             wall_k, _ = timed(lambda i: run_k(), args.steps, min(args.warmup, 50), lambda: None)

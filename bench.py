@@ -63,6 +63,10 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=4,
                     help="BLAS threads of the CPU baseline (4 measured fastest on the bench box: 1169 sentences/s vs 701 at 16 and 749 at 128; "
                          "the matrices are small)")
+    ap.add_argument("--launch", choices=["auto", "graph", "native"], default="auto",
+                    help="graph: the step's launches replayed as one hipGraph; native: eager launches from three native calls per step "
+                         "(gcnpt_pack_weights_multi, gcnpt_layers_fwd, gcnpt_layers_bwd), which keeps the queue fed as long as the host is "
+                         "fast enough; auto: both are tried during warm-up and the faster one is timed")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
     ap.add_argument("--no-pooled-only", action="store_true", help="skip the secondary pooled-only-rows measurement (profiling runs: its launches "
                                                                   "would mix into the per-kernel statistics of the headline step)")
@@ -203,6 +207,37 @@ class Stack(object):
         self._lib.check(self.L.gcnpt_layer_bwd_weight_multi(
             self._lib.stream(), n, A(self.zf), A(self.sf), self.B, self.T, ints([w.shape[1] for w in self.W]),
             ints([w.shape[0] for w in self.W]), A([g[0], g[2]]), A([g[1], g[3]]), self.compute))
+
+    # ---- the whole layer loop / backward sweep from one native call each (gcnpt_layers_fwd / gcnpt_layers_bwd) ----
+    def _native_args(self, k):
+        if not hasattr(self, "_nargs"):
+            self._nargs = {}
+        if k not in self._nargs:
+            P, A, tr, n = self._lib.ptr, self._lib.ptr_array, self.trees, len(self.W)
+            ints = lambda vals: (ctypes.c_int * n)(*vals)  # noqa: E731
+            Din, H = ints([w.shape[1] for w in self.W]), ints([w.shape[0] for w in self.W])
+            g = self.grads(k)
+            act = ints([self.act] * n)
+            fwd = (n, P(self.x), self.act, A(self.wf), A(self.b), P(tr.row_ptr), P(tr.col_idx), P(tr.ell), None, self.B, self.T, Din, H,
+                   A([self.h1, self.h2]), act, self.compute, (ctypes.c_float * n)(self.args.drop, 0.0), (ctypes.c_uint64 * n)(0x5eed, 0),
+                   A(self.sf), None)
+            bwd = (n, P(self.gy), A([self.h1, self.h2]), act, A(self.wb), P(tr.ell), P(tr.rowT_ptr), P(tr.colT_idx), P(tr.ellT), self.B, self.T,
+                   Din, H, A([self.dx, self.dh1]), act, self.compute, (ctypes.c_float * n)(self.scale, 1.0), A(self.zf), A(self.sf),
+                   A([g[0], g[2]]), A([g[1], g[3]]))
+            self._nargs[k] = (fwd, bwd)
+        return self._nargs[k]
+
+    def step_native(self, k=0, with_prune=False):
+        """One step as three native calls (pack, all forward layers, backward sweep + weight gradients): eager launches, no graph."""
+        fwd, bwd = self._native_args(k)
+        st = self._lib.stream()
+        if with_prune == "cached":
+            self.gather()
+        elif with_prune:
+            self.prune()
+        self.pack_all()
+        self._lib.check(self.L.gcnpt_layers_fwd(st, *fwd))
+        self._lib.check(self.L.gcnpt_layers_bwd(st, *bwd))
 
     # ---- sentence-resident stack: every layer in one launch per direction ----
     def stack_fwd(self, k=0):
@@ -433,23 +468,52 @@ def main():
 
     # ---- the timed step: layer stack fwd+bwd (+ overlapped gradient all-reduce when N > 1)
     multi = world > 1 or force_dist
-    replays = [capture(lambda k=k: stack.step(k), use_graph) for k in range(2 if multi else 1)]
-    graphed = replays[0][1]
     # SUM, not AVG: the 1/world factor belongs to the optimizer's learning rate, and SUM is supported by every backend
     reducer = OverlappedAllReduce(stack.buckets, dist, average=False) if multi else None
 
-    def run(i):
-        k = i & 1 if multi else 0
-        if reducer:
-            reducer.before_write(k)
-        replays[k][0]()
-        if reducer:
-            reducer.after_write(k)
+    def runner(mode, with_prune=False, n_buckets=1):
+        """[(callable, is_graph)] per gradient bucket for a launch mode."""
+        if mode == "native":
+            fns = [((lambda k=k: stack.step_native(k, with_prune)), False) for k in range(n_buckets)]
+            for f, _ in fns:
+                f()
+            torch.cuda.synchronize()
+            return fns
+        return [capture(lambda k=k: stack.step(k, with_prune=with_prune), use_graph) for k in range(n_buckets)]
 
-    wall, ev = timed(run, args.steps, args.warmup, barrier)
-    if reducer:
-        reducer.finish()
+    def make_run(replays):
+        def run(i):
+            k = i & 1 if multi else 0
+            if reducer:
+                reducer.before_write(k)
+            replays[k][0]()
+            if reducer:
+                reducer.after_write(k)
+        return run
+
+    def drain():
+        if reducer:
+            reducer.finish()
         torch.cuda.synchronize()
+
+    modes = ["graph"] if (stack.fused or args.launch == "graph") else (["native"] if args.launch == "native" else ["graph", "native"])
+    cands = {m: runner(m, n_buckets=2 if multi else 1) for m in modes}
+    launch, trial = modes[0], {}
+    if len(modes) > 1:
+        # part of the warm-up: a short trial of each launch mode (every rank must take the same one: MAX over ranks decides)
+        for m in modes:
+            w, _ = timed(make_run(cands[m]), 200, 20, barrier)
+            drain()
+            if multi:
+                tm = torch.tensor([w], dtype=torch.float64, device=dev)
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                w = float(tm.item())
+            trial[m] = w / 200
+        launch = min(modes, key=lambda m: trial[m])
+    replays = cands[launch]
+    graphed = replays[0][1]
+    wall, ev = timed(make_run(replays), args.steps, args.warmup, barrier)
+    drain()
     if multi:
         tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -460,9 +524,9 @@ def main():
     if rank == 0:
         sent = args.batch * world * args.steps
         # second measurement on rank 0 only: tree build inside the step
-        run_p, _ = capture(lambda: stack.step(0, with_prune=True), use_graph)
+        run_p = runner(launch, with_prune=True)[0][0]
         wall_p, _ = timed(lambda i: run_p(), args.steps, min(args.warmup, 50), lambda: None)
-        run_c, _ = capture(lambda: stack.step(0, with_prune="cached"), use_graph)
+        run_c = runner(launch, with_prune="cached")[0][0]
         wall_c, _ = timed(lambda i: run_c(), args.steps, min(args.warmup, 50), lambda: None)
         result = {
             "metric": "GCN-layer fwd+bwd sentences/sec at batch=50 seq=100 h=200",
@@ -473,7 +537,9 @@ def main():
                                    "synthetic TACRED-shaped random trees (lengths=%s), dropout %.1f between layers"
                                    % (args.batch, args.seq, args.din, args.hidden, args.prune_k, args.dtype, args.lengths, args.drop),
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "parallelism": "dp%d" % world,
-                       "launch": "hipGraph replay" if graphed else "eager", "nnz_per_batch": stack.nnz,
+                       "launch": "hipGraph replay" if graphed else ("eager launches from 3 native calls per step (pack, gcnpt_layers_fwd, gcnpt_layers_bwd)"
+                                                                     if launch == "native" else "eager"),
+                       "launch_trial_us_per_step": {m: round(t * 1e6, 2) for m, t in trial.items()} or None, "nnz_per_batch": stack.nnz,
                        "grad_allreduce": "flat fp32 bucket %d B per step over RCCL, overlapped with the next step" % (4 * stack.n_grad) if world > 1 else "none (1 GPU)"},
             "event_ms_per_step": ev / args.steps * 1e3,
             "with_prune": {"value": args.batch * args.steps / wall_p, "unit": "sentences/s", "ms_per_step": wall_p / args.steps * 1e3,
@@ -483,7 +549,12 @@ def main():
         }
         if not stack.fused and not args.no_pooled_only:
             sc = Stack(args, dev, seed=1234 + 17 * rank, pooled_only=True)
-            run_k, _ = capture(lambda: sc.step(0), use_graph)
+            if launch == "native":
+                run_k = sc.step_native
+                run_k()
+                torch.cuda.synchronize()
+            else:
+                run_k, _ = capture(lambda: sc.step(0), use_graph)
             wall_k, _ = timed(lambda i: run_k(), args.steps, min(args.warmup, 50), lambda: None)
             result["pooled_only_rows"] = {
                 "value": args.batch * args.steps / wall_k, "unit": "sentences/s", "ms_per_step": wall_k / args.steps * 1e3,

@@ -601,3 +601,56 @@ extern "C" int gcnpt_layer_bwd_data(void* stream, const void* dY, const void* Y,
     p.scale = scale; p.drop_p = 0.0f;
     return dispatch_rowtile<true>((hipStream_t)stream, p, g_dtype, dh_dtype, compute_dtype);
 }
+
+// ---- the whole layer loop / its autograd in one host call: the launches above, back to back (no kernel of their own) ----
+extern "C" int gcnpt_layer_bwd_weight_multi(void* stream, int n_layers, const void* const* z_frag, const void* const* s_frag,
+                                            int B, int T, const int* Din, const int* H, float* const* dW, float* const* db,
+                                            int compute_dtype);
+constexpr int LAYERS_MAX = 8;
+
+extern "C" int gcnpt_layers_fwd(void* stream, int n_layers, const void* x, int x_dtype, const void* const* w_fwd,
+                                const float* const* bias, const int32_t* row_ptr, const int32_t* col_idx, const int32_t* ell,
+                                const int32_t* deg_ell, int B, int T, const int* Din, const int* H, void* const* out,
+                                const int* out_dtype, int compute_dtype, const float* drop_p, const uint64_t* seed,
+                                void* const* s_frag, const uint64_t* seed_dev) {
+    GCNPT_REQUIRE(n_layers >= 1 && n_layers <= LAYERS_MAX, "layers_fwd: 1..%d layers per call", LAYERS_MAX);
+    GCNPT_REQUIRE(x && w_fwd && bias && Din && H && out && out_dtype && drop_p && seed, "layers_fwd: null pointer");
+    for (int l = 1; l < n_layers; ++l)
+        GCNPT_REQUIRE(Din[l] == H[l - 1], "layers_fwd: layer %d reads %d columns but layer %d writes %d", l, Din[l], l - 1, H[l - 1]);
+    const void* h = x;
+    int h_dtype = x_dtype;
+    for (int l = 0; l < n_layers; ++l) {
+        const int rc = gcnpt_layer_fwd(stream, h, h_dtype, w_fwd[l], bias[l], row_ptr, col_idx, ell, deg_ell, B, T, Din[l], H[l], out[l],
+                                       out_dtype[l], compute_dtype, drop_p[l], seed[l], s_frag ? s_frag[l] : nullptr, seed_dev);
+        if (rc != GCNPT_OK) return rc;
+        h = out[l];
+        h_dtype = out_dtype[l];
+    }
+    return GCNPT_OK;
+}
+
+extern "C" int gcnpt_layers_bwd(void* stream, int n_layers, const void* gy, const void* const* Y, const int* y_dtype,
+                                const void* const* w_bwd, const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
+                                const int32_t* ellT, int B, int T, const int* Din, const int* H, void* const* dh,
+                                const int* dh_dtype, int compute_dtype, const float* scale, void* const* z_frag,
+                                const void* const* s_frag, float* const* dW, float* const* db) {
+    GCNPT_REQUIRE(n_layers >= 1 && n_layers <= LAYERS_MAX, "layers_bwd: 1..%d layers per call", LAYERS_MAX);
+    GCNPT_REQUIRE(gy && Y && y_dtype && w_bwd && Din && H && dh && dh_dtype && scale, "layers_bwd: null pointer");
+    GCNPT_REQUIRE(!z_frag || (s_frag && dW && db), "layers_bwd: weight gradients need z_frag, s_frag, dW and db");
+    for (int l = 1; l < n_layers; ++l) {
+        GCNPT_REQUIRE(Din[l] == H[l - 1], "layers_bwd: layer %d reads %d columns but layer %d writes %d", l, Din[l], l - 1, H[l - 1]);
+        GCNPT_REQUIRE(dh[l] && dh_dtype[l] == y_dtype[l - 1], "layers_bwd: dh[%d] must exist and have the dtype of Y[%d]", l, l - 1);
+    }
+    const void* g = gy;
+    for (int l = n_layers - 1; l >= 0; --l) {
+        if (dh[l] || z_frag) {
+            const int rc = gcnpt_layer_bwd_data(stream, g, Y[l], y_dtype[l], w_bwd[l], ell, rowT_ptr, colT_idx, ellT, B, T, Din[l], H[l],
+                                                dh[l], dh_dtype[l], compute_dtype, scale[l], z_frag ? z_frag[l] : nullptr,
+                                                z_frag ? dW[l] : nullptr, z_frag ? db[l] : nullptr);
+            if (rc != GCNPT_OK) return rc;
+        }
+        g = dh[l];
+    }
+    if (!z_frag) return GCNPT_OK;
+    return gcnpt_layer_bwd_weight_multi(stream, n_layers, z_frag, s_frag, B, T, Din, H, dW, db, compute_dtype);
+}

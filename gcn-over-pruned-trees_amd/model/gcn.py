@@ -147,17 +147,14 @@ class _GCNLayersFn(torch.autograd.Function):
                                                 compute, _lib.ptr_array(wf), _lib.ptr_array(wb)))
         need_w = any(p.requires_grad for p in params)
         g_ell = trees.empty_ell() if cfg["no_adj"] else trees.ell
-        outs, s_frag, h = [], [], x
-        for l, (H, K) in enumerate(dims):
-            out = torch.empty((B, T, H), dtype=cfg["out_dtype"] if l == L - 1 else cfg["mid_dtype"], device=dev)
-            sf = torch.empty((lib.gcnpt_frag_bytes(B * T, K, compute),), **u8) if need_w else None
-            _lib.check(lib.gcnpt_layer_fwd(st, _lib.ptr(h), _lib.dtype_code(h.dtype), _lib.ptr(wf[l]), _lib.ptr(b32[l]),
-                                           _lib.ptr(trees.row_ptr), _lib.ptr(trees.col_idx), _lib.ptr(g_ell), _lib.ptr(trees.ell), B, T, K, H,
-                                           _lib.ptr(out), _lib.dtype_code(out.dtype), compute, float(cfg["drop_p"][l]), int(cfg["seed"][l]),
-                                           _lib.ptr(sf), _lib.ptr(cfg.get("seed_dev"))))
-            outs.append(out)
-            s_frag.append(sf)
-            h = out
+        outs = [torch.empty((B, T, H), dtype=cfg["out_dtype"] if l == L - 1 else cfg["mid_dtype"], device=dev) for l, (H, _) in enumerate(dims)]
+        s_frag = [torch.empty((lib.gcnpt_frag_bytes(B * T, K, compute),), **u8) if need_w else None for _, K in dims]
+        # every layer's launch from ONE native call (gcnpt_layers_fwd): no interpreter time between the launches
+        _lib.check(lib.gcnpt_layers_fwd(
+            st, L, _lib.ptr(x), _lib.dtype_code(x.dtype), _lib.ptr_array(wf), _lib.ptr_array(b32), _lib.ptr(trees.row_ptr),
+            _lib.ptr(trees.col_idx), _lib.ptr(g_ell), _lib.ptr(trees.ell), B, T, ints([k for _, k in dims]), ints([h for h, _ in dims]),
+            _lib.ptr_array(outs), ints([_lib.dtype_code(o.dtype) for o in outs]), compute, (ctypes.c_float * L)(*cfg["drop_p"]),
+            (ctypes.c_uint64 * L)(*cfg["seed"]), _lib.ptr_array(s_frag), _lib.ptr(cfg.get("seed_dev"))))
         ctx.save_for_backward(*outs, *wb, *[f for f in s_frag if f is not None])
         ctx.trees, ctx.cfg, ctx.dims, ctx.shape, ctx.need_w = trees, cfg, dims, (B, T, Din, L), need_w
         ctx.x_dtype = x.dtype
@@ -176,27 +173,25 @@ class _GCNLayersFn(torch.autograd.Function):
         u8 = dict(dtype=torch.uint8, device=dev)
         z_frag, dWs, dbs = [None] * L, [None] * L, [None] * L
         g = gout.to(outs[-1].dtype).contiguous()
-        for l in reversed(range(L)):
-            H, K = dims[l]
-            in_dtype = ctx.x_dtype if l == 0 else outs[l - 1].dtype
-            dh = torch.empty((B, T, K), dtype=in_dtype, device=dev) if (l > 0 or ctx.needs_input_grad[0]) else None
-            if want_w:
-                z_frag[l] = torch.empty((lib.gcnpt_frag_bytes(B * T, H, compute),), **u8)
-                dWs[l] = torch.empty((H, K), dtype=torch.float32, device=dev)          # cleared by bwd_data, filled at the end
-                dbs[l] = torch.empty((H,), dtype=torch.float32, device=dev)
-            if dh is not None or want_w:
-                scale = 1.0 / (1.0 - cfg["drop_p"][l]) if cfg["drop_p"][l] > 0 else 1.0
-                _lib.check(lib.gcnpt_layer_bwd_data(st, _lib.ptr(g), _lib.ptr(outs[l]), _lib.dtype_code(outs[l].dtype), _lib.ptr(wb[l]),
-                                                    _lib.ptr(trees.ell), _lib.ptr(trees.rowT_ptr), _lib.ptr(trees.colT_idx), _lib.ptr(g_ellT),
-                                                    B, T, K, H, _lib.ptr(dh), _lib.dtype_code(in_dtype), compute, scale, _lib.ptr(z_frag[l]),
-                                                    _lib.ptr(dWs[l]), _lib.ptr(dbs[l])))
-            g = dh
+        in_dtypes = [ctx.x_dtype if l == 0 else outs[l - 1].dtype for l in range(L)]
+        dhs = [torch.empty((B, T, K), dtype=in_dtypes[l], device=dev) if (l > 0 or ctx.needs_input_grad[0]) else None
+               for l, (_, K) in enumerate(dims)]
+        if want_w:
+            z_frag = [torch.empty((lib.gcnpt_frag_bytes(B * T, H, compute),), **u8) for H, _ in dims]
+            dWs = [torch.empty((H, K), dtype=torch.float32, device=dev) for H, K in dims]       # cleared by bwd_data, filled at the end
+            dbs = [torch.empty((H,), dtype=torch.float32, device=dev) for H, _ in dims]
+        ints = lambda v: (ctypes.c_int * L)(*v)  # noqa: E731
+        scales = [1.0 / (1.0 - p) if p > 0 else 1.0 for p in cfg["drop_p"]]
+        # the backward sweep and all weight gradients from ONE native call (gcnpt_layers_bwd)
+        _lib.check(lib.gcnpt_layers_bwd(
+            st, L, _lib.ptr(g), _lib.ptr_array(list(outs)), ints([_lib.dtype_code(o.dtype) for o in outs]), _lib.ptr_array(list(wb)),
+            _lib.ptr(trees.ell), _lib.ptr(trees.rowT_ptr), _lib.ptr(trees.colT_idx), _lib.ptr(g_ellT), B, T, ints([k for _, k in dims]),
+            ints([h for h, _ in dims]), _lib.ptr_array(dhs), ints([_lib.dtype_code(t) for t in in_dtypes]), compute,
+            (ctypes.c_float * L)(*scales), _lib.ptr_array(z_frag) if want_w else None, _lib.ptr_array(list(s_frag)) if want_w else None,
+            _lib.ptr_array(dWs) if want_w else None, _lib.ptr_array(dbs) if want_w else None))
+        g = dhs[0]
         grads = [None] * (2 * L)
         if want_w:
-            ints = lambda v: (ctypes.c_int * L)(*v)  # noqa: E731
-            _lib.check(lib.gcnpt_layer_bwd_weight_multi(st, L, _lib.ptr_array(z_frag), _lib.ptr_array(list(s_frag)), B, T,
-                                                        ints([k for _, k in dims]), ints([h for h, _ in dims]), _lib.ptr_array(dWs),
-                                                        _lib.ptr_array(dbs), compute))
             for l in range(L):
                 grads[2 * l] = dWs[l].to(ctx.param_dtypes[2 * l])
                 grads[2 * l + 1] = dbs[l].to(ctx.param_dtypes[2 * l + 1])

@@ -158,6 +158,27 @@ int gcnpt_layer_bwd_weight_multi(void* stream, int n_layers, const void* const* 
                                  int T, const int* Din, const int* H, float* const* dW, float* const* db,
                                  int compute_dtype);
 
+/* ---- the reference's whole layer loop (model/gcn.py:266-393) and its autograd in ONE host call each -------------------
+ * The per-layer entry points above enqueue one launch per host call; a step of an L-layer stack is 2L+1 launches, and what
+ * the host spends between them (interpreter, ctypes, hipGraph replay set-up: measured 5.3 us per replay) shows as idle
+ * gaps on the device.  These two enqueue the same launches back to back from native code.  Arrays have n_layers (<= 8)
+ * entries in host memory; every layer sees the same B x T rows and the same pattern.
+ * gcnpt_layers_fwd:  out[l] = layer l applied to out[l-1] (x for l = 0), Din[l] must equal H[l-1]; out_dtype[l] is also the
+ *   dtype layer l+1 reads; s_frag[l] may be NULL (or s_frag itself NULL) as in gcnpt_layer_fwd.
+ * gcnpt_layers_bwd:  top layer first, gy = gradient of out[L-1] in y_dtype[L-1]; dh[l] = gradient of layer l's input in
+ *   dh_dtype[l] (= y_dtype[l-1] for l > 0; dh[0] may be NULL when the input needs no gradient); scale[l] = 1/(1-p_l) of the
+ *   dropout layer l's forward applied.  z_frag == NULL: no weight gradients (dW, db, s_frag unused); otherwise z_frag[l],
+ *   s_frag[l], dW[l], db[l] for every layer, and the L weight gradients follow in ONE launch (gcnpt_layer_bwd_weight_multi). */
+int gcnpt_layers_fwd(void* stream, int n_layers, const void* x, int x_dtype, const void* const* w_fwd, const float* const* bias,
+                     const int32_t* row_ptr, const int32_t* col_idx, const int32_t* ell, const int32_t* deg_ell, int B, int T,
+                     const int* Din, const int* H, void* const* out, const int* out_dtype, int compute_dtype,
+                     const float* drop_p, const uint64_t* seed, void* const* s_frag, const uint64_t* seed_dev);
+int gcnpt_layers_bwd(void* stream, int n_layers, const void* gy, const void* const* Y, const int* y_dtype,
+                     const void* const* w_bwd, const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
+                     const int32_t* ellT, int B, int T, const int* Din, const int* H, void* const* dh, const int* dh_dtype,
+                     int compute_dtype, const float* scale, void* const* z_frag, const void* const* s_frag, float* const* dW,
+                     float* const* db);
+
 /* ---- optional: the whole L-layer stack in ONE launch per direction (sentence-resident kernels) ---------------
  * A workgroup owns a whole sentence (T <= 112 rows) and runs every layer with the inter-layer activations in LDS;
  * aggregation is done after the matrix product ((A+I)(h W^T)), LDS -> LDS, so nothing is ever gathered from HBM.

@@ -188,9 +188,11 @@ class Stack(object):
         H, Din = self.W[l].shape
         sc = self.scale if l == 0 else 1.0
         dW, db = self._dw_db(l, k)
+        # the hand-over gcnpt_layers_bwd uses: layer 1 leaves dZ of layer 0 in dh1 (it has h1's rows at hand), layer 0 takes it as is
+        relu, nsc, is_dz = (self.h1, self.scale, 0) if l == 1 else (None, 1.0, 1)
         self._lib.check(self.L.gcnpt_layer_bwd_data(self._lib.stream(), P(dy), P(y), self.act, P(self.wb[l]), P(tr.ell), P(tr.rowT_ptr),
                                                     P(tr.colT_idx), P(tr.ellT), self.B, self.T, Din, H, P(dst), self.act, self.compute, sc,
-                                                    P(self.zf[l]), P(dW), P(db)))
+                                                    P(self.zf[l]), P(dW), P(db), P(relu), nsc, is_dz))
 
     def bwd_weight(self, l, k=0):
         P = self._lib.ptr
@@ -310,7 +312,11 @@ class Stack(object):
         for l, (H, Din) in enumerate([tuple(w.shape) for w in self.W]):
             wp = self.wf[l].numel()
             out["fwd%d" % l] = e * N * (Din + H) + wp + 4 * H + csr + self.sf[l].numel()
-            out["bwd_data%d" % l] = e * N * (2 * H + Din) + self.wb[l].numel() + 2 * csr + self.zf[l].numel() + 4 * (H * Din + H)
+            # the top layer reads dY and Y, the layers below read the dZ the layer above left them; every layer but the bottom one
+            # also reads its input rows to leave dZ for the layer below (hand-over of gcnpt_layers_bwd)
+            top, bottom = l == len(self.W) - 1, l == 0
+            out["bwd_data%d" % l] = e * N * ((2 if top else 1) * H + (1 if bottom else 2) * Din) + self.wb[l].numel() + 2 * csr + \
+                self.zf[l].numel() + 4 * (H * Din + H)
             out["bwd_weight%d" % l] = self.zf[l].numel() + self.sf[l].numel() + 4 * (H * Din + H)
             out["bwd_weight"] = out.get("bwd_weight", 0) + out["bwd_weight%d" % l]
             out["pack"] = out.get("pack", 0) + 4 * H * Din + self.wf[l].numel() + self.wb[l].numel()

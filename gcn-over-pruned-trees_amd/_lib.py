@@ -25,7 +25,7 @@ SIGNATURES = {
     "gcnpt_pack_weights_multi": (_i, [_p, _i, _p, _p, _p, _i, _p, _p]),
     "gcnpt_frag_bytes": (_sz, [_i, _i, _i]),
     "gcnpt_layer_fwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _f, _u64, _p, _p]),
-    "gcnpt_layer_bwd_data": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _f, _p, _p, _p]),
+    "gcnpt_layer_bwd_data": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _f, _p, _p, _p, _p, _f, _i]),
     "gcnpt_layer_bwd_weight": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _i]),
     "gcnpt_layer_bwd_weight_multi": (_i, [_p, _i, _p, _p, _i, _i, _p, _p, _p, _p, _i]),
     "gcnpt_layers_fwd": (_i, [_p, _i, _p, _i] + [_p] * 6 + [_i, _i] + [_p] * 4 + [_i] + [_p] * 4),
@@ -75,8 +75,8 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)          # AttributeError here = header and library disagree
             fn.restype, fn.argtypes = res, args
-        if handle.gcnpt_abi_version() != 2:
-            raise ImportError("libgcnpt.so has ABI version %d, this binding needs 2" % handle.gcnpt_abi_version())
+        if handle.gcnpt_abi_version() != 3:
+            raise ImportError("libgcnpt.so has ABI version %d, this binding needs 3" % handle.gcnpt_abi_version())
         _lib = handle
     return _lib
 

@@ -50,15 +50,21 @@ struct RowTileParams {
     unsigned drop_thresh16;
     uint64_t seed;
     const uint64_t* seed_dev;   // NULL, or a device word added to `seed` (a counter the caller advances between graph replays)
+    const void* relu_src;       // bwd: NULL, or this layer's INPUT rows [N,NOUT] (the stored output of the layer below): the result then
+    float next_scale;           //      leaves as that layer's dZ = dh * 1[input > 0] * next_scale / (deg + 1) instead of dh
     unsigned long long* stamps;   // diagnostic builds only
     int knob;
 };
 
-template <typename CT, typename IT, typename OT, bool BWD, bool VEC, int NTW, int KSMAX>
+// DZIN (bwd only): `src` already holds dZ (the layer above wrote it, see relu_src), so the row loader is the forward's plain
+// gather -- one load per neighbour instead of three (dY, Y, degree).
+template <typename CT, typename IT, typename OT, bool BWD, bool VEC, int NTW, int KSMAX, bool DZIN = false>
 __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTileParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    static_assert(BWD || !DZIN, "DZIN is a backward mode");
+    constexpr bool MASKED = BWD && !DZIN;                       // the loader computes dZ = dY * 1[Y>0] * scale / (deg+1) itself
     constexpr int KSTEP = sizeof(CT) == 2 ? 32 : 16;            // K consumed per fragment
-    constexpr bool WIDE = BWD && sizeof(IT) == 4;               // two fp32 streams per row: fewer rows in flight per thread
+    constexpr bool WIDE = MASKED && sizeof(IT) == 4;            // two fp32 streams per row: fewer rows in flight per thread
     constexpr int ITEMS = WIDE ? 2 : 3;                         // 8-element chunks a thread gathers per batch
     constexpr int NBU = WIDE ? 2 : 4;                           // neighbour rows fetched together
     const int stride = lds_stride_dw(p.Kpad * (int)sizeof(CT) / 4) * 4 / (int)sizeof(CT);     // S row stride, CT elements
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
             const int row = div_chunk(it), k0 = (it - row * nchunk) * 8;
             const size_t r = (size_t)min(r0 + row, p.N - 1);
             issue8<IT, VEC>(src, r, p.K, min(k0, kmax8), self[u]);
-            if (BWD) issue8<IT, VEC>(yref, r, p.K, min(k0, kmax8), selfy[u]);
+            if (MASKED) issue8<IT, VEC>(yref, r, p.K, min(k0, kmax8), selfy[u]);
         }
     };
     issue_self(0);
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
         const int sbase = rsb[row];                                    // first row of this row's sentence
         const int k0c = min(k0, kmax8);
         issue8<IT, VEC>(src, r, p.K, k0c, g.s);
-        if (BWD) issue8<IT, VEC>(yref, r, p.K, k0c, g.sy);
+        if (MASKED) issue8<IT, VEC>(yref, r, p.K, k0c, g.sy);
 #pragma unroll
         for (int e = 0; e < NBU; ++e) {
             // no e-th neighbour: the first 16 bytes of the tile's first row, one cache line for all such lanes.  (NOT the
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
             const size_t c = on ? (size_t)(sbase + rell[row * 8 + 1 + e]) : (size_t)r0;
             const int kc = on ? k0c : 0;
             issue8<IT, VEC>(src, c, p.K, kc, g.nb[e]);
-            if (BWD) {
+            if (MASKED) {
                 issue8<IT, VEC>(yref, c, p.K, kc, g.nby[e]);
                 g.dcnt[e] = p.d_ell[c * 8];
             }
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
         const int k0c = min(k0, kmax8);
         float acc[8];
         unpack8<IT>(g.s, live, acc);                                    // the explicit W(h) term, gcn.py:271
-        if (BWD) {
+        if (MASKED) {
             float y[8];
             unpack8<IT>(g.sy, live, y);
             const float inv = rinv[row];
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
             const bool on = e < n_ell;
             float v[8];
             unpack8<IT>(g.nb[e], on, v);
-            if (BWD) {
+            if (MASKED) {
                 float y[8];
                 unpack8<IT>(g.nby[e], on, y);
                 const float ninv = p.scale / (float)(g.dcnt[e] + 1);
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
                 }
                 c = on ? c : rc;
                 issue8<IT, VEC>(src, c, p.K, k0c, nb[e]);
-                if (BWD) {
+                if (MASKED) {
                     issue8<IT, VEC>(yref, c, p.K, k0c, nby[e]);
                     ninv[e] = p.scale / (float)(p.d_ell[c * 8] + 1);
                 }
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
                 const bool on = e0 + e < lim;
                 float v[8];
                 unpack8<IT>(nb[e], on, v);
-                if (BWD) {
+                if (MASKED) {
                     float y[8];
                     unpack8<IT>(nby[e], on, y);
 #pragma unroll
@@ -301,12 +307,14 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
             }
             float acc[8];
             unpack8<IT>(self[u], live, acc);                            // the explicit W(h) term, gcn.py:271
-            if (BWD) {
+            if (MASKED) {
                 float y[8];
                 unpack8<IT>(selfy[u], live, y);
                 const float inv = rinv[row];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] = (y[j] > 0.0f) ? acc[j] * inv : 0.0f;
+            }
+            if (BWD) {
                 if (p.frag_out) tile<CT>::put8(Z + (size_t)row * stride + k0, acc);
             }
             if (!(p.out && rell[row * 8] > 0)) tile<CT>::put8(S + (size_t)row * stride + k0, acc);   // else: (2a) writes it
@@ -483,18 +491,62 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
         const int c_lo = pass * ncols_pass, c_hi = min(p.NOUT, c_lo + ncols_pass);
         const int width = c_hi - c_lo;
         constexpr int PER = 16 / (int)sizeof(OT);
+        const OT* relu = BWD ? static_cast<const OT*>(p.relu_src) : nullptr;
         if (p.vec_out && (width % PER) == 0 && (c_lo % PER) == 0) {
             const int pieces = width / PER;                                  // 16 threads per row: no division, 256 contiguous bytes each round
             const int row = tid >> 4, r = r0 + row;
-            if (r < p.N)
+            if (BWD && relu) {
+                // hand-over to the layer below: its dZ instead of dh (gcn.py:390-393 differentiated where the rows are at hand);
+                // the input rows are fetched in one batch, then masked and scaled while the tile leaves LDS
+                constexpr int RP = 4;
+                const float f = p.next_scale / rden[row];
+                const size_t rr = (size_t)min(r, p.N - 1) * p.NOUT + c_lo;
+                for (int pc0 = tid & 15; pc0 < pieces; pc0 += 16 * RP) {
+                    uint4 hin[RP];
+#pragma unroll
+                    for (int u = 0; u < RP; ++u) hin[u] = *reinterpret_cast<const uint4*>(relu + rr + min(pc0 + 16 * u, pieces - 1) * PER);
+#pragma unroll
+                    for (int u = 0; u < RP; ++u) {
+                        const int pc = pc0 + 16 * u;
+                        if (pc >= pieces || r >= p.N) continue;
+                        uint4 o = *reinterpret_cast<const uint4*>(O + (size_t)row * ostride + pc * PER);
+                        if constexpr (sizeof(OT) == 2) {
+                            unsigned* ow = reinterpret_cast<unsigned*>(&o);
+                            const unsigned* hw = reinterpret_cast<const unsigned*>(&hin[u]);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float lo = bf16_to_f32((bf16_t)(hw[q] & 0xffffu)) > 0.0f ? bf16_to_f32((bf16_t)(ow[q] & 0xffffu)) * f : 0.0f;
+                                const float hi = bf16_to_f32((bf16_t)(hw[q] >> 16)) > 0.0f ? bf16_to_f32((bf16_t)(ow[q] >> 16)) * f : 0.0f;
+                                ow[q] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+                            }
+                        } else {
+                            float* ow = reinterpret_cast<float*>(&o);
+                            const float* hw = reinterpret_cast<const float*>(&hin[u]);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) ow[q] = hw[q] > 0.0f ? ow[q] * f : 0.0f;
+                        }
+                        *reinterpret_cast<uint4*>(out + (size_t)r * p.NOUT + c_lo + pc * PER) = o;
+                    }
+                }
+            } else if (r < p.N) {
                 for (int pc = tid & 15; pc < pieces; pc += 16)
                     *reinterpret_cast<uint4*>(out + (size_t)r * p.NOUT + c_lo + pc * PER) =
                         *reinterpret_cast<const uint4*>(O + (size_t)row * ostride + pc * PER);
+            }
         } else {
             for (int it = tid; it < ROWS * width; it += RT_THREADS) {
                 const int row = it / width, c = it - row * width;
                 const int r = r0 + row;
-                if (r < p.N) out[(size_t)r * p.NOUT + c_lo + c] = O[(size_t)row * ostride + c];
+                if (r >= p.N) continue;
+                OT v = O[(size_t)row * ostride + c];
+                if (BWD && relu) {
+                    const OT hv = relu[(size_t)r * p.NOUT + c_lo + c];
+                    float x, hx;
+                    if constexpr (sizeof(OT) == 2) { x = bf16_to_f32(v); hx = bf16_to_f32(hv); } else { x = v; hx = hv; }
+                    x = hx > 0.0f ? x * (p.next_scale / rden[row]) : 0.0f;
+                    if constexpr (sizeof(OT) == 2) v = f32_to_bf16(x); else v = x;
+                }
+                out[(size_t)r * p.NOUT + c_lo + c] = v;
             }
         }
     }
@@ -508,7 +560,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
 // =====================================================================================================
 using namespace gcnpt;
 
-template <typename CT, typename IT, typename OT, bool BWD, bool VEC, int NTW, int KSMAX>
+template <typename CT, typename IT, typename OT, bool BWD, bool VEC, int NTW, int KSMAX, bool DZIN = false>
 static int launch_rowtile_cfg(hipStream_t s, const RowTileParams& p) {
     const int stride = lds_stride_dw(p.Kpad * (int)sizeof(CT) / 4) * 4 / (int)sizeof(CT);
     const int ncols_pass = RT_WAVES * NTW * 16;
@@ -517,7 +569,7 @@ static int launch_rowtile_cfg(hipStream_t s, const RowTileParams& p) {
     const size_t lds = s_bytes + (BWD ? std::max(s_bytes, o_bytes) : o_bytes) +
                        (size_t)ROWS * 13 * sizeof(int) + (size_t)RT_THREADS * sizeof(float);
     if (lds > 160 * 1024) return fail(GCNPT_E_UNSUPPORTED, "layer: K=%d needs %zu B of LDS per workgroup", p.K, lds);
-    auto kern = rowtile_kernel<CT, IT, OT, BWD, VEC, NTW, KSMAX>;
+    auto kern = rowtile_kernel<CT, IT, OT, BWD, VEC, NTW, KSMAX, DZIN>;
     static bool big_lds = false;                 // once per instantiation, to the CU's full 160 KB: not a stream operation, so it
     if (lds > 64 * 1024 && !big_lds) {           // must not recur inside a graph capture (the first launch is an eager warm-up)
         GCNPT_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -531,30 +583,30 @@ static int launch_rowtile_cfg(hipStream_t s, const RowTileParams& p) {
 // output tiles per wave: the smallest of {2,3,4} that covers NOUT in one pass (8 waves x NTW x 16 columns),
 // with as many K-steps of weight fragments resident in registers as ~128 VGPRs allow.  Rows that cannot be
 // read 16 bytes at a time (width not a multiple of 8, unaligned base) take the element-load instantiation.
-template <typename CT, typename IT, typename OT, bool BWD>
+template <typename CT, typename IT, typename OT, bool BWD, bool DZIN = false>
 static int launch_rowtile(hipStream_t s, const RowTileParams& p) {
     const int n_tiles = ceil_div(p.NOUT, 16);
-    if (!p.vec_in) return launch_rowtile_cfg<CT, IT, OT, BWD, false, 4, BWD ? 3 : 4>(s, p);
+    if (!p.vec_in) return launch_rowtile_cfg<CT, IT, OT, BWD, false, 4, BWD ? 3 : 4, DZIN>(s, p);
     if (n_tiles <= RT_WAVES * 2) {
         // 13 k-steps = the C-GCN input width (2 x 200 BiLSTM states): one more resident k-step instead of a second load phase
-        if (p.Kpad / (sizeof(CT) == 2 ? 32 : 16) == 13) return launch_rowtile_cfg<CT, IT, OT, BWD, true, 2, 13>(s, p);
-        return launch_rowtile_cfg<CT, IT, OT, BWD, true, 2, 12>(s, p);
+        if (p.Kpad / (sizeof(CT) == 2 ? 32 : 16) == 13) return launch_rowtile_cfg<CT, IT, OT, BWD, true, 2, 13, DZIN>(s, p);
+        return launch_rowtile_cfg<CT, IT, OT, BWD, true, 2, 12, DZIN>(s, p);
     }
-    if (n_tiles <= RT_WAVES * 3) return launch_rowtile_cfg<CT, IT, OT, BWD, true, 3, 7>(s, p);
-    return launch_rowtile_cfg<CT, IT, OT, BWD, true, 4, 5>(s, p);
+    if (n_tiles <= RT_WAVES * 3) return launch_rowtile_cfg<CT, IT, OT, BWD, true, 3, 7, DZIN>(s, p);
+    return launch_rowtile_cfg<CT, IT, OT, BWD, true, 4, 5, DZIN>(s, p);
 }
 
-template <bool BWD>
+template <bool BWD, bool DZIN = false>
 static int dispatch_rowtile(hipStream_t s, const RowTileParams& p, int in_dtype, int out_dtype, int compute) {
     if (compute == GCNPT_F32) {
         if (in_dtype != GCNPT_F32 || out_dtype != GCNPT_F32)
             return fail(GCNPT_E_UNSUPPORTED, "compute_dtype f32 needs f32 activations");
-        return launch_rowtile<float, float, float, BWD>(s, p);
+        return launch_rowtile<float, float, float, BWD, DZIN>(s, p);
     }
-    if (in_dtype == GCNPT_F32 && out_dtype == GCNPT_F32) return launch_rowtile<bf16_t, float, float, BWD>(s, p);
-    if (in_dtype == GCNPT_F32 && out_dtype == GCNPT_BF16) return launch_rowtile<bf16_t, float, bf16_t, BWD>(s, p);
-    if (in_dtype == GCNPT_BF16 && out_dtype == GCNPT_F32) return launch_rowtile<bf16_t, bf16_t, float, BWD>(s, p);
-    return launch_rowtile<bf16_t, bf16_t, bf16_t, BWD>(s, p);
+    if (in_dtype == GCNPT_F32 && out_dtype == GCNPT_F32) return launch_rowtile<bf16_t, float, float, BWD, DZIN>(s, p);
+    if (in_dtype == GCNPT_F32 && out_dtype == GCNPT_BF16) return launch_rowtile<bf16_t, float, bf16_t, BWD, DZIN>(s, p);
+    if (in_dtype == GCNPT_BF16 && out_dtype == GCNPT_F32) return launch_rowtile<bf16_t, bf16_t, float, BWD, DZIN>(s, p);
+    return launch_rowtile<bf16_t, bf16_t, bf16_t, BWD, DZIN>(s, p);
 }
 
 extern "C" int gcnpt_layer_fwd(void* stream, const void* h, int h_dtype, const void* w_fwd, const float* bias,
@@ -583,8 +635,10 @@ extern "C" int gcnpt_layer_fwd(void* stream, const void* h, int h_dtype, const v
 extern "C" int gcnpt_layer_bwd_data(void* stream, const void* dY, const void* Y, int g_dtype, const void* w_bwd,
                                     const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
                                     const int32_t* ellT, int B, int T, int Din, int H, void* dh, int dh_dtype,
-                                    int compute_dtype, float scale, void* z_frag, float* zero_dW, float* zero_db) {
-    GCNPT_REQUIRE(dY && Y && w_bwd && ell && rowT_ptr && colT_idx && ellT, "layer_bwd_data: null pointer");
+                                    int compute_dtype, float scale, void* z_frag, float* zero_dW, float* zero_db,
+                                    const void* relu_src, float next_scale, int src_is_dz) {
+    GCNPT_REQUIRE(dY && (Y || src_is_dz) && w_bwd && ell && rowT_ptr && colT_idx && ellT, "layer_bwd_data: null pointer");
+    GCNPT_REQUIRE(!relu_src || dh, "layer_bwd_data: relu_src without dh");
     GCNPT_REQUIRE(dh || z_frag, "layer_bwd_data: nothing to produce (dh and z_frag both NULL)");
     GCNPT_REQUIRE(B > 0 && T > 0 && Din > 0 && H > 0, "layer_bwd_data: sizes must be positive");
     GCNPT_REQUIRE(dtype_ok(g_dtype) && dtype_ok(dh_dtype) && dtype_ok(compute_dtype), "layer_bwd_data: bad dtype");
@@ -596,9 +650,12 @@ extern "C" int gcnpt_layer_bwd_data(void* stream, const void* dY, const void* Y,
     p.frag_out = z_frag;
     p.zero_a = zero_dW; p.zero_a_n = H * Din; p.zero_b = zero_db; p.zero_b_n = H;
     p.N = B * T; p.T = T; p.K = H; p.NOUT = Din; p.Kpad = round_up(H, kstep_of(compute_dtype)); p.chunk_magic = 0xffffffffu / (unsigned)(p.Kpad / 8) + 1u;
-    p.vec_in = (H % 8 == 0) && aligned16(dY) && aligned16(Y);
+    p.vec_in = (H % 8 == 0) && aligned16(dY) && (src_is_dz || aligned16(Y));
     p.vec_out = dh && ((Din * esize(dh_dtype)) % 16 == 0) && aligned16(dh);
     p.scale = scale; p.drop_p = 0.0f;
+    p.relu_src = relu_src; p.next_scale = next_scale;
+    if (relu_src && !aligned16(relu_src)) p.vec_out = 0;
+    if (src_is_dz) return dispatch_rowtile<true, true>((hipStream_t)stream, p, g_dtype, dh_dtype, compute_dtype);
     return dispatch_rowtile<true>((hipStream_t)stream, p, g_dtype, dh_dtype, compute_dtype);
 }
 
@@ -644,9 +701,13 @@ extern "C" int gcnpt_layers_bwd(void* stream, int n_layers, const void* gy, cons
     const void* g = gy;
     for (int l = n_layers - 1; l >= 0; --l) {
         if (dh[l] || z_frag) {
+            // every layer but the bottom one hands the layer below its dZ ready-made (dh[l] then holds dZ of layer l-1), and every
+            // layer but the top one receives it: one load per neighbour in the gather instead of three
+            const bool hand_down = l > 0, handed = l < n_layers - 1;
             const int rc = gcnpt_layer_bwd_data(stream, g, Y[l], y_dtype[l], w_bwd[l], ell, rowT_ptr, colT_idx, ellT, B, T, Din[l], H[l],
                                                 dh[l], dh_dtype[l], compute_dtype, scale[l], z_frag ? z_frag[l] : nullptr,
-                                                z_frag ? dW[l] : nullptr, z_frag ? db[l] : nullptr);
+                                                z_frag ? dW[l] : nullptr, z_frag ? db[l] : nullptr, hand_down ? Y[l - 1] : nullptr,
+                                                hand_down ? scale[l - 1] : 1.0f, handed ? 1 : 0);
             if (rc != GCNPT_OK) return rc;
         }
         g = dh[l];

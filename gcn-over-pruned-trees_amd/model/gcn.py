@@ -92,7 +92,7 @@ class _GCNLayerFn(torch.autograd.Function):
             _lib.check(L.gcnpt_layer_bwd_data(st, _lib.ptr(gout), _lib.ptr(out), gd, _lib.ptr(w_bwd), _lib.ptr(trees.ell),
                                               _lib.ptr(trees.rowT_ptr), _lib.ptr(trees.colT_idx), _lib.ptr(g_ellT), B, T, Din, H, _lib.ptr(dh),
                                               _lib.dtype_code(ctx.h_dtype), ctx.compute, ctx.scale, _lib.ptr(z_frag),
-                                              _lib.ptr(dW), _lib.ptr(db)))
+                                              _lib.ptr(dW), _lib.ptr(db), None, 1.0, 0))
         if want_w:
             _lib.check(L.gcnpt_layer_bwd_weight(st, _lib.ptr(z_frag), _lib.ptr(s_frag), B, T, Din, H, _lib.ptr(dW), _lib.ptr(db),
                                                 ctx.compute))

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define GCNPT_ABI_VERSION 2
+#define GCNPT_ABI_VERSION 3
 
 /* element types of activation / gradient buffers and of the MFMA operands */
 #define GCNPT_F32 0
@@ -143,12 +143,19 @@ int gcnpt_layer_fwd(void* stream, const void* h, int h_dtype, const void* w_fwd,
  * colT_idx / ellT the transposed pattern that is aggregated over.  dh may be NULL (input needs no gradient).  z_frag: NULL or gcnpt_frag_bytes(B*T, H, compute_dtype) bytes
  * receiving the fragment image of dZ; zero_dW [H*Din] / zero_db [H]: NULL or the accumulators the FOLLOWING
  * gcnpt_layer_bwd_weight adds into, cleared here so that no separate memset is needed.
+ * Hand-over between stacked layers (optional; gcnpt_layers_bwd uses it): the gather of the layer below needs, per neighbour,
+ * dY, Y and the neighbour's degree -- unless the layer above, which has its rows at hand, leaves dZ instead of dh:
+ *   relu_src / next_scale  NULL, or this layer's INPUT rows [B*T, Din] in dh_dtype (= the stored output of the layer below)
+ *                          and that layer's dropout scale: dh then receives dh * 1[relu_src > 0] * next_scale / (deg + 1),
+ *                          i.e. dZ of the layer below;
+ *   src_is_dz              non-zero: dY already IS this layer's dZ (written that way by the layer above); Y and scale are
+ *                          not used.  Same values either way, fp32 bit for bit.
  * gcnpt_layer_bwd_weight: streams the two fragment images (z_frag from bwd_data, s_frag from fwd) and adds the
  * K-slices into dW/db with float atomics; dW/db must be zero on entry (see zero_dW/zero_db above). */
 int gcnpt_layer_bwd_data(void* stream, const void* dY, const void* Y, int g_dtype, const void* w_bwd,
                          const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx, const int32_t* ellT,
                          int B, int T, int Din, int H, void* dh, int dh_dtype, int compute_dtype, float scale,
-                         void* z_frag, float* zero_dW, float* zero_db);
+                         void* z_frag, float* zero_dW, float* zero_db, const void* relu_src, float next_scale, int src_is_dz);
 int gcnpt_layer_bwd_weight(void* stream, const void* z_frag, const void* s_frag, int B, int T, int Din, int H,
                            float* dW, float* db, int compute_dtype);
 /* The weight gradients of n_layers (<= 8) layers in ONE launch: they all become computable at the end of the backward
@@ -166,7 +173,8 @@ int gcnpt_layer_bwd_weight_multi(void* stream, int n_layers, const void* const* 
  * gcnpt_layers_fwd:  out[l] = layer l applied to out[l-1] (x for l = 0), Din[l] must equal H[l-1]; out_dtype[l] is also the
  *   dtype layer l+1 reads; s_frag[l] may be NULL (or s_frag itself NULL) as in gcnpt_layer_fwd.
  * gcnpt_layers_bwd:  top layer first, gy = gradient of out[L-1] in y_dtype[L-1]; dh[l] = gradient of layer l's input in
- *   dh_dtype[l] (= y_dtype[l-1] for l > 0; dh[0] may be NULL when the input needs no gradient); scale[l] = 1/(1-p_l) of the
+ *   dh_dtype[l] (= y_dtype[l-1] for l > 0; dh[0] may be NULL when the input needs no gradient; dh[l] for l > 0 is scratch for
+ *   the caller: it holds dZ of layer l-1, see the hand-over above); scale[l] = 1/(1-p_l) of the
  *   dropout layer l's forward applied.  z_frag == NULL: no weight gradients (dW, db, s_frag unused); otherwise z_frag[l],
  *   s_frag[l], dW[l], db[l] for every layer, and the L weight gradients follow in ONE launch (gcnpt_layer_bwd_weight_multi). */
 int gcnpt_layers_fwd(void* stream, int n_layers, const void* x, int x_dtype, const void* const* w_fwd, const float* const* bias,

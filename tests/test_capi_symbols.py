@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(handle, n), "libgcnpt.so does not export %s" % n
     assert sorted(_lib.SIGNATURES) == names                      # the ctypes binding covers the header, nothing else
-    assert _lib.lib().gcnpt_abi_version() == 2
+    assert _lib.lib().gcnpt_abi_version() == 3
 
 
 def test_argument_validation_needs_no_gpu():
@@ -40,7 +40,7 @@ def test_argument_validation_needs_no_gpu():
     assert L.gcnpt_prune_to_csr(None, p, p, p, p, p, None, 1, 4, -1, 12, p, p, None, None, None, p, None, None, p) == _lib.E_PRUNE_NEGATIVE
     assert L.gcnpt_layer_fwd(None, p, 0, p, p, p, p, p, None, 1, 1, 8, 8, p, 0, 7, 0.0, 0, None, None) == _lib.E_INVALID
     assert L.gcnpt_layer_fwd(None, p, 0, p, p, p, p, p, None, 1, 1, 8, 8, p, 0, 0, 1.5, 0, None, None) == _lib.E_INVALID
-    assert L.gcnpt_layer_bwd_data(None, p, p, 0, p, p, p, p, p, 1, 1, 8, 8, None, 0, 0, 1.0, None, None, None) == _lib.E_INVALID
+    assert L.gcnpt_layer_bwd_data(None, p, p, 0, p, p, p, p, p, 1, 1, 8, 8, None, 0, 0, 1.0, None, None, None, None, 1.0, 0) == _lib.E_INVALID
     assert L.gcnpt_frag_bytes(5000, 360, _lib.BF16) == 23 * 157 * 1024 and L.gcnpt_frag_bytes(5000, 360, _lib.F32) == 23 * 314 * 1024
     assert L.gcnpt_packed_bytes(200, 360, _lib.BF16) == 13 * 12 * 64 * 16
     assert L.gcnpt_packed_bytes(200, 360, _lib.F32) == 13 * 23 * 64 * 16

@@ -420,9 +420,15 @@ def test_layer_loop_op_matches_chained_layers(api, dev, compute):
     h.backward(_t(g["gy"], dev))
     f = lambda t: t.detach().float().cpu().numpy()  # noqa: E731
     np.testing.assert_array_equal(f(h), base["h"])
-    np.testing.assert_array_equal(f(x.grad), base["dx"])
+    # backward: gcn_layers hands dZ from layer to layer (gcnpt_layers_bwd; the chained ops pass dh and every layer derives dZ
+    # itself).  Bit-identical in fp32; with bf16 storage dZ is rounded before the neighbour sum instead of after it
+    if compute == torch.float32:
+        np.testing.assert_array_equal(f(x.grad), base["dx"])
+    else:
+        assert max_rel(f(x.grad), base["dx"]) <= 1e-2
+    tol = 1e-5 if compute == torch.float32 else 1e-2
     for l in range(2):
-        assert max_rel(f(Ws[l].grad), base["dW"][l]) <= 1e-5 and max_rel(f(bs[l].grad), base["db"][l]) <= 1e-5
+        assert max_rel(f(Ws[l].grad), base["dW"][l]) <= tol and max_rel(f(bs[l].grad), base["db"][l]) <= tol
     # three layers of different widths, no input gradient wanted
     rng = np.random.RandomState(3)
     dims = [(96, g["x"].shape[2]), (40, 96), (72, 40)]
@@ -439,7 +445,7 @@ def test_layer_loop_op_matches_chained_layers(api, dev, compute):
         hh = gcn.gcn_layer(hh, Ws[l], bs[l], trees, 0.0, 0, compute, torch.float32 if l == 2 else compute)
     hh.backward(gy)
     for a, t in zip(got, Ws + bs):
-        assert max_rel(a, f(t.grad)) <= 1e-5
+        assert max_rel(a, f(t.grad)) <= tol
 
 
 # ---------------------------------------------------------------------------------------------------

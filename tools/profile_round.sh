@@ -9,6 +9,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 200 --warmup 20 --launch native --no-cpu-baseline --no-kernel-breakdown --no-pooled-only"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $ARGS > $OUT/trace.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_graph -- python3 $R/bench.py --steps 200 --warmup 20 --launch graph --no-cpu-baseline --no-kernel-breakdown --no-pooled-only > $OUT/trace_graph.log 2>&1 || exit 1
 PMC="--steps 30 --warmup 5 --launch native --no-cpu-baseline --no-kernel-breakdown --no-pooled-only"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $R/bench.py $PMC > $OUT/fetch.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 $R/bench.py $PMC > $OUT/write.log 2>&1 || exit 1

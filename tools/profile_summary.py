@@ -73,6 +73,9 @@ os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 stats = glob.glob(os.path.join(SRC, "trace", "*", "*kernel_stats.csv"))
 if stats:
     shutil.copy(max(stats, key=os.path.getmtime), os.path.join(ROOT, "profiles", "%s_kernel_stats.csv" % tag))
+stats = glob.glob(os.path.join(SRC, "trace_graph", "*", "*kernel_stats.csv"))
+if stats:
+    shutil.copy(max(stats, key=os.path.getmtime), os.path.join(ROOT, "profiles", "%s_kernel_stats_graph.csv" % tag))
 merged = collections.defaultdict(dict)
 for run in ("fetch", "write", "sq", "mfma"):
     for k, cs in per_kernel(run).items():

@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GCNPT_LIB") or os.path.join(_HERE, "csrc", "libgcnpt.so")   # GCNPT_LIB: diagnostic builds
 
 F32, BF16 = 0, 1
+ABI_VERSION = 3            # GCNPT_ABI_VERSION of the include/gcnpt.h this binding was written against
 OK, E_INVALID, E_PRUNE_NEGATIVE, E_NO_SUBJECT, E_NO_LCA, E_CYCLE, E_BAD_HEAD, E_ASSERT, E_CAPACITY, E_HIP, E_UNSUPPORTED, E_LENGTH = \
     0, -1, -2, -3, -4, -5, -6, -7, -8, -9, -10, -11
 
@@ -75,8 +76,8 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)          # AttributeError here = header and library disagree
             fn.restype, fn.argtypes = res, args
-        if handle.gcnpt_abi_version() != 3:
-            raise ImportError("libgcnpt.so has ABI version %d, this binding needs 3" % handle.gcnpt_abi_version())
+        if handle.gcnpt_abi_version() != ABI_VERSION:
+            raise ImportError("libgcnpt.so has ABI version %d, this binding needs %d" % (handle.gcnpt_abi_version(), ABI_VERSION))
         _lib = handle
     return _lib
 

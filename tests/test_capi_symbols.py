@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(handle, n), "libgcnpt.so does not export %s" % n
     assert sorted(_lib.SIGNATURES) == names                      # the ctypes binding covers the header, nothing else
-    assert _lib.lib().gcnpt_abi_version() == 3
+    assert _lib.lib().gcnpt_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_argument_validation_needs_no_gpu():

@@ -73,6 +73,9 @@ def parse():
     return ap.parse_args()
 
 
+N_BUCKETS = 4       # gradient buckets in flight for N > 1: the all-reduce of a bucket is long over when its turn comes again
+
+
 class Stack(object):
     """Device buffers of one rank's shard and the C-ABI calls of one step."""
 
@@ -116,9 +119,9 @@ class Stack(object):
         # saved operands in MFMA fragment order: S_l = (A+I)h_l written by fwd, dZ_l written by bwd_data
         self.sf = [torch.empty((self.L.gcnpt_frag_bytes(B * T, d, self.compute),), dtype=torch.uint8, device=dev) for h, d in dims]
         self.zf = [torch.empty((self.L.gcnpt_frag_bytes(B * T, h, self.compute),), dtype=torch.uint8, device=dev) for h, d in dims]
-        # two flat gradient buckets [dW0, db0, dW1, db1] so that the all-reduce of step i overlaps step i+1
+        # a ring of flat gradient buckets [dW0, db0, dW1, db1] so that the all-reduce of step i overlaps the following steps
         self.n_grad = H * Din + H + H * H + H
-        self.buckets = [torch.zeros((self.n_grad,), dtype=torch.float32, device=dev) for _ in range(2)]
+        self.buckets = [torch.zeros((self.n_grad,), dtype=torch.float32, device=dev) for _ in range(N_BUCKETS)]
         # loader-side pre-pruning (N4): a "dataset" of 20 batches pruned once; a step then only gathers its batch's rows
         reps = 20
         rep = lambda a: a.repeat(reps, 1)  # noqa: E731
@@ -489,7 +492,7 @@ def main():
 
     def make_run(replays):
         def run(i):
-            k = i & 1 if multi else 0
+            k = i % N_BUCKETS if multi else 0
             if reducer:
                 reducer.before_write(k)
             replays[k][0]()
@@ -503,7 +506,7 @@ def main():
         torch.cuda.synchronize()
 
     modes = ["graph"] if (stack.fused or args.launch == "graph") else (["native"] if args.launch == "native" else ["graph", "native"])
-    cands = {m: runner(m, n_buckets=2 if multi else 1) for m in modes}
+    cands = {m: runner(m, n_buckets=N_BUCKETS if multi else 1) for m in modes}
     launch, trial = modes[0], {}
     if len(modes) > 1:
         # part of the warm-up: a short trial of each launch mode (every rank must take the same one: MAX over ranks decides)
@@ -545,8 +548,9 @@ def main():
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "parallelism": "dp%d" % world,
                        "launch": "hipGraph replay" if graphed else ("eager launches from 3 native calls per step (pack, gcnpt_layers_fwd, gcnpt_layers_bwd)"
                                                                      if launch == "native" else "eager"),
+                       "allreduce_stream_waits": reducer.stream_waits if reducer else None,
                        "launch_trial_us_per_step": {m: round(t * 1e6, 2) for m, t in trial.items()} or None, "nnz_per_batch": stack.nnz,
-                       "grad_allreduce": "flat fp32 bucket %d B per step over RCCL, overlapped with the next step" % (4 * stack.n_grad) if world > 1 else "none (1 GPU)"},
+                       "grad_allreduce": "flat fp32 bucket %d B per step over RCCL, overlapped with the following steps (ring of %d buckets)" % (4 * stack.n_grad, N_BUCKETS) if world > 1 else "none (1 GPU)"},
             "event_ms_per_step": ev / args.steps * 1e3,
             "with_prune": {"value": args.batch * args.steps / wall_p, "unit": "sentences/s", "ms_per_step": wall_p / args.steps * 1e3,
                            "note": "rank 0, pruned-tree adjacency build (gcnpt_prune_to_csr) inside every step"},

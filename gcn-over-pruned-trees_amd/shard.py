@@ -14,6 +14,8 @@ the sentence-sharded scheme of SURVEY.md 8(e):
 Everything here is backend-agnostic torch.distributed, so the same code is covered by world_size-2
 `gloo` tests on CPU (tests/test_shard_gloo.py).
 """
+import time
+
 import numpy as np
 import torch
 
@@ -79,24 +81,39 @@ class FlatGradBucket(object):
 
 class OverlappedAllReduce(object):
     """
-    Double-buffered gradient exchange: the kernels of step i write bucket i%2 while the all-reduce of
-    step i-1 (other bucket) is still in flight on the communication stream.
+    Multi-buffered gradient exchange: the kernels of step i write bucket i % n while the all-reduces of
+    the previous steps (other buckets) are still in flight on the communication stream.
 
-        before_write(k)   the current stream waits for the pending all-reduce of bucket k
+        before_write(k)   make sure the pending all-reduce of bucket k is over before the bucket is written again
         after_write(k)    enqueue the all-reduce of bucket k (asynchronous)
-        finish()          wait for everything; afterwards every bucket holds the rank-average
+        finish()          wait for everything; afterwards every bucket holds the rank-sum / rank-average
+
+    A completion the HOST has observed (Work.is_completed) already orders every later launch after it, so with poll=True
+    the host spins until the all-reduce the bucket was last part of is over (n-1 steps ago: the host may run at most that
+    far ahead of the device, which keeps the queue fed) and the compute stream gets no wait-for-event marker -- on ROCm such
+    a marker breaks the back-to-back dispatch of the step's kernels (measured with RCCL: 6.6 us of device time per step).
+    If the completion does not show within `spin_s` seconds the stream wait is inserted after all; poll=False always does.
     """
 
-    def __init__(self, buckets, dist, average=True):
-        self.buckets, self.dist, self.average = buckets, dist, average
+    def __init__(self, buckets, dist, average=True, poll=True, spin_s=0.05):
+        self.buckets, self.dist, self.average, self.poll, self.spin_s = buckets, dist, average, poll, spin_s
         self.pending = [None] * len(buckets)
         self.world = dist.get_world_size()
         self.native_avg = average and dist.get_backend() == "nccl"
+        self.stream_waits = 0                # how often the stream had to wait after all (diagnostics)
 
     def before_write(self, k):
         w = self.pending[k]
         if w is not None:
-            w.wait()
+            done = False
+            if self.poll:
+                t_end = time.perf_counter() + self.spin_s
+                done = w.is_completed()
+                while not done and time.perf_counter() < t_end:
+                    done = w.is_completed()
+            if not done:
+                w.wait()
+                self.stream_waits += 1
             self.pending[k] = None
             if self.average and not self.native_avg:
                 self.buckets[k].div_(self.world)

@@ -102,8 +102,34 @@ def _overlapped(rank, world):
     assert torch.all(buckets[0] == 1.5 * 7) and torch.all(buckets[1] == 1.5 * 6)
 
 
+def _overlapped_ring(rank, world):
+    """Four buckets; whether a completed all-reduce is noticed by polling or waited for, every bucket is reduced exactly once per use."""
+    for poll in (True, False):
+        n = 4
+        buckets = [torch.zeros(257) for _ in range(n)]
+        red = shard.OverlappedAllReduce(buckets, dist, average=False, poll=poll)
+        for i in range(11):
+            k = i % n
+            red.before_write(k)
+            if i >= n:
+                assert torch.all(buckets[k] == 3.0 * (i - n + 1)), (poll, i, buckets[k][0])     # sum over ranks of (rank+1)*(step+1)
+            buckets[k].fill_(float((rank + 1) * (i + 1)))
+            red.after_write(k)
+        red.finish()
+        assert all(w is None for w in red.pending)
+        for k in range(n):
+            last = max(i for i in range(11) if i % n == k)
+            assert torch.all(buckets[k] == 3.0 * (last + 1))
+        if not poll:
+            assert red.stream_waits == 11
+
+
 def test_overlapped_all_reduce():
     _spawn(_overlapped, 2)
+
+
+def test_overlapped_all_reduce_ring_of_buckets():
+    _spawn(_overlapped_ring, 2)
 
 
 def _gather(rank, world):

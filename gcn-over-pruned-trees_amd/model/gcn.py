@@ -310,6 +310,35 @@ def gcn_stack(x, weights, biases, trees, drop_p=None, seeds=None, out_dtype=torc
     return _GCNStackFn.apply(x, trees, cfg, *params)
 
 
+class _EmbedFn(torch.autograd.Function):
+    """nn.Embedding lookup (model/gcn.py:235-239) whose backward is ONE index_add_ of float atomics.  PyTorch-ROCm 2.10's own
+    embedding backward takes ~140 us per table at the 1.5-5 k indices of a batch (embedding_backward_feature_kernel: three
+    tables = half of the no-LSTM training step) and above 3072 indices a rocPRIM sort path that faults when replayed in a
+    hipGraph; same sums, same zero row for padding_idx."""
+
+    @staticmethod
+    def forward(ctx, weight, idx, padding_idx):
+        ctx.save_for_backward(idx)
+        ctx.table, ctx.pad = tuple(weight.shape), padding_idx
+        return torch.nn.functional.embedding(idx, weight)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        gw = torch.zeros(ctx.table, dtype=g.dtype, device=g.device)
+        gw.index_add_(0, idx.reshape(-1), g.reshape(-1, g.shape[-1]))
+        if ctx.pad is not None:
+            gw[ctx.pad].zero_()
+        return gw, None, None
+
+
+def _embed(table, idx):
+    """table: nn.Embedding.  Same result as table(idx)."""
+    if idx.is_cuda and table.weight.requires_grad and torch.is_grad_enabled():
+        return _EmbedFn.apply(table.weight, idx, table.padding_idx)
+    return table(idx)
+
+
 # ------------------------------------------------------------------------------------------------------
 # modules with the reference's names and state_dict layout
 # ------------------------------------------------------------------------------------------------------
@@ -468,7 +497,7 @@ class GCN(nn.Module):
     def _word_embeddings(self, words):
         """EmbeddingDropout of the reference (model/dropouts.py:23-39): in training, every word TYPE of a
         sentence is dropped with probability emb_dropout and the rest is scaled by 1/(1-p)."""
-        embs = self.emb(words)
+        embs = _embed(self.emb, words)
         p = self.emb_dropout
         if not self.training or p <= 0.0:
             return embs
@@ -553,7 +582,7 @@ class GCN(nn.Module):
             for edges, shift, on in ((fwd_e, 0, True), (rev_e, constant.DEPREL_FORWARD_BOUND, not directed)):
                 if not on or tok.numel() == 0:
                     continue
-                e = self.deprel_emb(deprel_tok + shift)
+                e = _embed(self.deprel_emb, deprel_tok + shift)
                 keep_prop = opt.get('deprel_keep_prop', 1.0)
                 if self.training and keep_prop < 1.0:                                             # maybe_forget_deprels, gcn.py:451-470
                     kept = torch.empty((tok.numel(), 1), device=dev).bernoulli_(keep_prop) == 1
@@ -594,9 +623,9 @@ class GCN(nn.Module):
                 ner = ct.take(ner) if ner is not None else None
         parts = [words if words.dim() > 2 else self._word_embeddings(words)]    # gcn.py:235-239
         if self.opt['pos_dim'] > 0:
-            parts.append(self.pos_emb(pos))
+            parts.append(_embed(self.pos_emb, pos))
         if self.opt['ner_dim'] > 0 and ner is not None:
-            parts.append(self.ner_emb(ner))
+            parts.append(_embed(self.ner_emb, ner))
         embs = self.in_drop(torch.cat(parts, dim=2))
         if use_rnn:
             gcn_inputs = self.rnn_drop(self.encode_with_rnn(embs, masks, words.size(0)))

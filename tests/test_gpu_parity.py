@@ -1260,6 +1260,86 @@ def test_training_step_graph_capture(api, dev, dtype):
     assert abs(float(le) - l1) <= 1e-6 * abs(l1)
 
 
+@pytest.mark.parametrize("compact", [False, True])
+def test_training_step_graph_capture_full_size(api, dev, compact):
+    """The same at the bench shape (B=50, T=100, 5000 embedding indices per table -- PyTorch-ROCm's own embedding backward cannot
+    be replayed above 3072, the mirror's can), trees from a TreeCache inside the captured step, all rows and pooled-only rows."""
+    gcn, tree = api
+    from gcn_over_pruned_trees_amd.utils import synthetic
+    B, T = 50, 100
+    opt = dict(vocab_size=5000, emb_dim=300, pos_dim=30, ner_dim=30, hidden_dim=200, num_layers=2, input_dropout=0.5, gcn_dropout=0.5,
+               word_dropout=0.0, emb_dropout=0.0, topn=1e10, prune_k=1, pooling="max", pooling_l2=0.003, mlp_layers=2, no_adj=False,
+               rnn=False, cuda=True, dataset="tacred", num_class=42, adj_type="regular", gcn_dtype="bf16", gcn_check_trees=False,
+               gcn_graph_rng=True)
+    tb = synthetic.random_tree_batch(1236, B, T, "tacred")
+    rng = np.random.RandomState(7)
+    words = rng.randint(2, 5000, size=(B, T)).astype(np.int64)
+    words[tb["masks"]] = 0
+    inputs = (_t(words, dev), _t(tb["masks"], dev), _t(rng.randint(0, 47, size=(B, T)).astype(np.int64), dev),
+              _t(rng.randint(0, 15, size=(B, T)).astype(np.int64), dev), _t(tb["deprel"], dev), _t(tb["head"], dev),
+              _t(tb["subj_pos"], dev), _t(tb["obj_pos"], dev))
+    labels = _t(rng.randint(0, 42, size=(B,)).astype(np.int64), dev)
+    torch.manual_seed(1234)
+    model = gcn.GCNClassifier(opt).to(dev).train()
+    model.gcn_model.gcn.in_drop.p = 0.0                 # torch's dropout draws from its own generator; the layer dropout stays on
+    cache = tree.TreeCache.build(inputs[5], inputs[6], inputs[7], inputs[4], 1, masks=inputs[1], want_label=False, compact=True)
+    idx = torch.arange(B, device=dev)
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        logits, pooled = model(inputs, trees=cache.batch(idx, T, compact=compact))
+        loss = torch.nn.functional.cross_entropy(logits, labels) + 0.003 * (pooled ** 2).sum(1).mean()
+        loss.backward()
+        return loss.detach()
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    counter = model.gcn_model.gcn._rng_step
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        loss = step()
+    emb = model.gcn_model.emb.weight
+    counter.fill_(7)
+    graph.replay()
+    l1, g1 = float(loss), emb.grad.clone()
+    graph.replay()
+    assert float(loss) != l1 and int(counter) == 9
+    counter.fill_(7)
+    le = float(step())                                   # eager, same counter value: same masks, same loss
+    assert abs(le - l1) <= 1e-5 * abs(l1)
+    assert torch.isfinite(g1).all() and g1.abs().sum() > 0 and not g1[0].any()            # padding row stays zero
+    assert max_rel(emb.grad.cpu().numpy(), g1.cpu().numpy()) <= 1e-4
+
+
+def test_embedding_lookup_backward_matches_torch(api, dev):
+    """The mirror's embedding lookup (index_add_ backward) against nn.Embedding's own: same values, same gradients incl. the
+    zero row of padding_idx, repeated indices summed."""
+    gcn, _ = api
+    torch.manual_seed(5)
+    for pad in (0, None):
+        a = torch.nn.Embedding(97, 30, padding_idx=pad).to(dev)
+        b = torch.nn.Embedding(97, 30, padding_idx=pad).to(dev)
+        b.load_state_dict(a.state_dict())
+        idx = torch.randint(0, 97, (50, 47), device=dev)
+        idx[:, -5:] = 0
+        g = torch.randn(50, 47, 30, device=dev)
+        ya, yb = gcn._embed(a, idx), b(idx)
+        assert ya.grad_fn is not None and "Embed" in type(ya.grad_fn).__name__
+        assert torch.equal(ya, yb)
+        ya.backward(g)
+        yb.backward(g)
+        assert max_rel(a.weight.grad.cpu().numpy(), b.weight.grad.cpu().numpy()) <= 1e-6
+        if pad is not None:
+            assert not a.weight.grad[pad].any()
+    with torch.no_grad():
+        assert torch.equal(gcn._embed(a, idx), a(idx))
+
+
 @pytest.mark.parametrize("kind", ["max", "avg", "sum"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_pool3_matches_three_pool_calls(api, dev, kind, dtype):

@@ -536,11 +536,11 @@ class GCN(nn.Module):
             x = diag_layer(x, table, deprel, trees, ps[l], seeds[l], seed_dev)
         return x.float(), trees.pool_mask
 
-    def _forward_full(self, adj, gcn_inputs, deprel):
+    def _forward_full(self, adj, gcn_inputs, deprel, all_tokens=False):
         """adj_type='full_deprel', gcn.py:296-388 + traverse_deprel / traverse_self_loop 400-434; fp32, or with
         opt['gcn_dtype']='bf16' the traversal's contraction on csrc/bilinear_kernels.hip (bf16 MFMA operands, fp32 accumulate).
         trav(x, e)[n] = sum_d e[n,d] (x[n] W3[d] + b3[d]) is only needed for tokens that sit in a pruned tree, so those are
-        compacted (one host sync for their number), their outer products e (x) x meet W3 as [D*Tin, H] in ONE library GEMM per
+        compacted (one host sync for their number; none with CompactTrees, whose rows are those tokens already), their outer products e (x) x meet W3 as [D*Tin, H] in ONE library GEMM per
         direction, and the results travel along the CSR entries of the device pruner (value ranges pick forward / reverse).
         The reference materialises [B,T,D,Tin] for all tokens and multiplies dense [B,T,T] matrices instead."""
         opt = self.opt
@@ -563,9 +563,12 @@ class GCN(nn.Module):
         fwd_e = valid & (lab > 0) & (lab < constant.DEPREL_FORWARD_BOUND)                        # gcn.py:308-311
         rev_e = valid & (lab > constant.DEPREL_FORWARD_BOUND) & (lab < constant.DEPREL_REVERSE_BOUND)   # gcn.py:340-344
         denom = (trees.ell.view(N, 8)[:, 0] + 1).to(torch.float32).unsqueeze(1)                  # gcn.py:261
-        tok = torch.nonzero(~trees.pool_mask.view(-1)).squeeze(1)                                # tokens of the pruned trees
-        pos = torch.zeros((N,), dtype=torch.int64, device=dev)
-        pos[tok] = torch.arange(tok.numel(), device=dev)
+        if all_tokens:        # CompactTrees: the rows ARE the tokens of the pruned trees (plus a few empty slots): no compaction, no sync
+            tok = pos = torch.arange(N, device=dev)
+        else:
+            tok = torch.nonzero(~trees.pool_mask.view(-1)).squeeze(1)                            # tokens of the pruned trees
+            pos = torch.zeros((N,), dtype=torch.int64, device=dev)
+            pos[tok] = torch.arange(tok.numel(), device=dev)
         deprel_tok = deprel.reshape(-1)[tok]
         b3 = self.W.bias.reshape(D, H)                                                            # gcn.py:303
         x = gcn_inputs.to(torch.float32)
@@ -637,7 +640,7 @@ class GCN(nn.Module):
         if self.adj_type == 'diagonal_deprel':
             return self._forward_diagonal(adj, gcn_inputs, deprel)
         if self.adj_type == 'full_deprel':
-            return self._forward_full(adj, gcn_inputs, deprel)
+            return self._forward_full(adj, gcn_inputs, deprel, all_tokens=ct is not None)
         trees = adj if isinstance(adj, PrunedTrees) else adj_to_csr(adj, want_label=False)   # gcn.py:260-262
         no_adj = bool(self.opt.get('no_adj', False))                                           # gcn.py:264-265
         x = gcn_inputs

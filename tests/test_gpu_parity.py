@@ -13,6 +13,8 @@ Tolerances (stated by SURVEY.md 8c / BASELINE.json north_star):
         bit near zero flips whole gradient terms, so the backward kernels are checked on their own), and
         ||err||_F <= 1e-1 * ||ref||_F against the reference's own fp32 gradients (SURVEY.md 7 "hard parts" measured ~6e-2 at C2).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1314,6 +1316,32 @@ def test_training_step_graph_capture_full_size(api, dev, compact):
     assert abs(le - l1) <= 1e-5 * abs(l1)
     assert torch.isfinite(g1).all() and g1.abs().sum() > 0 and not g1[0].any()            # padding row stays zero
     assert max_rel(emb.grad.cpu().numpy(), g1.cpu().numpy()) <= 1e-4
+
+
+def test_bench_step_native_equals_per_launch_step(api, dev):
+    """bench.py's two ways of launching a step -- six per-launch C-ABI calls (what the hipGraph replays) and the three native
+    calls (gcnpt_pack_weights_multi, gcnpt_layers_fwd, gcnpt_layers_bwd) -- enqueue the same kernels on the same buffers."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    argv, sys.argv = sys.argv, ["bench.py", "--lengths", "tacred"]
+    try:
+        args = bench.parse()
+    finally:
+        sys.argv = argv
+    st = bench.Stack(args, dev, seed=99)
+    st.step(0)
+    torch.cuda.synchronize()
+    want = [t.clone() for t in (st.h1, st.h2, st.dh1, st.dx, st.buckets[0])]
+    for t in (st.h1, st.h2, st.dh1, st.dx, st.buckets[0]):
+        t.zero_()
+    st.step_native(0)
+    torch.cuda.synchronize()
+    got = (st.h1, st.h2, st.dh1, st.dx, st.buckets[0])
+    for a, b in zip(got[:4], want[:4]):
+        assert torch.equal(a, b)
+    assert max_rel(got[4].cpu().numpy(), want[4].cpu().numpy()) <= 1e-5          # weight gradients: order of the float atomics
+    assert got[4].abs().sum() > 0
 
 
 def test_embedding_lookup_backward_matches_torch(api, dev):

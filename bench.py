@@ -229,20 +229,24 @@ class Stack(object):
             bwd = (n, P(self.gy), A([self.h1, self.h2]), act, A(self.wb), P(tr.ell), P(tr.rowT_ptr), P(tr.colT_idx), P(tr.ellT), self.B, self.T,
                    Din, H, A([self.dx, self.dh1]), act, self.compute, (ctypes.c_float * n)(self.scale, 1.0), A(self.zf), A(self.sf),
                    A([g[0], g[2]]), A([g[1], g[3]]))
-            self._nargs[k] = (fwd, bwd)
+            vp = ctypes.c_void_p
+            pack = (n, (vp * n)(*[w.data_ptr() for w in self.W]), H, Din, self.compute, A(self.wf), A(self.wb))
+            self._nargs[k] = (pack, fwd, bwd)
         return self._nargs[k]
 
     def step_native(self, k=0, with_prune=False):
-        """One step as three native calls (pack, all forward layers, backward sweep + weight gradients): eager launches, no graph."""
-        fwd, bwd = self._native_args(k)
+        """One step as three native calls (pack, all forward layers, backward sweep + weight gradients): eager launches, no graph.
+        The argument lists are built once: the host has ~50 us per step for six launches and must not spend them marshalling."""
+        pack, fwd, bwd = self._native_args(k)
         st = self._lib.stream()
         if with_prune == "cached":
             self.gather()
         elif with_prune:
             self.prune()
-        self.pack_all()
-        self._lib.check(self.L.gcnpt_layers_fwd(st, *fwd))
-        self._lib.check(self.L.gcnpt_layers_bwd(st, *bwd))
+        L = self.L
+        rc = L.gcnpt_pack_weights_multi(st, *pack) or L.gcnpt_layers_fwd(st, *fwd) or L.gcnpt_layers_bwd(st, *bwd)
+        if rc:
+            self._lib.check(rc)
 
     # ---- sentence-resident stack: every layer in one launch per direction ----
     def stack_fwd(self, k=0):

@@ -67,6 +67,9 @@ def parse():
                     help="graph: the step's launches replayed as one hipGraph; native: eager launches from three native calls per step "
                          "(gcnpt_pack_weights_multi, gcnpt_layers_fwd, gcnpt_layers_bwd), which keeps the queue fed as long as the host is "
                          "fast enough; auto: both are tried during warm-up and the faster one is timed")
+    ap.add_argument("--exchange", choices=["auto", "overlap", "inline"], default="auto",
+                    help="N > 1: gradient all-reduce overlapped with the following steps on the communication stream, in line with the "
+                         "compute (synchronous call), or whichever a warm-up trial finds faster")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
     ap.add_argument("--no-pooled-only", action="store_true", help="skip the secondary pooled-only-rows measurement (profiling runs: its launches "
                                                                   "would mix into the per-kernel statistics of the headline step)")
@@ -500,14 +503,19 @@ def main():
             return fns
         return [capture(lambda k=k: stack.step(k, with_prune=with_prune), use_graph) for k in range(n_buckets)]
 
-    def make_run(replays):
+    def make_run(replays, exchange="overlap"):
+        """A step + (N > 1) the all-reduce of the bucket it wrote.  exchange "overlap": asynchronous, on the communication stream,
+        beside the following steps (ring of buckets); "inline": a synchronous all_reduce, in line with the compute."""
         def run(i):
             k = i % N_BUCKETS if multi else 0
-            if reducer:
+            if reducer and exchange == "overlap":
                 reducer.before_write(k)
             replays[k][0]()
             if reducer:
-                reducer.after_write(k)
+                if exchange == "overlap":
+                    reducer.after_write(k)
+                else:
+                    dist.all_reduce(stack.buckets[k])
         return run
 
     def drain():
@@ -517,21 +525,24 @@ def main():
 
     modes = ["graph"] if (stack.fused or args.launch == "graph") else (["native"] if args.launch == "native" else ["graph", "native"])
     cands = {m: runner(m, n_buckets=N_BUCKETS if multi else 1) for m in modes}
-    launch, trial = modes[0], {}
-    if len(modes) > 1:
-        # part of the warm-up: a short trial of each launch mode (every rank must take the same one: MAX over ranks decides)
-        for m in modes:
-            w, _ = timed(make_run(cands[m]), 200, 20, barrier)
+    exchanges = (["overlap", "inline"] if args.exchange == "auto" else [args.exchange]) if multi else ["overlap"]
+    combos = [(m, x) for m in modes for x in exchanges]
+    (launch, exchange), trial = combos[0], {}
+    if len(combos) > 1:
+        # part of the warm-up: a short trial of each launch mode (and, for N > 1, of each way to run the exchange); every rank
+        # must take the same one: MAX over ranks decides
+        for m, x in combos:
+            w, _ = timed(make_run(cands[m], x), 200, 20, barrier)
             drain()
             if multi:
                 tm = torch.tensor([w], dtype=torch.float64, device=dev)
                 dist.all_reduce(tm, op=dist.ReduceOp.MAX)
                 w = float(tm.item())
-            trial[m] = w / 200
-        launch = min(modes, key=lambda m: trial[m])
+            trial[m + ("/" + x if multi else "")] = w / 200
+        launch, exchange = min(combos, key=lambda c: trial[c[0] + ("/" + c[1] if multi else "")])
     replays = cands[launch]
     graphed = replays[0][1]
-    wall, ev = timed(make_run(replays), args.steps, args.warmup, barrier)
+    wall, ev = timed(make_run(replays, exchange), args.steps, args.warmup, barrier)
     drain()
     if multi:
         tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
@@ -560,7 +571,9 @@ def main():
                                                                      if launch == "native" else "eager"),
                        "allreduce_stream_waits": reducer.stream_waits if reducer else None,
                        "launch_trial_us_per_step": {m: round(t * 1e6, 2) for m, t in trial.items()} or None, "nnz_per_batch": stack.nnz,
-                       "grad_allreduce": "flat fp32 bucket %d B per step over RCCL, overlapped with the following steps (ring of %d buckets)" % (4 * stack.n_grad, N_BUCKETS) if world > 1 else "none (1 GPU)"},
+                       "grad_allreduce": ("flat fp32 bucket %d B per step over RCCL, " % (4 * stack.n_grad)) +
+                                         ("overlapped with the following steps (ring of %d buckets)" % N_BUCKETS if exchange == "overlap"
+                                          else "synchronous, in line with the compute") if world > 1 else "none (1 GPU)"},
             "event_ms_per_step": ev / args.steps * 1e3,
             "with_prune": {"value": args.batch * args.steps / wall_p, "unit": "sentences/s", "ms_per_step": wall_p / args.steps * 1e3,
                            "note": "rank 0, pruned-tree adjacency build (gcnpt_prune_to_csr) inside every step"},

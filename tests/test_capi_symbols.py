@@ -45,6 +45,21 @@ def test_argument_validation_needs_no_gpu():
     assert L.gcnpt_packed_bytes(200, 360, _lib.BF16) == 13 * 12 * 64 * 16
     assert L.gcnpt_packed_bytes(200, 360, _lib.F32) == 13 * 23 * 64 * 16
     assert L.gcnpt_packed_bytes(0, 360, _lib.BF16) == 0
+    # the whole-loop entry points check that the layers chain before anything is launched
+    two = lambda *v: (ctypes.c_int * 2)(*v)  # noqa: E731
+    ptrs = (ctypes.c_void_p * 2)(p, p)
+    f2, u2 = (ctypes.c_float * 2)(0.0, 0.0), (ctypes.c_uint64 * 2)(0, 0)
+    assert L.gcnpt_layers_fwd(None, 2, p, 0, ptrs, ptrs, p, p, p, None, 1, 1, two(8, 9), two(8, 8), ptrs, two(0, 0), 0, f2, u2, None, None) == _lib.E_INVALID
+    assert b"layer 1 reads 9 columns" in L.gcnpt_last_error()
+    assert L.gcnpt_layers_fwd(None, 9, p, 0, ptrs, ptrs, p, p, p, None, 1, 1, two(8, 8), two(8, 8), ptrs, two(0, 0), 0, f2, u2, None, None) == _lib.E_INVALID
+    none2 = (ctypes.c_void_p * 2)(None, None)
+    assert L.gcnpt_layers_bwd(None, 2, p, ptrs, two(0, 0), ptrs, p, p, p, p, 1, 1, two(8, 8), two(8, 8), none2, two(0, 0), 0, f2, None, None, None, None) == _lib.E_INVALID
+    assert b"dh[1] must exist" in L.gcnpt_last_error()
+    assert L.gcnpt_layers_bwd(None, 2, p, ptrs, two(0, 0), ptrs, p, p, p, p, 1, 1, two(8, 8), two(8, 8), ptrs, two(0, 0), 0, f2, ptrs, None, None, None) == _lib.E_INVALID
+    assert b"weight gradients need" in L.gcnpt_last_error()
+    assert L.gcnpt_compact_trees(None, p, p, None, None, None, p, None, p, p, 1, 4, 12, 0, 12, p, p, None, None, None, p, None, p, p, p, p) == _lib.E_INVALID
+    assert L.gcnpt_compact_trees(None, p, p, None, None, None, p, None, p, p, 1, 4, 12, 4, 12, p, p, p, None, None, p, None, p, p, p, p) == _lib.E_INVALID
+    assert b"labels wanted" in L.gcnpt_last_error()
 
 
 def test_no_cpu_fallback():

@@ -740,6 +740,45 @@ def test_compact_trees_structure(api, dev):
         np.testing.assert_array_equal(got.kept.cpu().numpy(), kept[idx])
 
 
+def test_compact_trees_of_a_dense_adjacency(api, dev):
+    """Compaction of an arbitrary (non-symmetric, rows with more than 7 entries, empty rows and columns) adjacency from
+    gcnpt_adj_to_csr: the kept tokens are those with any entry in their row or column, and layers on them equal the full batch."""
+    gcn, tree = api
+    rng = np.random.RandomState(21)
+    B, T, din, hid = 4, 37, 24, 40
+    adj = ((rng.random_sample((B, T, T)) < 0.3) * rng.randint(1, 40, size=(B, T, T))).astype(np.float32)
+    dead = rng.random_sample((B, T)) < 0.5                                    # tokens outside every edge
+    adj[dead] = 0
+    adj.transpose(0, 2, 1)[dead] = 0
+    full = tree.adj_to_csr(_t(adj, dev)).check()
+    assert (full.ell.view(B, T, 8)[:, :, 0] > 7).any()
+    ct = full.compact().check()
+    keep = ~_oracle_mask(adj)[:, :, 0]
+    np.testing.assert_array_equal(ct.kept.cpu().numpy(), keep.sum(1))
+    dense_c = ct.trees.to_dense().cpu().numpy()
+    want = np.zeros_like(dense_c)
+    for b in range(B):
+        t = np.nonzero(keep[b])[0]
+        want[b, :len(t), :len(t)] = adj[b][np.ix_(t, t)]
+        np.testing.assert_array_equal(ct.tok.cpu().numpy()[b, :len(t)], t)
+    np.testing.assert_array_equal(dense_c, want)
+    _check_ell(ct.trees, want)
+    Ws = [_t(rng.uniform(-.3, .3, (hid, din)).astype(np.float32), dev), _t(rng.uniform(-.3, .3, (hid, hid)).astype(np.float32), dev)]
+    bs = [_t(rng.uniform(-.3, .3, (hid,)).astype(np.float32), dev) for _ in range(2)]
+    x = _t(rng.standard_normal((B, T, din)).astype(np.float32), dev)
+    gy = _t(rng.standard_normal((B, T, hid)).astype(np.float32), dev) * _t(keep, dev).unsqueeze(-1)
+
+    def run(xin, trees, g):
+        xin = xin.clone().requires_grad_()
+        out = gcn.gcn_layers(xin, Ws, bs, trees, None, None, torch.float32, torch.float32)
+        out.backward(g)
+        return out.detach(), xin.grad
+    o_f, dx_f = run(x, full, gy)
+    o_c, dx_c = run(ct.take(x), ct.trees, ct.take(gy) * ct.valid.unsqueeze(-1))
+    v = ct.valid
+    assert torch.equal(o_c[v], ct.take(o_f)[v]) and torch.equal(dx_c[v], ct.take(dx_f)[v])
+
+
 @pytest.mark.parametrize("compute", [torch.float32, torch.bfloat16])
 def test_pooled_only_rows_equal_full_batch_rows(api, dev, compute):
     """Layers on the kept tokens give, row for row, what the full batch gives for those tokens (forward and dx exactly:

@@ -64,6 +64,37 @@ __global__ __launch_bounds__(THREADS) void rounds2_kernel(float* buf, unsigned* 
     }
 }
 
+// variant: the publish / consume recipe of cdna_hip_programming.md (ONE agent-scope release by lane 0 after every wave has
+// drained its stores, a relaxed ticket, relaxed polling, ONE agent-scope acquire by lane 0) on the two-level counters
+__global__ __launch_bounds__(THREADS) void rounds3_kernel(float* buf, unsigned* counters, int rounds, unsigned* bad, unsigned* timeouts) {
+    const int wg = blockIdx.x, tid = threadIdx.x, grp = wg & 7;
+    const unsigned members = (WGS - grp + 7) / 8;
+    for (int r = 0; r < rounds; ++r) {
+        float* mine = buf + ((size_t)(r & 1) * WGS + wg) * SLAB;
+        for (int i = tid; i < SLAB; i += THREADS) mine[i] = (float)(r * 1000 + wg);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned before = __hip_atomic_fetch_add(counters + grp * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (before + 1 == (unsigned)(r + 1) * members) __hip_atomic_fetch_add(counters + 8 * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = (unsigned)(r + 1) * 8;
+            int it = 0;
+            while (__hip_atomic_load(counters + 8 * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && it < (1 << 22)) { __builtin_amdgcn_s_sleep(1); ++it; }
+            if (it >= (1 << 22)) atomicAdd(timeouts, 1u);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        const int other = (wg + 3) % WGS;
+        const float* theirs = buf + ((size_t)(r & 1) * WGS + other) * SLAB;
+        unsigned wrong = 0;
+        for (int i = tid; i < SLAB; i += THREADS) wrong += theirs[i] != (float)(r * 1000 + other);
+        if (wrong) atomicAdd(bad, wrong);
+    }
+}
+
 __global__ __launch_bounds__(THREADS) void one_phase_kernel(float* buf, int r, unsigned* bad) {      // the same work, one round per LAUNCH
     const int wg = blockIdx.x, tid = threadIdx.x;
     float* mine = buf + ((size_t)(r & 1) * WGS + wg) * SLAB;
@@ -114,6 +145,22 @@ int main() {
             printf("one launch, %2d rounds, two-level barrier, fences %d:       %7.2f us (%.2f us per round), wrong values %u, timeouts %u\n",
                    rounds, fences, best * 1e3, best * 1e3 / rounds, hb, ht);
         }
+    for (int rounds : {1, 2, 16, 64}) {
+        float best = 1e9f; unsigned hb = 0, ht = 0;
+        for (int rep = 0; rep < 20; ++rep) {
+            CHECK(hipMemset(counters, 0, 4 * 9 * 32)); CHECK(hipMemset(bad, 0, 4)); CHECK(hipMemset(timeouts, 0, 4));
+            CHECK(hipDeviceSynchronize());
+            CHECK(hipEventRecord(e0));
+            hipLaunchKernelGGL(rounds3_kernel, dim3(WGS), dim3(THREADS), 0, 0, buf, counters, rounds, bad, timeouts);
+            CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best) best = ms;
+            unsigned b, t; CHECK(hipMemcpy(&b, bad, 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(&t, timeouts, 4, hipMemcpyDeviceToHost));
+            hb += b; ht += t;
+        }
+        printf("one launch, %2d rounds, lane-0 release/acquire recipe:       %7.2f us (%.2f us per round), wrong values %u, timeouts %u\n",
+               rounds, best * 1e3, best * 1e3 / rounds, hb, ht);
+    }
     for (int rounds : {16, 64}) {
         float best = 1e9f; unsigned hb = 0;
         for (int rep = 0; rep < 20; ++rep) {

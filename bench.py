@@ -59,10 +59,10 @@ def parse():
                          "measured slower on MI355X (85 -> 88 us with the pruner, 68 -> 82 with cached trees): parallel graph branches cost more than they hide")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--cpu-threads", type=int, default=4,
-                    help="BLAS threads of the CPU baseline (4 measured fastest on the bench box: 1169 sentences/s vs 701 at 16 and 749 at 128; "
-                         "the matrices are small)")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="seconds of CPU work per cpu_baseline leg (three legs)")
+    ap.add_argument("--cpu-threads", type=int, default=8,
+                    help="threads of the headline cpu_baseline leg (8 = what BASELINE.md timed the reference itself with); an all-cores "
+                         "leg and the NumPy port (4 BLAS threads, its measured optimum) are reported beside it")
     ap.add_argument("--launch", choices=["auto", "graph", "native"], default="auto",
                     help="graph: the step's launches replayed as one hipGraph; native: eager launches from three native calls per step "
                          "(gcnpt_pack_weights_multi, gcnpt_layers_fwd, gcnpt_layers_bwd), which keeps the queue fed as long as the host is "
@@ -71,6 +71,8 @@ def parse():
                     help="N > 1: gradient all-reduce overlapped with the following steps on the communication stream, in line with the "
                          "compute (synchronous call), or whichever a warm-up trial finds faster")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements on rank 0 (with_prune, with_cached_trees, the fp32 "
+                                                                "strict-parity block): quick runs and tests")
     ap.add_argument("--no-pooled-only", action="store_true", help="skip the secondary pooled-only-rows measurement (profiling runs: its launches "
                                                                   "would mix into the per-kernel statistics of the headline step)")
     return ap.parse_args()
@@ -341,6 +343,28 @@ class Stack(object):
             out["stack_bwd_weight"] = hf + gf + 4 * (H * Din + H * H)
         return out
 
+    def survey_bytes(self):
+        """SURVEY.md 8(d)'s ALGORITHMIC bytes of the layer math each launch covers (padded layout, S recomputed in backward, no saved
+        images, no pack): fwd = e N (Din+H) + e Din H + 4H + CSR; bwd = e N (2H+2Din) + (e+4) Din H + 4H + CSR, of which the data
+        half reads dY, Y, W, CSR and writes dh, and the weight half reads h and writes dW, db.  Launches that cover several of these
+        get their sum; `pack` covers none (0)."""
+        e = 2 if self.args.dtype == "bf16" else 4
+        N = self.B * self.T
+        csr = 4 * (N + 1) + 4 * self.nnz
+        per = {}
+        for l, (H, Din) in enumerate([tuple(w.shape) for w in self.W]):
+            per["fwd%d" % l] = e * N * (Din + H) + e * Din * H + 4 * H + csr
+            per["bwd_data%d" % l] = e * N * (2 * H + Din) + e * Din * H + csr
+            per["bwd_weight%d" % l] = e * N * Din + 4 * Din * H + 4 * H
+        L = len(self.W)
+        per["bwd_weight"] = sum(per["bwd_weight%d" % l] for l in range(L))
+        per["fwd"] = per["stack_fwd"] = sum(per["fwd%d" % l] for l in range(L))
+        per["bwd_data"] = per["stack_bwd"] = sum(per["bwd_data%d" % l] for l in range(L))
+        per["stack_bwd_weight"] = per["bwd_weight"]
+        per["pack"] = 0
+        per["prune"] = 0
+        return per
+
 
 def capture(fn, use_graph):
     """Returns a callable that replays `fn` (a hipGraph when possible)."""
@@ -424,15 +448,16 @@ def kernel_breakdown(stack, use_graph, rounds=100, reps=8):
 
 
 def cpu_baseline(args, seconds):
-    """The CPU oracle (numpy port of the reference's dense-bmm layer loop, fp32) on this box's host cores, same workload."""
+    """
+    The reference's CPU path on this box's host cores, same workload, three legs (bounded: `seconds` each):
+      value      oracle/gcn_ref_torch.py -- the reference's own library ops (dense bmm over [B,T,T], 2 x linear per layer, autograd),
+                 pinned to the reference's recorded outputs in tests/test_oracle_golden.py -- at --cpu-threads (8: BASELINE.md's setting)
+      all_cores  the same at torch's default thread count for this box
+      numpy_port oracle/gcn_ref.py (explicit NumPy backward), 4 BLAS threads
+    The tree build is excluded (as in `value` of the GPU line); the C oracle's time for it is in `sample`.
+    """
     from gcn_over_pruned_trees_amd.utils import synthetic
-    from oracle import gcn_ref, prune_ref
-    try:
-        from threadpoolctl import threadpool_info, threadpool_limits
-        threadpool_limits(limits=max(1, min(args.cpu_threads, os.cpu_count() or 1)))
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        cores = os.cpu_count() or 1
+    from oracle import gcn_ref, gcn_ref_torch, prune_ref
     B, T, Din, H = args.batch, args.seq, args.din, args.hidden
     tb = synthetic.random_tree_batch(1234, B, T, args.lengths)
     Ws, bs = synthetic.layer_params(1235, [Din, H, H])
@@ -440,24 +465,99 @@ def cpu_baseline(args, seconds):
     t0 = time.perf_counter()
     adj = prune_ref.batch_adj(tb["head"], tb["subj_pos"], tb["obj_pos"], tb["deprel"], tb["lens"], args.prune_k)["adj"]
     t_prune = time.perf_counter() - t0
-    gcn_ref.gcn_backward(adj, x, Ws, bs, gy)          # warm-up (its forward is inside)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        gcn_ref.gcn_backward(adj, x, Ws, bs, gy)      # forward + backward of the 2-layer stack
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= seconds and n >= 3:
-            break
-    return dict(value=B * n / el, unit="sentences/s", cores=int(cores), kind="port",
-                sample="%d fwd+bwd steps of the same %dx%d workload in %.1f s (numpy/BLAS fp32 port of the reference's dense-bmm layer loop, "
-                       "oracle/gcn_ref.py; tree build excluded, it took %.1f ms per batch in the C oracle on 1 core)" % (n, B, T, el, t_prune * 1e3))
+
+    def loop(fn):
+        fn()                                              # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            fn()
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= seconds and n >= 3:
+                return n, el
+
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
+    targs = (tt(adj), tt(x), [tt(w) for w in Ws], [tt(b) for b in bs], tt(gy))
+    default_threads = torch.get_num_threads()
+    legs = {}
+    for key, nthr in (("t", max(1, min(args.cpu_threads, os.cpu_count() or 1))), ("all", default_threads)):
+        torch.set_num_threads(nthr)
+        n, el = loop(lambda: gcn_ref_torch.forward_backward(*targs))
+        legs[key] = dict(value=B * n / el, cores=nthr, steps=n, seconds=el)
+    torch.set_num_threads(default_threads)
+    np_cores = 4
+    try:
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=np_cores):
+            n, el = loop(lambda: gcn_ref.gcn_backward(adj, x, Ws, bs, gy))
+    except Exception:
+        np_cores = os.cpu_count() or 1
+        n, el = loop(lambda: gcn_ref.gcn_backward(adj, x, Ws, bs, gy))
+    t = legs["t"]
+    return dict(value=t["value"], unit="sentences/s", cores=int(t["cores"]), kind="port",
+                sample="%d fwd+bwd steps of the same %dx%d workload in %.1f s: torch-CPU restatement of the reference's layer loop with its own ops "
+                       "(dense bmm + 2 x linear per layer + autograd, oracle/gcn_ref_torch.py, fp32); tree build excluded (%.1f ms per batch in the C "
+                       "oracle on 1 core); host has %d logical CPUs" % (t["steps"], B, T, t["seconds"], t_prune * 1e3, os.cpu_count() or 0),
+                all_cores=dict(value=legs["all"]["value"], cores=int(legs["all"]["cores"]), steps=legs["all"]["steps"]),
+                numpy_port=dict(value=B * n / el, cores=int(np_cores), steps=n,
+                                note="oracle/gcn_ref.py, explicit NumPy/BLAS backward (round 1's baseline)"))
+
+
+def self_launch(args):
+    """
+    `python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): start N fresh rank processes, one per
+    GPU, BEFORE anything in this process touches the GPU (this parent never does: it only waits), and relay rank 0's single
+    JSON line.  The children are this same script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, exactly what
+    `python -m torch.distributed.run --nproc-per-node N` would give them.  A rank that fails ends the others and the run
+    exits non-zero; nothing is restarted.
+    """
+    import socket
+    import subprocess
+    n = args.gpus
+    one_dev = bool(os.environ.get("GCNPT_BENCH_ONE_DEVICE"))
+    have = torch.cuda.device_count()                # counting devices does not initialise the GPU on this image
+    if have < n and not one_dev:
+        print("[bench] --gpus %d but only %d GPU(s) visible (GCNPT_BENCH_ONE_DEVICE=1 rehearses N ranks on one GPU)" % (n, have), file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), GCNPT_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "4")
+        out = subprocess.PIPE if r == 0 else sys.stderr           # only rank 0 owns the JSON line
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
+    line0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for pr in procs[1:]:
+        if rc != 0 and pr.poll() is None:
+            pr.kill()                                               # by handle: these are exactly the processes started above
+        rc = pr.wait() or rc
+    text = line0.decode("utf-8", "replace") if line0 else ""
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    if rc != 0 or len(lines) != 1:
+        sys.stderr.write(text)
+        print("[bench] self-launched %d ranks: exit code %d, %d JSON line(s) from rank 0" % (n, rc, len(lines)), file=sys.stderr)
+        return rc or 1
+    print(lines[0], flush=True)
+    return 0
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        # N comes from the launcher (WORLD_SIZE); a mismatch with --gpus is a caller error, not something to guess about
+        if rank == 0:
+            print("[bench] --gpus %d but WORLD_SIZE %d: they must agree" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     force_dist = bool(os.environ.get("GCNPT_BENCH_FORCE_DIST"))      # rehearsal: the N > 1 code path (RCCL init, overlapped all-reduce) with one rank
     saved_stdout = None
     if world > 1 or force_dist:
@@ -480,12 +580,13 @@ def main():
         dist = None
         torch.cuda.set_device(0)
         barrier = lambda: None  # noqa: E731
-    if args.gpus != world and rank == 0 and world > 1:
-        print("[bench] --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     dev = torch.device("cuda", local if world > 1 else 0)
     use_graph = not args.no_graph
 
-    stack = Stack(args, dev, seed=1234 + 17 * rank)
+    # every rank draws its own shard of the global batch; GCNPT_BENCH_SAME_SHARD=1 (tests) gives all ranks rank 0's shard, so that
+    # the all-reduced bucket must be exactly world x the one-rank bucket
+    shard_seed = 1234 + (0 if os.environ.get("GCNPT_BENCH_SAME_SHARD") else 17 * rank)
+    stack = Stack(args, dev, seed=shard_seed)
     from gcn_over_pruned_trees_amd.shard import OverlappedAllReduce
 
     # ---- the timed step: layer stack fwd+bwd (+ overlapped gradient all-reduce when N > 1)
@@ -544,20 +645,27 @@ def main():
     graphed = replays[0][1]
     wall, ev = timed(make_run(replays, exchange), args.steps, args.warmup, barrier)
     drain()
+    rank_ms = [wall / args.steps * 1e3]
     if multi:
-        tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        wall = float(tmax.item())
+        mine = torch.tensor([wall], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, mine)
+        rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
+        wall = max(float(t.item()) for t in every)                 # contract: MAX over ranks
     assert torch.isfinite(stack.buckets[0]).all() and torch.isfinite(stack.dx.float()).all()
+    # the bucket the LAST timed step wrote, after its all-reduce (drain() above): rank-sum of [dW0, db0, dW1, db1]
+    last_bucket = stack.buckets[(args.steps - 1) % N_BUCKETS if multi else 0]
+    grad_abs_sum = float(last_bucket.double().abs().sum().item())
 
     result = None
     if rank == 0:
         sent = args.batch * world * args.steps
         # second measurement on rank 0 only: tree build inside the step
-        run_p = runner(launch, with_prune=True)[0][0]
-        wall_p, _ = timed(lambda i: run_p(), args.steps, min(args.warmup, 50), lambda: None)
-        run_c = runner(launch, with_prune="cached")[0][0]
-        wall_c, _ = timed(lambda i: run_c(), args.steps, min(args.warmup, 50), lambda: None)
+        if not args.no_secondary:
+            run_p = runner(launch, with_prune=True)[0][0]
+            wall_p, _ = timed(lambda i: run_p(), args.steps, min(args.warmup, 50), lambda: None)
+            run_c = runner(launch, with_prune="cached")[0][0]
+            wall_c, _ = timed(lambda i: run_c(), args.steps, min(args.warmup, 50), lambda: None)
         result = {
             "metric": "GCN-layer fwd+bwd sentences/sec at batch=50 seq=100 h=200",
             "value": sent / wall, "unit": "sentences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -567,6 +675,10 @@ def main():
                                    "synthetic TACRED-shaped random trees (lengths=%s), dropout %.1f between layers"
                                    % (args.batch, args.seq, args.din, args.hidden, args.prune_k, args.dtype, args.lengths, args.drop),
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "parallelism": "dp%d" % world,
+                       "world_size": dist.get_world_size() if multi else 1, "dist_backend": dist.get_backend() if multi else None,
+                       "ranks_started_by": ("bench.py itself (--gpus N without a launcher)" if os.environ.get("GCNPT_BENCH_SELF_LAUNCHED")
+                                            else "torch.distributed.run / caller") if world > 1 else None,
+                       "ms_per_step_by_rank": [round(t, 6) for t in rank_ms], "grad_bucket_abs_sum": grad_abs_sum,
                        "launch": "hipGraph replay" if graphed else ("eager launches from 3 native calls per step (pack, gcnpt_layers_fwd, gcnpt_layers_bwd)"
                                                                      if launch == "native" else "eager"),
                        "allreduce_stream_waits": reducer.stream_waits if reducer else None,
@@ -575,13 +687,32 @@ def main():
                                          ("overlapped with the following steps (ring of %d buckets)" % N_BUCKETS if exchange == "overlap"
                                           else "synchronous, in line with the compute") if world > 1 else "none (1 GPU)"},
             "event_ms_per_step": ev / args.steps * 1e3,
-            "with_prune": {"value": args.batch * args.steps / wall_p, "unit": "sentences/s", "ms_per_step": wall_p / args.steps * 1e3,
-                           "note": "rank 0, pruned-tree adjacency build (gcnpt_prune_to_csr) inside every step"},
-            "with_cached_trees": {"value": args.batch * args.steps / wall_c, "unit": "sentences/s", "ms_per_step": wall_c / args.steps * 1e3,
-                                  "note": "rank 0, dataset pruned once; every step assembles its batch's adjacency with gcnpt_gather_trees"},
         }
+        if not args.no_secondary:
+            result["with_prune"] = {"value": args.batch * args.steps / wall_p, "unit": "sentences/s", "ms_per_step": wall_p / args.steps * 1e3,
+                                    "note": "rank 0, pruned-tree adjacency build (gcnpt_prune_to_csr) inside every step"}
+            result["with_cached_trees"] = {"value": args.batch * args.steps / wall_c, "unit": "sentences/s", "ms_per_step": wall_c / args.steps * 1e3,
+                                           "note": "rank 0, dataset pruned once; every step assembles its batch's adjacency with gcnpt_gather_trees"}
+            if args.dtype == "bf16":
+                # the reference's own arithmetic: fp32 activations, exact fp32 MFMA (the strict-parity mode of the tests), same step
+                import copy
+                a32 = copy.copy(args)
+                a32.dtype = "fp32"
+                s32 = Stack(a32, dev, seed=shard_seed)
+                if launch == "native":
+                    run32 = s32.step_native
+                    run32()
+                    torch.cuda.synchronize()
+                else:
+                    run32, _ = capture(lambda: s32.step(0), use_graph)
+                n32 = max(args.steps // 4, 50)
+                wall32, _ = timed(lambda i: run32(), n32, min(args.warmup, 50), lambda: None)
+                result["fp32"] = {"value": args.batch * n32 / wall32, "unit": "sentences/s", "ms_per_step": wall32 / n32 * 1e3, "dtype": "f32",
+                                  "steps": n32, "note": "rank 0, same step with fp32 activations and exact fp32 MFMA (v_mfma_f32_16x16x4_f32): the "
+                                                        "reference's own arithmetic, the mode the 1e-5 / 1e-4 parity tests run in"}
+                del s32
         if not stack.fused and not args.no_pooled_only:
-            sc = Stack(args, dev, seed=1234 + 17 * rank, pooled_only=True)
+            sc = Stack(args, dev, seed=shard_seed, pooled_only=True)
             if launch == "native":
                 run_k = sc.step_native
                 run_k()
@@ -600,32 +731,40 @@ def main():
         if not args.no_kernel_breakdown:
             kt = kernel_breakdown(stack, use_graph)
             step_keys = [k for k in kt if k != "prune"]
-            result["config"]["kernels_per_step"] = "sentence-resident stack: pack, stack_fwd, stack_bwd, stack_bwd_weight" if stack.fused \
-                else ("pack, fwd0, fwd1, bwd_data1, bwd_weight1, bwd_data0, bwd_weight0" if args.split_weight_grad
-                      else "pack, fwd0, fwd1, bwd_data1, bwd_data0, bwd_weight (both layers, one launch)")
+            result["config"]["kernels_per_step"] = ", ".join(k for k, _ in stack.calls(0))
             dom = max(step_keys, key=lambda k: kt[k])
-            traffic = None
-            tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # per-launch HBM bytes from rocprofv3 --pmc passes, if recorded
+            sv = stack.survey_bytes()
+            # HBM-side bytes per launch from separate rocprofv3 --pmc passes (tools/profile_round.sh): only quoted when that recording was
+            # made for THIS shape / dtype / launch list (its "meta"), otherwise null -- a replayed number for another workload is no evidence
+            traffic, traffic_src = None, None
+            tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tf):
                 with open(tf) as f:
-                    traffic = json.load(f).get(dom)
-            gbs = alg[dom] / kt[dom] / 1e9
+                    rec = json.load(f)
+                meta = rec.get("meta", {})
+                here = dict(batch=args.batch, seq=args.seq, din=args.din, hidden=args.hidden, prune_k=args.prune_k, dtype=args.dtype,
+                            lengths=args.lengths, kernels=[k for k, _ in stack.calls(0)])
+                if all(meta.get(k) == v for k, v in here.items()):
+                    traffic = rec.get("traffic", {}).get(dom)
+                    traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload at git %s, 2*FETCH+WRITE)" % meta.get("git_sha", "?")
+            gbs = sv[dom] / kt[dom] / 1e9
             result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                                  "traffic": traffic, "algorithmic_bytes": alg[dom], "avg_launch_us": kt[dom] * 1e6,
-                                  "note": "in-step duration: HIP events around replays of the step truncated after k launches (8 copies per hipGraph, so the replay "
-                                          "overhead is spread out), t(k)-t(k-1); includes the launch boundary"}
-            result["kernels"] = {k: {"avg_us": kt[k] * 1e6, "algorithmic_bytes": alg[k], "GBps": alg[k] / kt[k] / 1e9} for k in kt}
+                                  "traffic": traffic, "traffic_source": traffic_src,
+                                  "algorithmic_bytes": sv[dom], "avg_launch_us": kt[dom] * 1e6,
+                                  "dataflow_bytes": alg[dom], "dataflow_frac": alg[dom] / kt[dom] / 1e9 / HBM_PEAK_GBS,
+                                  "note": "achieved = SURVEY.md 8(d) bytes of the layer math this launch covers / its in-step duration (HIP events around replays of "
+                                          "the step truncated after k launches, 8 copies per hipGraph, t(k)-t(k-1); includes the launch boundary); dataflow_* counts "
+                                          "what this implementation moves on top (saved-operand fragment images, packed weights)"}
+            result["kernels"] = {k: {"avg_us": kt[k] * 1e6, "survey_8d_bytes": sv.get(k), "dataflow_bytes": alg[k],
+                                     "GBps_8d": (sv[k] / kt[k] / 1e9) if sv.get(k) else None} for k in kt}
             tot_b = sum(alg[k] for k in step_keys)
-            # SURVEY.md 8(d) counts the layer math only (S = (A+I)h recomputed in backward, no saved-operand images, no pack):
-            e, Nr, csr = (2 if args.dtype == "bf16" else 4), args.batch * args.seq, 4 * (args.batch * args.seq + 1) + 4 * stack.nnz
-            survey = sum(e * Nr * (Din + H) + e * Din * H + 4 * H + csr + e * Nr * (2 * H + 2 * Din) + (e + 4) * Din * H + 4 * H + csr
-                         for H, Din in [tuple(w.shape) for w in stack.W])
+            survey = sum(sv.get(k, 0) for k in step_keys)
             t_step = wall / args.steps
-            result["step_roofline"] = {"algorithmic_bytes": tot_b, "sum_kernel_us": sum(kt[k] for k in step_keys) * 1e6,
-                                       "frac_of_hbm_peak": tot_b / sum(kt[k] for k in step_keys) / 1e9 / HBM_PEAK_GBS,
-                                       "survey_8d_bytes": survey, "survey_8d_frac_of_hbm_peak": survey / t_step / 1e9 / HBM_PEAK_GBS,
-                                       "note": "algorithmic_bytes = what this dataflow must move (incl. the saved-operand images and the "
-                                               "weight pack); survey_8d_bytes = SURVEY.md 8(d)'s formula for the layer math alone, over the whole step time"}
+            result["step_roofline"] = {"survey_8d_bytes": survey, "frac_of_hbm_peak": survey / t_step / 1e9 / HBM_PEAK_GBS,
+                                       "sum_kernel_us": sum(kt[k] for k in step_keys) * 1e6,
+                                       "dataflow_bytes": tot_b, "dataflow_frac_of_hbm_peak": tot_b / sum(kt[k] for k in step_keys) / 1e9 / HBM_PEAK_GBS,
+                                       "note": "survey_8d_bytes = SURVEY.md 8(d)'s formula for the layer math alone (S recomputed, no saved images, no pack), "
+                                               "over the WHOLE timed step (ms_per_step); dataflow_bytes = what this implementation moves, over the summed kernel times"}
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         sys.stdout.flush()

@@ -91,6 +91,24 @@ def test_layers_forward_backward(name):
         assert max_rel(dbs[l], g["db%d" % l]) <= GRAD_RTOL
 
 
+@pytest.mark.parametrize("name", ["layers_c1_l2.npz", "layers_c2s.npz"])
+def test_torch_cpu_restatement_pinned_to_reference(name):
+    """oracle/gcn_ref_torch.py (bench.py's cpu_baseline: the reference's own library ops -- bmm, 2 x linear, autograd) against the
+    outputs and gradients recorded from the live reference."""
+    import torch
+    from oracle import gcn_ref_torch
+    g = layer_case(name)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
+    h, dx, dWs, dbs = gcn_ref_torch.forward_backward(t(g["adj"]), t(g["x"]), [t(w) for w in g["Ws"]], [t(b) for b in g["bs"]], t(g["gy"]))
+    _, _, mask = gcn_ref_torch.prep(t(g["adj"]))
+    np.testing.assert_array_equal(mask.numpy(), g["mask"])
+    assert max_rel(h.numpy(), g["h"]) <= FWD_RTOL
+    assert max_rel(dx.numpy(), g["dx"]) <= GRAD_RTOL
+    for l in range(int(g["layers"])):
+        assert max_rel(dWs[l].numpy(), g["dW%d" % l]) <= GRAD_RTOL
+        assert max_rel(dbs[l].numpy(), g["db%d" % l]) <= GRAD_RTOL
+
+
 def test_bf16_variant_close_to_fp32():
     g = layer_case("layers_c1_l2.npz")
     h, _, _ = gcn_ref.gcn_forward_bf16(g["adj"], g["x"], g["Ws"], g["bs"])

@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--fused", action="store_true",
                     help="sentence-resident stack kernels (all layers in one launch per direction) instead of one launch per layer; "
                          "measured slower on MI355X at this size (109 vs 76 us/step): 50 workgroups carry every elementwise phase")
+    ap.add_argument("--fused2", action="store_true",
+                    help="both layers' forward in ONE launch (gcnpt_fused2_fwd, halo recompute, no inter-workgroup wait) instead of one launch "
+                         "per layer; same bits; measured slower on MI355X at this size (fwd 32 us against 18 us)")
     ap.add_argument("--split-weight-grad", action="store_true",
                     help="one weight-gradient launch per layer (right after that layer's backward-data) instead of one launch "
                          "for all layers at the end of the backward sweep")
@@ -249,6 +252,10 @@ class Stack(object):
         elif with_prune:
             self.prune()
         L = self.L
+        if self.args.fused2:                    # opt-in A/B: the step with the two-layer forward launch (eager launches from Python)
+            for _, call in self.calls(k):
+                call()
+            return
         rc = L.gcnpt_pack_weights_multi(st, *pack) or L.gcnpt_layers_fwd(st, *fwd) or L.gcnpt_layers_bwd(st, *bwd)
         if rc:
             self._lib.check(rc)
@@ -276,6 +283,18 @@ class Stack(object):
         self._lib.check(self.L.gcnpt_stack_bwd_weight(self._lib.stream(), L, A(self.gf), A(self.hf), self.B, self.T, self.Din, self.H,
                                                       A([g[0], g[2]])))
 
+    def fwd_all(self):
+        """Both layers' forward in ONE launch (csrc/fused_kernels.hip, opt-in)."""
+        P, A, tr = self._lib.ptr, self._lib.ptr_array, self.trees
+        self._lib.check(self.L.gcnpt_fused2_fwd(
+            self._lib.stream(), P(self.x), A(self.wf), A(self.b), P(tr.row_ptr), P(tr.col_idx), P(tr.ell), None, self.B, self.T, self.Din,
+            (ctypes.c_int * 2)(self.H, self.H), P(self.h1), P(self.h2), self.act, (ctypes.c_float * 2)(self.args.drop, 0.0),
+            (ctypes.c_uint64 * 2)(0x5eed, 0), A(self.sf), None))
+
+    def two_layer_launches(self):
+        return (self.args.fused2 and len(self.W) == 2 and self.args.dtype == "bf16" and
+                bool(self.L.gcnpt_fused2_supported(self.T, self.Din, self.H, self.H, self.act, self.compute)))
+
     def calls(self, k=0):
         """The launches of one step, in order (name, callable)."""
         if self.fused:
@@ -285,6 +304,9 @@ class Stack(object):
             return [("pack", self.pack_all), ("fwd0", lambda: self.fwd(0)), ("fwd1", lambda: self.fwd(1)),
                     ("bwd_data1", lambda: self.bwd_data(1, k)), ("bwd_weight1", lambda: self.bwd_weight(1, k)),
                     ("bwd_data0", lambda: self.bwd_data(0, k)), ("bwd_weight0", lambda: self.bwd_weight(0, k))]
+        if self.two_layer_launches():
+            return [("pack", self.pack_all), ("fwd", self.fwd_all), ("bwd_data1", lambda: self.bwd_data(1, k)),
+                    ("bwd_data0", lambda: self.bwd_data(0, k)), ("bwd_weight", lambda: self.bwd_weight_all(k))]
         return [("pack", self.pack_all), ("fwd0", lambda: self.fwd(0)), ("fwd1", lambda: self.fwd(1)),
                 ("bwd_data1", lambda: self.bwd_data(1, k)), ("bwd_data0", lambda: self.bwd_data(0, k)),
                 ("bwd_weight", lambda: self.bwd_weight_all(k))]
@@ -332,6 +354,8 @@ class Stack(object):
             out["bwd_weight%d" % l] = self.zf[l].numel() + self.sf[l].numel() + 4 * (H * Din + H)
             out["bwd_weight"] = out.get("bwd_weight", 0) + out["bwd_weight%d" % l]
             out["pack"] = out.get("pack", 0) + 4 * H * Din + self.wf[l].numel() + self.wb[l].numel()
+        out["fwd"] = sum(out["fwd%d" % l] for l in range(len(self.W)))
+        out["bwd_data"] = sum(out["bwd_data%d" % l] for l in range(len(self.W)))
         out["prune"] = 4 * 8 * N + N + 2 * (csr + 4 * B * (T + 1) + 4 * self.nnz) + N + 4 * (B + 1)
         if self.fused:
             (H, Din), grads = tuple(self.W[0].shape), 4 * self.n_grad

@@ -410,11 +410,7 @@ template <int MODE>
 static int bilinear_launch(hipStream_t s, BilinearParams& p) {
     const size_t lds = ((size_t)BL_RING * BL_FRAGS + BL_WAVES) * 64 * sizeof(uint4) + sizeof(float) * (BL_ROWS + 1) * (size_t)p.d_per_slice;
     if (lds > 160 * 1024) return fail(GCNPT_E_UNSUPPORTED, "bilinear: %zu B of LDS", lds);
-    static bool big_lds = false;
-    if (lds > 64 * 1024 && !big_lds) {
-        GCNPT_HIP_CHECK(hipFuncSetAttribute((const void*)bilinear_fwd_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        big_lds = true;
-    }
+    GCNPT_LDS_ATTR_ONCE(bilinear_fwd_kernel<MODE>, 160 * 1024);
     hipLaunchKernelGGL(bilinear_fwd_kernel<MODE>, dim3(p.mb * p.nb * p.slices), dim3(BL_THREADS), lds, s, p);
     GCNPT_HIP_CHECK(hipGetLastError());
     return GCNPT_OK;

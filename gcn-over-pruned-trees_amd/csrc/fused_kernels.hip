@@ -1,0 +1,622 @@
+// Two stacked GCN layers' FORWARD in ONE launch for gfx950 (CDNA4): reference model/gcn.py:266-271, 390-393 (the loop over l for
+// num_layers = 2).  bf16 MFMA operands / bf16 activations between the layers, fp32 accumulation.  OPT-IN (gcnpt_fused2_fwd).
+//
+// A layer needs its neighbours' rows of the layer below, which other workgroups own: the per-layer kernels
+// (rowtile_kernels.hip) therefore end at a kernel boundary after every layer.  Here a workgroup owns a tile R of 32 token
+// rows as before, but computes layer 0 also for the halo
+//     H1 = { c : c is a neighbour of some r in R, c not in R }
+// so that every row layer 1 gathers is already in its own LDS.  Neighbours never leave a sentence (model/tree.py:167-204: the
+// adjacency is block diagonal), so H1 lies inside the window of +-(T-1) rows around the tile and |H1| <= 2 (T-1).  No workgroup
+// ever waits for another one: no flags, no device-scope fences, any grid size.
+//
+// Values are bit-identical to the per-layer kernels: same summation order in the gather (own row, then the row's entries in
+// CSR order), same k order on the matrix cores, same epilogue arithmetic, same bf16 rounding points, same dropout hash.
+//
+// MEASURED (MI355X, B=50, T=100, 360->200->200): 32 us against 18 us for the two per-layer launches.  With
+// full-length sentences H1 is ~15-20 rows per tile, i.e. ~50 % extra layer-0 rows whose gather, MFMA and dropout epilogue are
+// all on one workgroup's critical path (45.7 k cycles per workgroup against 16 k + 12.5 k for the two launches); the launch
+// boundary it removes costs ~4 us.  Kept as a tested opt-in; gcnpt_layers_fwd does not use it.
+#include "layer_common.h"
+
+namespace gcnpt {
+
+constexpr int FU_ROWS = 32;            // rows a workgroup owns
+constexpr int FU_THREADS = 512;
+constexpr int FU_WAVES = 8;
+constexpr int FU_PASS = 64;            // first-stage rows per pass (four 16-row MFMA tiles)
+constexpr int FU_NTW = 2;              // output tiles per wave: 8 waves x 2 x 16 = 256 columns
+constexpr int FU_NBU = 4;              // neighbour rows fetched with a row in its first round trip
+constexpr int FU_NB_INLINE = 7;        // entries an ELL head carries (include/gcnpt.h)
+constexpr int FU_WIN_MAX = 256;        // window rows whose ELL heads are staged (32 + 2 (T-1) <= 256)
+
+struct FusedParams {
+    // forward: src = x [N,K0] bf16, mid = h1 [N,H0] bf16 (written), out = h2 [N,H1] (written)
+    // backward: src = dY [N,H1], yref = Y1 = h2 [N,H1], mid_y = Y0 = h1 [N,H0], mid = dZ0 scratch (not written), out = dx [N,K0]
+    const void* src; const void* yref; const void* mid_y;
+    void* mid; void* out;
+    const uint4* wA; const uint4* wB;          // packed weights of the first / second stage (gcnpt_pack_weights images)
+    const float* bA; const float* bB;          // forward: biases of layer 0 / layer 1
+    const int32_t* g_row_ptr; const int32_t* g_col_idx; const int32_t* g_ell;     // aggregated pattern (fwd: A, bwd: A^T)
+    const int32_t* d_ell;                      // ELL head whose [8r] gives deg (always the forward pattern)
+    uint4* fragA; uint4* fragB;                // fragment images (fwd: S0, S1; bwd: dZ1, dZ0) or NULL
+    float* zero_a; float* zero_b; float* zero_c; float* zero_d;     // bwd: dW1, db1, dW0, db0 to clear (or NULL)
+    int zero_a_n, zero_b_n, zero_c_n, zero_d_n;
+    int N, T, hw;                              // rows, padded sentence length, halo window (T - 1)
+    int KA, NA, KB, NB;                        // first stage [*,KA] x [KA,NA]; second stage [*,KB = NA] x [KB,NB]
+    int KApad, KBpad;
+    int ycap;                                  // rows the LDS row store holds (32 + 2 hw)
+    float scaleA, scaleB;                      // fwd: 1/(1-p) of the dropout after layer 0 / layer 1; bwd: of Y1 / Y0
+    float dropA, dropB;
+    unsigned threshA, threshB;
+    uint64_t seedA, seedB;
+    const uint64_t* seed_dev;
+    int out_f32;                               // element type of `out` (0 = bf16)
+    unsigned long long* stamps;                // diagnostic builds only
+};
+
+// LDS carve (bytes), the same function on host and device
+struct FusedLds {
+    int strideA, strideB, ystride, ostride;    // element strides: S (first stage), S1 (second stage), row store, out tile
+    size_t off_s, off_y, off_well, off_wdeg, off_wmark, off_wslot, off_list, off_bias, total;
+};
+__host__ __device__ inline FusedLds fused_lds(int KApad, int KBpad, int NA, int NB, int ycap, int out_esize) {
+    FusedLds L;
+    L.strideA = lds_stride_dw(KApad / 2) * 2;
+    L.strideB = lds_stride_dw(KBpad / 2) * 2;
+    L.ystride = out_stride_dw(round_up(NA, 8) / 2) * 2;
+    L.ostride = out_stride_dw(round_up(NB, 16) * out_esize / 4) * 4 / out_esize;
+    const size_t sA = (size_t)FU_PASS * L.strideA * 2;
+    const size_t sB = (size_t)FU_ROWS * L.strideB * 2 + (size_t)FU_ROWS * L.ostride * out_esize;     // S1 + out tile alias the S region
+    L.off_s = 0;
+    L.off_y = round_up((int)(sA > sB ? sA : sB), 16);
+    L.off_well = L.off_y + round_up(ycap * L.ystride * 2, 16);
+    L.off_wdeg = L.off_well + (size_t)FU_WIN_MAX * 32;
+    L.off_wmark = L.off_wdeg + (size_t)FU_WIN_MAX * 4;
+    L.off_wslot = L.off_wmark + (size_t)FU_WIN_MAX * 4;
+    L.off_list = L.off_wslot + (size_t)FU_WIN_MAX * 4;
+    L.off_bias = L.off_list + (size_t)(FU_WIN_MAX + FU_ROWS) * 4;
+    L.total = L.off_bias + 2 * 256 * 4;
+    return L;
+}
+
+__device__ __forceinline__ void unpack_bf16x8(const uint4& a, bool live, float (&v)[8]) {
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    const uint4 u = live ? a : z;
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+    v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack_bf16x8(const float (&v)[8]) {
+    uint4 u;
+    u.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+    u.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+    u.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+    u.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+    return u;
+}
+
+// the tile's 32 rows of an LDS bf16 tile X (stride in elements) as a fragment image (include/gcnpt.h): row-contraction
+// operand of the weight gradient, 8 consecutive rows per lane, read transposed with ds_read_b64_tr_b16
+__device__ __forceinline__ void emit_frag_image(uint4* F, const bf16_t* X, int stride, int width, int wave, int lane, size_t nks, size_t blk) {
+    const int w_tiles = ceil_div(width, 16);
+    const int i = lane & 15, g = lane >> 4, q4 = i >> 2, pp = i & 3;
+    for (int t = wave; t < w_tiles; t += FU_WAVES) {
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4_t*)(X + (size_t)(8 * g + q4) * stride + 16 * t + 4 * pp));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4_t*)(X + (size_t)(8 * g + 4 + q4) * stride + 16 * t + 4 * pp));
+        uint4 u;
+        u.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
+        u.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
+        u.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
+        u.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
+        F[((size_t)t * nks + blk) * 64 + lane] = u;
+    }
+}
+
+// =====================================================================================================
+// forward: h1 = layer0(x), h2 = layer1(h1)
+// =====================================================================================================
+template <typename OT2, int KSA, int KSB>
+__global__ __launch_bounds__(FU_THREADS, 2) void fused_fwd_kernel(const FusedParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+    const FusedLds L = fused_lds(p.KApad, p.KBpad, p.NA, p.NB, p.ycap, (int)sizeof(OT2));
+    bf16_t* S = reinterpret_cast<bf16_t*>(fsm + L.off_s);                   // [FU_PASS][strideA] first-stage operand tile
+    bf16_t* S1 = reinterpret_cast<bf16_t*>(fsm + L.off_s);                  // [32][strideB] second-stage operand tile (after stage A)
+    OT2* O = reinterpret_cast<OT2*>(fsm + L.off_s + (size_t)FU_ROWS * L.strideB * 2);   // [32][ostride] out tile
+    bf16_t* Y = reinterpret_cast<bf16_t*>(fsm + L.off_y);                   // [ycap][ystride] layer-0 rows of R and H1
+    int* well = reinterpret_cast<int*>(fsm + L.off_well);                   // [win][8] ELL heads, columns ABSOLUTE
+    int* wdeg = reinterpret_cast<int*>(fsm + L.off_wdeg);                   // [win] degree (forward pattern)
+    int* wmark = reinterpret_cast<int*>(fsm + L.off_wmark);                 // [win] 1 = halo row
+    int* wslot = reinterpret_cast<int*>(fsm + L.off_wslot);                 // [win] slot of a window row in Y / list
+    int* list = reinterpret_cast<int*>(fsm + L.off_list);                   // [n_list] global row of each slot: R then H1 ascending
+    float* sbiasA = reinterpret_cast<float*>(fsm + L.off_bias);
+    float* sbiasB = sbiasA + 256;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r0 = blockIdx.x * FU_ROWS;
+    const int win_lo = max(0, r0 - p.hw), win_hi = min(p.N, r0 + FU_ROWS + p.hw), win = win_hi - win_lo;
+    const bf16_t* x = static_cast<const bf16_t*>(p.src);
+    const int ntA = ceil_div(p.NA, 16), ntB = ceil_div(p.NB, 16);
+    uint64_t seed_off = 0;
+    if (p.seed_dev) seed_off = *p.seed_dev;
+    GCNPT_STAMP_REAL(p.stamps);
+    GCNPT_STAMP(p.stamps, 0);
+
+    // ---- (1) everything that needs no other load: ELL window, degrees, the tile's own rows, biases, the first weight fragments
+    for (int i = tid; i < 2 * win; i += FU_THREADS) {
+        const int wi = i >> 1, half = i & 1;
+        const int r = win_lo + wi;
+        int4 v = reinterpret_cast<const int4*>(p.g_ell)[(size_t)r * 2 + half];
+        const int base = r / p.T * p.T;
+        if (half == 0) { v.y += base; v.z += base; v.w += base; }
+        else { v.x += base; v.y += base; v.z += base; v.w += base; }
+        reinterpret_cast<int4*>(well)[wi * 2 + half] = v;
+    }
+    for (int i = tid; i < win; i += FU_THREADS) {
+        wdeg[i] = p.d_ell[(size_t)(win_lo + i) * 8];
+        wmark[i] = 0;
+    }
+    if (tid < 256) {
+        sbiasA[tid] = p.bA[min(tid, p.NA - 1)];
+        sbiasB[tid] = p.bB[min(tid, p.NB - 1)];
+    }
+    const int kcA = min(lane * 8, p.KA - 8);            // this lane's 8 columns of a first-stage row (clamped; lanes past KA are zeroed)
+    const bool liveA = lane * 8 < p.KA;
+    // weight fragments, register resident: wave w owns output tiles w and w + 8; k-step ks of tile t is 1 KiB at (t KS + ks) * 64 + lane
+    uint4 wregA[KSA][FU_NTW], wregB[KSB][FU_NTW];
+    const uint4* wbaseA[FU_NTW];
+    const uint4* wbaseB[FU_NTW];
+#pragma unroll
+    for (int j = 0; j < FU_NTW; ++j) {
+        wbaseA[j] = p.wA + (size_t)min(j * FU_WAVES + wave, ntA - 1) * KSA * 64 + lane;
+        wbaseB[j] = p.wB + (size_t)min(j * FU_WAVES + wave, ntB - 1) * KSB * 64 + lane;
+    }
+    constexpr int KS_EARLY = KSA / 4;
+#pragma unroll
+    for (int ks = 0; ks < KS_EARLY; ++ks)
+#pragma unroll
+        for (int j = 0; j < FU_NTW; ++j) wregA[ks][j] = wbaseA[j][ks * 64];
+    __syncthreads();
+    GCNPT_STAMP(p.stamps, 1);
+
+    // ---- (2) row gather helpers: a wave takes one row at a time, a lane 8 of its columns
+    struct Row { uint4 own, nb[FU_NBU]; int cnt, wi; };
+    auto row_meta = [&](int grow, int& cnt, int& wi) {
+        const bool valid = grow < p.N;
+        wi = valid ? grow - win_lo : 0;
+        cnt = valid ? __builtin_amdgcn_readfirstlane(well[wi * 8]) : 0;
+    };
+    auto issue_nb = [&](int grow, Row& R) {
+        row_meta(grow, R.cnt, R.wi);
+        const int n_ell = min(R.cnt, FU_NB_INLINE);
+        R.own = *reinterpret_cast<const uint4*>(x + (size_t)min(grow, p.N - 1) * p.KA + kcA);
+#pragma unroll
+        for (int e = 0; e < FU_NBU; ++e) {
+            const int c = __builtin_amdgcn_readfirstlane(well[R.wi * 8 + 1 + e]);
+            const size_t rr = (size_t)((e < n_ell) ? c : min(grow, p.N - 1));      // no e-th entry: the row itself (same lines), dropped below
+            R.nb[e] = *reinterpret_cast<const uint4*>(x + rr * p.KA + kcA);
+        }
+    };
+    // S[slot_in_pass] = own + sum of the row's entries in CSR order (gcn.py:269 + the explicit W(h) term of gcn.py:271)
+    auto finish_row = [&](int grow, const Row& R, bf16_t* dst) {
+        float acc[8];
+        unpack_bf16x8(R.own, liveA && grow < p.N, acc);
+        const int n_ell = min(R.cnt, FU_NB_INLINE);
+#pragma unroll
+        for (int e = 0; e < FU_NBU; ++e) {
+            float v[8];
+            unpack_bf16x8(R.nb[e], liveA && e < n_ell, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += v[j];
+        }
+        for (int e = FU_NBU; e < n_ell; ++e) {                               // rows with 5..7 entries
+            const int c = __builtin_amdgcn_readfirstlane(well[R.wi * 8 + 1 + e]);
+            float v[8];
+            unpack_bf16x8(*reinterpret_cast<const uint4*>(x + (size_t)c * p.KA + kcA), liveA, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += v[j];
+        }
+        if (R.cnt > FU_NB_INLINE) {                                          // > 7 entries: the rest from the CSR
+            const int b = grow / p.T, base = b * p.T;
+            const int beg = p.g_row_ptr[(size_t)b * (p.T + 1) + (grow - base)];
+            for (int e = FU_NB_INLINE; e < R.cnt; ++e) {
+                const int c = base + p.g_col_idx[beg + e];
+                float v[8];
+                unpack_bf16x8(*reinterpret_cast<const uint4*>(x + (size_t)c * p.KA + kcA), liveA, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += v[j];
+            }
+        }
+        if (lane * 8 < p.KApad) *reinterpret_cast<uint4*>(dst + lane * 8) = pack_bf16x8(acc);
+    };
+
+    // ---- (3) the halo: mark every entry of the tile's rows that lies outside the tile
+    if (tid < FU_ROWS * 8) {
+        const int i = tid >> 3, e = tid & 7;
+        const int grow = r0 + i;
+        if (grow < p.N) {
+            const int wi = grow - win_lo, cnt = well[wi * 8];
+            if (e < FU_NB_INLINE) {
+                if (e < cnt) {
+                    const int c = well[wi * 8 + 1 + e];
+                    if (c < r0 || c >= r0 + FU_ROWS) wmark[c - win_lo] = 1;
+                }
+            } else if (cnt > FU_NB_INLINE) {
+                const int b = grow / p.T, base = b * p.T;
+                const int beg = p.g_row_ptr[(size_t)b * (p.T + 1) + (grow - base)];
+                for (int k = FU_NB_INLINE; k < cnt; ++k) {
+                    const int c = base + p.g_col_idx[beg + k];
+                    if (c < r0 || c >= r0 + FU_ROWS) wmark[c - win_lo] = 1;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    GCNPT_STAMP(p.stamps, 2);
+    // every wave builds the same tables (same values to the same places) and reads them back after its own writes: no barrier
+    int n_list = FU_ROWS;
+    for (int c0 = 0; c0 < win; c0 += 64) {
+        const int idx = c0 + lane;
+        const bool m = idx < win && wmark[idx] != 0;
+        const unsigned long long mask = __ballot(m);
+        if (m) {
+            const int slot = n_list + __popcll(mask & ((1ull << lane) - 1ull));
+            wslot[idx] = slot;
+            list[slot] = win_lo + idx;
+        }
+        n_list += __popcll(mask);
+    }
+    if (lane < FU_ROWS) {
+        list[lane] = r0 + lane;
+        if (r0 + lane < win_hi) wslot[r0 + lane - win_lo] = lane;
+    }
+    wave_lds_fence();
+    GCNPT_STAMP(p.stamps, 3);
+
+    // ---- (4) stage A = layer 0 on R and H1, 64 list rows per pass.  Pass 0 (the tile's own rows + the first 32 halo rows: all
+    //          there is for pruned trees) runs on the register-resident weights; further passes (dense adjacencies) stream them.
+    const int n_pass = ceil_div(n_list, FU_PASS);
+    const int arow = lane & 15, kgrp = lane >> 4;
+    auto gather_pass = [&](int slot0, bool first) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            // 4 list rows per wave with all their loads (own row + first FU_NBU entries) in flight together
+            Row rr[4]; int grow[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int slot = slot0 + FU_ROWS * half + wave + 8 * u;
+                grow[u] = slot < n_list ? __builtin_amdgcn_readfirstlane(list[slot]) : p.N;
+                issue_nb(grow[u], rr[u]);
+            }
+            if (first && half == 1) {                                                    // behind the gather loads: the queue retires in order
+#pragma unroll
+                for (int ks = KS_EARLY; ks < KSA; ++ks)
+#pragma unroll
+                    for (int j = 0; j < FU_NTW; ++j) wregA[ks][j] = wbaseA[j][ks * 64];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) finish_row(grow[u], rr[u], S + (size_t)(FU_ROWS * half + wave + 8 * u) * L.strideA);
+            __builtin_amdgcn_sched_barrier(0);                                           // keep the next batch's loads behind this one's sums (registers)
+        }
+    };
+    // epilogue of layer 0 -> Y[slot] (bf16): +2b, /(deg+1), ReLU, dropout (gcn.py:270-271, 390-393)
+    auto epilogue_a = [&](int slot0, int n_mt, const f32x4_t (&acc)[4][FU_NTW]) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            if (mt >= n_mt) continue;
+            const int slot = slot0 + 16 * mt + arow;
+            const int grow = slot < n_list ? list[slot] : p.N;
+            const bool valid = grow < p.N;
+            const float den = valid ? (float)(wdeg[grow - win_lo] + 1) : 1.0f;
+            const float inv = 1.0f / den;
+#pragma unroll
+            for (int j = 0; j < FU_NTW; ++j) {
+                const int tl = wave + j * FU_WAVES;
+                if (tl >= ntA) continue;
+                const int col0 = tl * 16 + kgrp * 4;
+                const float4 bv = *reinterpret_cast<const float4*>(sbiasA + col0);
+                const float bq[4] = {bv.x, bv.y, bv.z, bv.w};
+                float v[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float t = div_by(acc[mt][j][g] + 2.0f * bq[g], den, inv);
+                    v[g] = t > 0.0f ? t : 0.0f;
+                }
+                if (p.dropA > 0.0f) {
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const unsigned dh = drop_hash(p.seedA + seed_off, (unsigned)grow, (unsigned)(col0 >> 1) + h2);
+                        v[2 * h2] = drop_keep(dh, 0u, p.threshA) ? v[2 * h2] * p.scaleA : 0.0f;
+                        v[2 * h2 + 1] = drop_keep(dh, 1u, p.threshA) ? v[2 * h2 + 1] * p.scaleA : 0.0f;
+                    }
+                }
+                if (slot < n_list && col0 < L.ystride) {
+                    uint2 pk;
+                    pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                    pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                    *reinterpret_cast<uint2*>(Y + (size_t)slot * L.ystride + col0) = pk;
+                }
+            }
+        }
+    };
+    {
+        gather_pass(0, true);
+        GCNPT_STAMP(p.stamps, 4);
+        __syncthreads();
+        GCNPT_STAMP(p.stamps, 5);
+        if (p.fragA) emit_frag_image(p.fragA, S, L.strideA, p.KA, wave, lane, gridDim.x, blockIdx.x);
+        GCNPT_STAMP(p.stamps, 6);
+        // MFMA with swapped operands (weights as A): a lane ends up with 4 consecutive output columns of one row
+        const int n_mt = ceil_div(min(FU_PASS, n_list), 16);
+        f32x4_t acc[4][FU_NTW];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int j = 0; j < FU_NTW; ++j) acc[mt][j] = (f32x4_t){0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < KSA; ++ks) {
+            uint4 a[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                if (mt < n_mt) a[mt] = *reinterpret_cast<const uint4*>(S + (size_t)(arow + 16 * mt) * L.strideA + ks * 32 + kgrp * 8);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                if (mt < n_mt)
+#pragma unroll
+                    for (int j = 0; j < FU_NTW; ++j)
+                        acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wregA[ks][j]),
+                                                                              __builtin_bit_cast(bf16x8_t, a[mt]), acc[mt][j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSB; ++ks)                                     // layer 1's weights travel during the epilogue
+#pragma unroll
+            for (int j = 0; j < FU_NTW; ++j) wregB[ks][j] = wbaseB[j][ks * 64];
+        GCNPT_STAMP(p.stamps, 7);
+        epilogue_a(0, n_mt, acc);
+        __syncthreads();
+        GCNPT_STAMP(p.stamps, 8);
+        {                                                                    // the tile's own layer-0 rows leave for the backward pass
+            bf16_t* h1 = static_cast<bf16_t*>(p.mid);
+            const int pieces = p.NA / 8;
+            const int row = tid >> 4, r = r0 + row;
+            if (r < p.N)
+                for (int pc = tid & 15; pc < pieces; pc += 16)
+                    *reinterpret_cast<uint4*>(h1 + (size_t)r * p.NA + pc * 8) = *reinterpret_cast<const uint4*>(Y + (size_t)row * L.ystride + pc * 8);
+        }
+    }
+#pragma unroll 1
+    for (int pass = 1; pass < n_pass; ++pass) {
+        const int slot0 = pass * FU_PASS;
+        gather_pass(slot0, false);
+        __syncthreads();
+        const int n_mt = ceil_div(min(FU_PASS, n_list - slot0), 16);
+        f32x4_t acc[4][FU_NTW];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int j = 0; j < FU_NTW; ++j) acc[mt][j] = (f32x4_t){0, 0, 0, 0};
+#pragma unroll 1
+        for (int ks = 0; ks < KSA; ++ks) {
+            uint4 wk[FU_NTW];
+#pragma unroll
+            for (int j = 0; j < FU_NTW; ++j) wk[j] = wbaseA[j][ks * 64];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                if (mt >= n_mt) continue;
+                const uint4 a = *reinterpret_cast<const uint4*>(S + (size_t)(arow + 16 * mt) * L.strideA + ks * 32 + kgrp * 8);
+#pragma unroll
+                for (int j = 0; j < FU_NTW; ++j)
+                    acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wk[j]), __builtin_bit_cast(bf16x8_t, a), acc[mt][j], 0, 0, 0);
+            }
+        }
+        epilogue_a(slot0, n_mt, acc);
+        __syncthreads();
+    }
+
+    GCNPT_STAMP(p.stamps, 9);
+    // ---- (5) stage B = layer 1 on R; every row it gathers is in Y
+    {
+        const bool liveB = lane * 8 < p.KB;
+        const int kcB = min(lane * 8, p.KB - 8);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = wave + 8 * u, grow = r0 + i;
+            int cnt, wi;
+            row_meta(grow, cnt, wi);
+            float acc[8];
+            unpack_bf16x8(*reinterpret_cast<const uint4*>(Y + (size_t)i * L.ystride + kcB), liveB && grow < p.N, acc);
+            const int n_ell = min(cnt, FU_NB_INLINE);
+            uint4 nb[FU_NBU];
+#pragma unroll
+            for (int e = 0; e < FU_NBU; ++e) {
+                const int c = __builtin_amdgcn_readfirstlane(well[wi * 8 + 1 + e]);
+                const int s = (e < n_ell) ? __builtin_amdgcn_readfirstlane(wslot[c - win_lo]) : i;
+                nb[e] = *reinterpret_cast<const uint4*>(Y + (size_t)s * L.ystride + kcB);
+            }
+#pragma unroll
+            for (int e = 0; e < FU_NBU; ++e) {
+                float v[8];
+                unpack_bf16x8(nb[e], liveB && e < n_ell, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += v[j];
+            }
+            for (int e = FU_NBU; e < n_ell; ++e) {
+                const int c = __builtin_amdgcn_readfirstlane(well[wi * 8 + 1 + e]);
+                const int s = __builtin_amdgcn_readfirstlane(wslot[c - win_lo]);
+                float v[8];
+                unpack_bf16x8(*reinterpret_cast<const uint4*>(Y + (size_t)s * L.ystride + kcB), liveB, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += v[j];
+            }
+            if (cnt > FU_NB_INLINE) {
+                const int b = grow / p.T, base = b * p.T;
+                const int beg = p.g_row_ptr[(size_t)b * (p.T + 1) + (grow - base)];
+                for (int e = FU_NB_INLINE; e < cnt; ++e) {
+                    const int c = base + p.g_col_idx[beg + e];
+                    const int s = wslot[c - win_lo];
+                    float v[8];
+                    unpack_bf16x8(*reinterpret_cast<const uint4*>(Y + (size_t)s * L.ystride + kcB), liveB, v);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += v[j];
+                }
+            }
+            if (lane * 8 < p.KBpad) *reinterpret_cast<uint4*>(S1 + (size_t)i * L.strideB + lane * 8) = pack_bf16x8(acc);
+        }
+    }
+    __syncthreads();
+    GCNPT_STAMP(p.stamps, 10);
+    if (p.fragB) emit_frag_image(p.fragB, S1, L.strideB, p.KB, wave, lane, gridDim.x, blockIdx.x);
+    GCNPT_STAMP(p.stamps, 11);
+    {
+        f32x4_t acc[2][FU_NTW];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int j = 0; j < FU_NTW; ++j) acc[mt][j] = (f32x4_t){0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < KSB; ++ks) {
+            const uint4 a0 = *reinterpret_cast<const uint4*>(S1 + (size_t)arow * L.strideB + ks * 32 + kgrp * 8);
+            const uint4 a1 = *reinterpret_cast<const uint4*>(S1 + (size_t)(arow + 16) * L.strideB + ks * 32 + kgrp * 8);
+#pragma unroll
+            for (int j = 0; j < FU_NTW; ++j) {
+                const bf16x8_t bq = __builtin_bit_cast(bf16x8_t, wregB[ks][j]);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq, __builtin_bit_cast(bf16x8_t, a0), acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq, __builtin_bit_cast(bf16x8_t, a1), acc[1][j], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int row = 16 * mt + arow, grow = r0 + row;
+            const float den = grow < p.N ? (float)(wdeg[grow - win_lo] + 1) : 1.0f;
+            const float inv = 1.0f / den;
+#pragma unroll
+            for (int j = 0; j < FU_NTW; ++j) {
+                const int tl = wave + j * FU_WAVES;
+                if (tl >= ntB) continue;
+                const int col0 = tl * 16 + kgrp * 4;
+                const float4 bv = *reinterpret_cast<const float4*>(sbiasB + col0);
+                const float bq[4] = {bv.x, bv.y, bv.z, bv.w};
+                float v[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float t = div_by(acc[mt][j][g] + 2.0f * bq[g], den, inv);
+                    v[g] = t > 0.0f ? t : 0.0f;
+                }
+                if (p.dropB > 0.0f) {
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const unsigned dh = drop_hash(p.seedB + seed_off, (unsigned)grow, (unsigned)(col0 >> 1) + h2);
+                        v[2 * h2] = drop_keep(dh, 0u, p.threshB) ? v[2 * h2] * p.scaleB : 0.0f;
+                        v[2 * h2 + 1] = drop_keep(dh, 1u, p.threshB) ? v[2 * h2 + 1] * p.scaleB : 0.0f;
+                    }
+                }
+                OT2* dst = O + (size_t)row * L.ostride + col0;
+                if constexpr (sizeof(OT2) == 2) {
+                    uint2 pk;
+                    pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                    pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                    *reinterpret_cast<uint2*>(dst) = pk;
+                } else {
+                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    GCNPT_STAMP(p.stamps, 12);
+    {
+        OT2* out = static_cast<OT2*>(p.out);
+        constexpr int PER = 16 / (int)sizeof(OT2);
+        const int pieces = p.NB / PER;
+        const int row = tid >> 4, r = r0 + row;
+        if (r < p.N)
+            for (int pc = tid & 15; pc < pieces; pc += 16)
+                *reinterpret_cast<uint4*>(out + (size_t)r * p.NB + pc * PER) = *reinterpret_cast<const uint4*>(O + (size_t)row * L.ostride + pc * PER);
+    }
+    GCNPT_STAMP(p.stamps, 13);
+}
+
+}  // namespace gcnpt
+
+// =====================================================================================================
+// host side
+// =====================================================================================================
+using namespace gcnpt;
+
+// Whether the two-layer launch handles a stack: two layers, bf16 operands and bf16 rows in between, widths the register-resident
+// weight fragments cover, and a sentence length whose halo window fits the LDS row store.  Otherwise: one launch per layer.
+static bool fused_shape_ok(int T, int K0, int H0, int H1, int esz_out, size_t* lds_out) {
+    if (T < 1 || K0 % 8 || H0 % 8 || H1 % 8) return false;
+    const int hw = T - 1;
+    if (FU_ROWS + 2 * hw > FU_WIN_MAX) return false;
+    const int KApad = round_up(K0, 32), KBpad = round_up(H0, 32);
+    // the instantiated k-step pairs: C2 (360 -> 200), C3 (400 -> 200), C1 / equal widths (200 -> 200), 300 -> 300
+    const int ksA = KApad / 32, ksB = KBpad / 32;
+    const bool have = (ksA == 12 && ksB == 7) || (ksA == 13 && ksB == 7) || (ksA == 7 && ksB == 7) || (ksA == 10 && ksB == 7);
+    if (!have || ceil_div(H0, 16) > FU_WAVES * FU_NTW || ceil_div(H1, 16) > FU_WAVES * FU_NTW) return false;
+    const FusedLds L = fused_lds(KApad, KBpad, H0, H1, FU_ROWS + 2 * hw, esz_out);
+    if (L.total > 160 * 1024) return false;
+    if (lds_out) *lds_out = L.total;
+    return true;
+}
+
+extern "C" int gcnpt_fused2_supported(int T, int Din, int H0, int H1, int out_dtype, int compute_dtype) {
+    if (compute_dtype != GCNPT_BF16 || !dtype_ok(out_dtype)) return 0;
+    return fused_shape_ok(T, Din, H0, H1, (int)esize(out_dtype), nullptr) ? 1 : 0;
+}
+
+template <typename OT2, int KSA, int KSB>
+static int launch_fused_fwd(hipStream_t s, const FusedParams& p, size_t lds) {
+    auto kern = fused_fwd_kernel<OT2, KSA, KSB>;
+    GCNPT_LDS_ATTR_ONCE(kern, 160 * 1024);
+    hipLaunchKernelGGL(kern, dim3(ceil_div(p.N, FU_ROWS)), dim3(FU_THREADS), lds, s, p);
+    GCNPT_HIP_CHECK(hipGetLastError());
+    return GCNPT_OK;
+}
+
+template <typename OT2>
+static int dispatch_fused_fwd(hipStream_t s, const FusedParams& p, size_t lds) {
+    const int ksA = p.KApad / 32;
+    if (ksA == 12) return launch_fused_fwd<OT2, 12, 7>(s, p, lds);
+    if (ksA == 13) return launch_fused_fwd<OT2, 13, 7>(s, p, lds);
+    if (ksA == 10) return launch_fused_fwd<OT2, 10, 7>(s, p, lds);
+    return launch_fused_fwd<OT2, 7, 7>(s, p, lds);
+}
+
+extern "C" int gcnpt_fused2_fwd(void* stream, const void* x, const void* const* w_fwd, const float* const* bias, const int32_t* row_ptr,
+                                const int32_t* col_idx, const int32_t* ell, const int32_t* deg_ell, int B, int T, int Din, const int* H,
+                                void* h1, void* h2, int out_dtype, const float* drop_p, const uint64_t* seed, void* const* s_frag,
+                                const uint64_t* seed_dev) {
+    GCNPT_REQUIRE(x && w_fwd && bias && row_ptr && col_idx && ell && H && h1 && h2 && drop_p && seed, "fused2_fwd: null pointer");
+    GCNPT_REQUIRE(w_fwd[0] && w_fwd[1] && bias[0] && bias[1], "fused2_fwd: null pointer (per layer)");
+    GCNPT_REQUIRE(B > 0 && T > 0 && Din > 0 && H[0] > 0 && H[1] > 0, "fused2_fwd: sizes must be positive");
+    GCNPT_REQUIRE(dtype_ok(out_dtype), "fused2_fwd: bad dtype");
+    for (int l = 0; l < 2; ++l) GCNPT_REQUIRE(drop_p[l] >= 0.0f && drop_p[l] < 1.0f, "fused2_fwd: drop_p=%f outside [0,1)", (double)drop_p[l]);
+    if ((long long)B * T > 0x7fffffffLL / 2) return fail(GCNPT_E_UNSUPPORTED, "fused2_fwd: B*T too large");
+    size_t lds = 0;
+    if (!fused_shape_ok(T, Din, H[0], H[1], (int)esize(out_dtype), &lds) || !aligned16(x) || !aligned16(h1) || !aligned16(h2))
+        return fail(GCNPT_E_UNSUPPORTED, "fused2_fwd: shape T=%d %d->%d->%d is outside the two-layer kernel (see gcnpt_fused2_supported)", T, Din, H[0], H[1]);
+    FusedParams p{};
+    p.src = x; p.mid = h1; p.out = h2;
+    p.wA = static_cast<const uint4*>(w_fwd[0]); p.wB = static_cast<const uint4*>(w_fwd[1]);
+    p.bA = bias[0]; p.bB = bias[1];
+    p.g_row_ptr = row_ptr; p.g_col_idx = col_idx; p.g_ell = ell; p.d_ell = deg_ell ? deg_ell : ell;
+    p.fragA = s_frag ? static_cast<uint4*>(s_frag[0]) : nullptr;
+    p.fragB = s_frag ? static_cast<uint4*>(s_frag[1]) : nullptr;
+    p.N = B * T; p.T = T; p.hw = T - 1;
+    p.KA = Din; p.NA = H[0]; p.KB = H[0]; p.NB = H[1];
+    p.KApad = round_up(Din, 32); p.KBpad = round_up(H[0], 32);
+    p.ycap = FU_ROWS + 2 * p.hw;
+    p.dropA = drop_p[0]; p.dropB = drop_p[1];
+    p.scaleA = drop_p[0] > 0.0f ? 1.0f / (1.0f - drop_p[0]) : 1.0f;
+    p.scaleB = drop_p[1] > 0.0f ? 1.0f / (1.0f - drop_p[1]) : 1.0f;
+    p.threshA = (unsigned)((double)drop_p[0] * 65536.0); p.threshB = (unsigned)((double)drop_p[1] * 65536.0);
+    p.seedA = seed[0]; p.seedB = seed[1]; p.seed_dev = seed_dev;
+    p.out_f32 = out_dtype == GCNPT_F32;
+    p.stamps = static_cast<unsigned long long*>(g_debug_stamps);
+    hipStream_t s = (hipStream_t)stream;
+    if (out_dtype == GCNPT_F32) return dispatch_fused_fwd<float>(s, p, lds);
+    return dispatch_fused_fwd<bf16_t>(s, p, lds);
+}

@@ -1,6 +1,7 @@
 // Shared host/device helpers for libgcnpt.so (gfx950 only; wave = 64 lanes).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -10,8 +11,14 @@ namespace gcnpt {
 
 // ---- error reporting across the C boundary (no exceptions leave the library) -------------------
 char* err_buf();   // thread-local, defined in capi.hip
+#ifdef GCNPT_STAMPS
 extern int g_debug_knob;      // diagnostic builds: timing-experiment switches (results become wrong)
 extern void* g_debug_stamps;   // diagnostic builds (-DGCNPT_STAMPS): device buffer for in-kernel time stamps
+#else
+// the shipped library has no mutable global state (include/gcnpt.h): the diagnostic hooks are compile-time constants here
+constexpr int g_debug_knob = 0;
+constexpr void* g_debug_stamps = nullptr;
+#endif
 
 #ifdef GCNPT_STAMPS
 // one stamp = shader-clock counter of wave 0 / lane 0 of the workgroup; slot 15 = 100 MHz real time at entry
@@ -42,6 +49,16 @@ int fail(int code, const char* fmt, ...);
         hipError_t _e = (expr);                                                                \
         if (_e != hipSuccess)                                                                  \
             return gcnpt::fail(GCNPT_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));    \
+    } while (0)
+
+// hipFuncSetAttribute(max dynamic LDS) exactly once per kernel instantiation, whichever thread comes first (std::call_once);
+// it is not a stream operation, so it must not recur inside a graph capture either (the first launch is an eager warm-up)
+#define GCNPT_LDS_ATTR_ONCE(kern, bytes)                                                                              \
+    do {                                                                                                              \
+        static std::once_flag _once;                                                                                  \
+        static hipError_t _rc = hipSuccess;                                                                           \
+        std::call_once(_once, [&] { _rc = hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); }); \
+        GCNPT_HIP_CHECK(_rc);                                                                                         \
     } while (0)
 
 #define GCNPT_REQUIRE(cond, ...)                                      \

@@ -570,11 +570,7 @@ static int launch_rowtile_cfg(hipStream_t s, const RowTileParams& p) {
                        (size_t)ROWS * 13 * sizeof(int) + (size_t)RT_THREADS * sizeof(float);
     if (lds > 160 * 1024) return fail(GCNPT_E_UNSUPPORTED, "layer: K=%d needs %zu B of LDS per workgroup", p.K, lds);
     auto kern = rowtile_kernel<CT, IT, OT, BWD, VEC, NTW, KSMAX, DZIN>;
-    static bool big_lds = false;                 // once per instantiation, to the CU's full 160 KB: not a stream operation, so it
-    if (lds > 64 * 1024 && !big_lds) {           // must not recur inside a graph capture (the first launch is an eager warm-up)
-        GCNPT_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        big_lds = true;
-    }
+    GCNPT_LDS_ATTR_ONCE(kern, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3(ceil_div(p.N, ROWS)), dim3(RT_THREADS), lds, s, p);
     GCNPT_HIP_CHECK(hipGetLastError());
     return GCNPT_OK;

@@ -514,11 +514,7 @@ template <typename IT, typename OT, bool VECX>
 static int launch_stack_fwd(hipStream_t s, const StackFwdParams& p) {
     const size_t lds = stack_fwd_lds(p.Din, p.H);
     auto kern = stack_fwd_kernel<IT, OT, VECX>;
-    static bool big_lds = false;                 // once per instantiation (not a stream operation: keep it out of graph captures)
-    if (!big_lds) {
-        GCNPT_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        big_lds = true;
-    }
+    GCNPT_LDS_ATTR_ONCE(kern, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3(p.B), dim3(ST_THREADS), lds, s, p);
     GCNPT_HIP_CHECK(hipGetLastError());
     return GCNPT_OK;
@@ -565,11 +561,7 @@ template <typename GT, typename XT, bool VECG>
 static int launch_stack_bwd(hipStream_t s, const StackBwdParams& p) {
     const size_t lds = stack_bwd_lds(p.H);
     auto kern = stack_bwd_kernel<GT, XT, VECG>;
-    static bool big_lds = false;
-    if (!big_lds) {
-        GCNPT_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        big_lds = true;
-    }
+    GCNPT_LDS_ATTR_ONCE(kern, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3(p.B), dim3(ST_THREADS), lds, s, p);
     GCNPT_HIP_CHECK(hipGetLastError());
     return GCNPT_OK;

@@ -667,11 +667,8 @@ extern "C" int gcnpt_prune_to_csr(void* stream, const int64_t* head, const int64
     const size_t lds = sizeof(int) * ((size_t)7 * T + 4);
     if (T > PRUNE_MAX_T) return fail(GCNPT_E_UNSUPPORTED, "prune_to_csr: T=%d exceeds the %d tokens a sentence may have", T, PRUNE_MAX_T);
     hipStream_t s = (hipStream_t)stream;
-    static bool big_lds = false;                 // sentences beyond ~2300 tokens need more than the default 64 KB of LDS (7 words per token)
-    if (lds > 64 * 1024 && !big_lds) {
-        GCNPT_HIP_CHECK(hipFuncSetAttribute((const void*)prune_to_csr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));   // minus its few static words
-        big_lds = true;
-    }
+    // sentences beyond ~2300 tokens need more than the default 64 KB of LDS (7 words per token); minus the kernel's few static words
+    if (lds > 64 * 1024) GCNPT_LDS_ATTR_ONCE(prune_to_csr_kernel, 160 * 1024 - 256);
     if ((long long)B * T > PRUNE_SCAN_MAX) GCNPT_HIP_CHECK(hipMemsetAsync(status + B, 0, sizeof(int32_t), s));   // big batches: atomicMax per sentence
     hipLaunchKernelGGL(prune_to_csr_kernel, dim3(B), dim3(PRUNE_THREADS), lds, s, head, subj_pos, obj_pos, deprel,
                        pad_mask, len, B, T, prune_k, cap, row_ptr, col_idx, label, rowT_ptr, colT_idx, ell, ellT, pool_mask, status,

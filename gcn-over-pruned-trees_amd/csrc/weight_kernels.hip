@@ -310,11 +310,7 @@ static int plan_weight_grad(WeightGradParams& p, const void* z_frag, const void*
 template <typename CT, int NW>
 static int launch_weight_grad_cfg(hipStream_t s, const WeightGradMulti& mp) {
     const size_t lds = (sizeof(f32x4_t) * WG_MT * WG_NT * WAVE + sizeof(float) * WG_MT * 16) * NW;      // 49 / 98 KiB
-    static bool attr_set = false;                       // once per instantiation (and so never first inside a stream capture replay)
-    if (lds > 64 * 1024 && !attr_set) {
-        GCNPT_HIP_CHECK(hipFuncSetAttribute((const void*)weight_grad_kernel<CT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    GCNPT_LDS_ATTR_ONCE((weight_grad_kernel<CT, NW>), 160 * 1024);
     hipLaunchKernelGGL((weight_grad_kernel<CT, NW>), dim3(mp.first[mp.n]), dim3(NW * WAVE), lds, s, mp);
     GCNPT_HIP_CHECK(hipGetLastError());
     return GCNPT_OK;

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define GCNPT_ABI_VERSION 3
+#define GCNPT_ABI_VERSION 4
 
 /* element types of activation / gradient buffers and of the MFMA operands */
 #define GCNPT_F32 0
@@ -186,6 +186,22 @@ int gcnpt_layers_bwd(void* stream, int n_layers, const void* gy, const void* con
                      const int32_t* ellT, int B, int T, const int* Din, const int* H, void* const* dh, const int* dh_dtype,
                      int compute_dtype, const float* scale, void* const* z_frag, const void* const* s_frag, float* const* dW,
                      float* const* db);
+
+/* ---- optional: two stacked layers' FORWARD in ONE launch without any inter-workgroup wait (csrc/fused_kernels.hip) -----------
+ * The layer loop of model/gcn.py:266-393 for num_layers = 2 (the reference's default, train.py:57) without the kernel boundary
+ * between the layers: a workgroup owns 32 token rows and computes layer 0 also for the neighbours of its rows that other
+ * workgroups own (they lie within T-1 rows: the adjacency is block diagonal, model/tree.py:167-204), so layer 1 gathers from
+ * its own LDS.  bf16 MFMA operands and bf16 rows between the layers, fp32 accumulation; every output is bit-identical to two
+ * gcnpt_layer_fwd calls.  MEASURED SLOWER than two launches at B=50, T=100 (32 us against 18 us, DESIGN.md section 5: the halo is
+ * ~50 % extra first-layer rows and the gather/epilogue phases are VALU-bound), so gcnpt_layers_fwd does NOT use it; it stays as
+ * a tested opt-in.  gcnpt_fused2_supported: 1 when the shape fits (widths multiples of 8, Din/32 and H0/32 k-steps among the
+ * instantiated pairs, 32 + 2 (T-1) <= 256 window rows, LDS).
+ *   gcnpt_fused2_fwd: x [B*T,Din] bf16 -> h1 [B*T,H[0]] bf16 (layer 0's output, dropout drop_p[0] applied) and h2 [B*T,H[1]] of
+ *     out_dtype; w_fwd / bias / drop_p / seed / s_frag: host arrays of 2 entries, meaning as in gcnpt_layer_fwd. */
+int gcnpt_fused2_supported(int T, int Din, int H0, int H1, int out_dtype, int compute_dtype);
+int gcnpt_fused2_fwd(void* stream, const void* x, const void* const* w_fwd, const float* const* bias, const int32_t* row_ptr,
+                     const int32_t* col_idx, const int32_t* ell, const int32_t* deg_ell, int B, int T, int Din, const int* H, void* h1,
+                     void* h2, int out_dtype, const float* drop_p, const uint64_t* seed, void* const* s_frag, const uint64_t* seed_dev);
 
 /* ---- optional: the whole L-layer stack in ONE launch per direction (sentence-resident kernels) ---------------
  * A workgroup owns a whole sentence (T <= 112 rows) and runs every layer with the inter-layer activations in LDS;

@@ -124,6 +124,24 @@ __device__ __forceinline__ void issue8(const IT* base, size_t row, int K, int k0
     }
 }
 
+// The same for rows that are only 8-byte (bf16) / 16-byte (f32) aligned: K % 4 == 0 (hidden = 300 is the case in point).  Two half
+// loads, the upper one clamped to the row's last 4 columns: in the row's last chunk it then returns real, finite values of the row
+// in the 4 slots past its end, which is harmless -- those columns meet zero weights (the packed images are zero padded past K) and
+// fall outside what the weight gradient stores.  k0 <= K - 4.
+template <typename IT>
+__device__ __forceinline__ void issue8_half(const IT* base, size_t row, int K, int k0, raw8<IT>& r) {
+    const IT* p = base + row * (size_t)K;
+    const int k1 = min(k0 + 4, K - 4);
+    if constexpr (sizeof(IT) == 4) {
+        r.a = *reinterpret_cast<const uint4*>(p + k0);
+        r.b = *reinterpret_cast<const uint4*>(p + k1);
+    } else {
+        const uint2 lo = *reinterpret_cast<const uint2*>(p + k0);
+        const uint2 hi = *reinterpret_cast<const uint2*>(p + k1);
+        r.a = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+}
+
 // the 8 floats of a raw8, all zero when !live
 template <typename IT>
 __device__ __forceinline__ void unpack8(const raw8<IT>& r, bool live, float (&v)[8]) {

@@ -44,7 +44,7 @@ struct RowTileParams {
     int zero_a_n, zero_b_n;
     int N, T, K, NOUT, Kpad;
     unsigned chunk_magic;   // ceil(2^32 / (Kpad / 8)): division by the chunks per row as a multiply-high
-    int vec_in, vec_out;    // rows may be read / written 16 bytes at a time (vec_in selects the VEC instantiation)
+    int vec_in, vec_out;    // vec_in: 8 / 4 / 0 elements per row load (selects the VEC instantiation); vec_out: 16 / 8 / 0 bytes per row store
     float scale;            // bwd: 1/(1-p) of the dropout applied to Y; fwd: 1/(1-drop_p)
     float drop_p;           // fwd
     unsigned drop_thresh16;
@@ -58,7 +58,7 @@ struct RowTileParams {
 
 // DZIN (bwd only): `src` already holds dZ (the layer above wrote it, see relu_src), so the row loader is the forward's plain
 // gather -- one load per neighbour instead of three (dY, Y, degree).
-template <typename CT, typename IT, typename OT, bool BWD, bool VEC, int NTW, int KSMAX, bool DZIN = false>
+template <typename CT, typename IT, typename OT, bool BWD, int VEC, int NTW, int KSMAX, bool DZIN = false>
 __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTileParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     static_assert(BWD || !DZIN, "DZIN is a backward mode");
@@ -115,7 +115,13 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
     const int nchunk = p.Kpad / 8;
     auto div_chunk = [&](int x) { return (int)__umulhi((unsigned)x, p.chunk_magic); };    // x / nchunk, exact for x * nchunk < 2^32
     const int n_items = ROWS * nchunk;
-    const int kmax8 = VEC ? p.K - 8 : p.K - 1;
+    // VEC: 8 = rows read 16 bytes at a time (K % 8 == 0), 4 = in 8-byte (bf16) / 16-byte (f32) halves (K % 4 == 0), 0 = element loads
+    const int kmax8 = VEC == 8 ? p.K - 8 : (VEC == 4 ? p.K - 4 : p.K - 1);
+    auto ld8 = [&](const IT* base, size_t row, int k0c, raw8<IT>& dst) {
+        if constexpr (VEC == 8) issue8<IT, true>(base, row, p.K, k0c, dst);
+        else if constexpr (VEC == 4) issue8_half<IT>(base, row, p.K, k0c, dst);
+        else issue8<IT, false>(base, row, p.K, k0c, dst);
+    };
     raw8<IT> self[ITEMS], selfy[ITEMS];
     auto issue_self = [&](int batch) {
 #pragma unroll
@@ -123,8 +129,8 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
             const int it = (batch * ITEMS + u) * RT_THREADS + tid;
             const int row = div_chunk(it), k0 = (it - row * nchunk) * 8;
             const size_t r = (size_t)min(r0 + row, p.N - 1);
-            issue8<IT, VEC>(src, r, p.K, min(k0, kmax8), self[u]);
-            if (MASKED) issue8<IT, VEC>(yref, r, p.K, min(k0, kmax8), selfy[u]);
+            ld8(src, r, min(k0, kmax8), self[u]);
+            if (MASKED) ld8(yref, r, min(k0, kmax8), selfy[u]);
         }
     };
     issue_self(0);
@@ -195,8 +201,8 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
         const size_t r = (size_t)min(r0 + row, p.N - 1);
         const int sbase = rsb[row];                                    // first row of this row's sentence
         const int k0c = min(k0, kmax8);
-        issue8<IT, VEC>(src, r, p.K, k0c, g.s);
-        if (MASKED) issue8<IT, VEC>(yref, r, p.K, k0c, g.sy);
+        ld8(src, r, k0c, g.s);
+        if (MASKED) ld8(yref, r, k0c, g.sy);
 #pragma unroll
         for (int e = 0; e < NBU; ++e) {
             // no e-th neighbour: the first 16 bytes of the tile's first row, one cache line for all such lanes.  (NOT the
@@ -204,9 +210,9 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
             const bool on = e < min(n, NB_INLINE);
             const size_t c = on ? (size_t)(sbase + rell[row * 8 + 1 + e]) : (size_t)r0;
             const int kc = on ? k0c : 0;
-            issue8<IT, VEC>(src, c, p.K, kc, g.nb[e]);
+            ld8(src, c, kc, g.nb[e]);
             if (MASKED) {
-                issue8<IT, VEC>(yref, c, p.K, kc, g.nby[e]);
+                ld8(yref, c, kc, g.nby[e]);
                 g.dcnt[e] = p.d_ell[c * 8];
             }
         }
@@ -259,9 +265,9 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
                     c = (size_t)(sbase + p.g_col_idx[on ? beg + e0 + e : beg]);
                 }
                 c = on ? c : rc;
-                issue8<IT, VEC>(src, c, p.K, k0c, nb[e]);
+                ld8(src, c, k0c, nb[e]);
                 if (MASKED) {
-                    issue8<IT, VEC>(yref, c, p.K, k0c, nby[e]);
+                    ld8(yref, c, k0c, nby[e]);
                     ninv[e] = p.scale / (float)(p.d_ell[c * 8] + 1);
                 }
             }
@@ -487,12 +493,14 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
         __syncthreads();
         GCNPT_STAMP(p.stamps, 9);
 
-        // whole rows leave in 16-byte pieces
+        // whole rows leave in 16-byte pieces (8-byte ones when the row width only allows those: bf16 rows of 300 columns)
         const int c_lo = pass * ncols_pass, c_hi = min(p.NOUT, c_lo + ncols_pass);
         const int width = c_hi - c_lo;
-        constexpr int PER = 16 / (int)sizeof(OT);
         const OT* relu = BWD ? static_cast<const OT*>(p.relu_src) : nullptr;
-        if (p.vec_out && (width % PER) == 0 && (c_lo % PER) == 0) {
+        auto store_rows = [&](auto vtag) {
+            using V = decltype(vtag);                                       // uint4 or uint2
+            constexpr int PER = (int)sizeof(V) / (int)sizeof(OT);
+            constexpr int NW = (int)sizeof(V) / 4;
             const int pieces = width / PER;                                  // 16 threads per row: no division, 256 contiguous bytes each round
             const int row = tid >> 4, r = r0 + row;
             if (BWD && relu) {
@@ -502,19 +510,19 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
                 const float f = p.next_scale / rden[row];
                 const size_t rr = (size_t)min(r, p.N - 1) * p.NOUT + c_lo;
                 for (int pc0 = tid & 15; pc0 < pieces; pc0 += 16 * RP) {
-                    uint4 hin[RP];
+                    V hin[RP];
 #pragma unroll
-                    for (int u = 0; u < RP; ++u) hin[u] = *reinterpret_cast<const uint4*>(relu + rr + min(pc0 + 16 * u, pieces - 1) * PER);
+                    for (int u = 0; u < RP; ++u) hin[u] = *reinterpret_cast<const V*>(relu + rr + min(pc0 + 16 * u, pieces - 1) * PER);
 #pragma unroll
                     for (int u = 0; u < RP; ++u) {
                         const int pc = pc0 + 16 * u;
                         if (pc >= pieces || r >= p.N) continue;
-                        uint4 o = *reinterpret_cast<const uint4*>(O + (size_t)row * ostride + pc * PER);
+                        V o = *reinterpret_cast<const V*>(O + (size_t)row * ostride + pc * PER);
                         if constexpr (sizeof(OT) == 2) {
                             unsigned* ow = reinterpret_cast<unsigned*>(&o);
                             const unsigned* hw = reinterpret_cast<const unsigned*>(&hin[u]);
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
+                            for (int q = 0; q < NW; ++q) {
                                 const float lo = bf16_to_f32((bf16_t)(hw[q] & 0xffffu)) > 0.0f ? bf16_to_f32((bf16_t)(ow[q] & 0xffffu)) * f : 0.0f;
                                 const float hi = bf16_to_f32((bf16_t)(hw[q] >> 16)) > 0.0f ? bf16_to_f32((bf16_t)(ow[q] >> 16)) * f : 0.0f;
                                 ow[q] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
@@ -523,16 +531,22 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
                             float* ow = reinterpret_cast<float*>(&o);
                             const float* hw = reinterpret_cast<const float*>(&hin[u]);
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) ow[q] = hw[q] > 0.0f ? ow[q] * f : 0.0f;
+                            for (int q = 0; q < NW; ++q) ow[q] = hw[q] > 0.0f ? ow[q] * f : 0.0f;
                         }
-                        *reinterpret_cast<uint4*>(out + (size_t)r * p.NOUT + c_lo + pc * PER) = o;
+                        *reinterpret_cast<V*>(out + (size_t)r * p.NOUT + c_lo + pc * PER) = o;
                     }
                 }
             } else if (r < p.N) {
                 for (int pc = tid & 15; pc < pieces; pc += 16)
-                    *reinterpret_cast<uint4*>(out + (size_t)r * p.NOUT + c_lo + pc * PER) =
-                        *reinterpret_cast<const uint4*>(O + (size_t)row * ostride + pc * PER);
+                    *reinterpret_cast<V*>(out + (size_t)r * p.NOUT + c_lo + pc * PER) =
+                        *reinterpret_cast<const V*>(O + (size_t)row * ostride + pc * PER);
             }
+        };
+        constexpr int PER16 = 16 / (int)sizeof(OT), PER8 = 8 / (int)sizeof(OT);
+        if (p.vec_out == 16 && (width % PER16) == 0 && (c_lo % PER16) == 0) {
+            store_rows(uint4{});
+        } else if (p.vec_out >= 8 && (width % PER8) == 0 && (c_lo % PER8) == 0) {
+            store_rows(uint2{});
         } else {
             for (int it = tid; it < ROWS * width; it += RT_THREADS) {
                 const int row = it / width, c = it - row * width;
@@ -560,7 +574,23 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
 // =====================================================================================================
 using namespace gcnpt;
 
-template <typename CT, typename IT, typename OT, bool BWD, bool VEC, int NTW, int KSMAX, bool DZIN = false>
+// how rows of `width` elements of `es` bytes at base a (and b, if given) may be read: 8 elements per load when rows are 16-byte
+// aligned and whole chunks, 4 when they are aligned to half chunks (bf16: 8 bytes, f32: 16 bytes; width % 4 == 0), else element-wise
+static int vec_elems(int width, size_t es, const void* a, const void* b) {
+    auto al = [&](size_t n) { return (reinterpret_cast<uintptr_t>(a) % n) == 0 && (!b || (reinterpret_cast<uintptr_t>(b) % n) == 0); };
+    if (width % 8 == 0 && al(16)) return 8;
+    if (width % 4 == 0 && width >= 4 && al(4 * es)) return 4;
+    return 0;
+}
+// bytes per row-store piece: 16, 8 or 0 (element stores)
+static int vec_bytes(int width, size_t es, const void* a, const void* b) {
+    auto al = [&](size_t n) { return (reinterpret_cast<uintptr_t>(a) % n) == 0 && (!b || (reinterpret_cast<uintptr_t>(b) % n) == 0); };
+    if ((width * es) % 16 == 0 && al(16)) return 16;
+    if ((width * es) % 8 == 0 && al(8)) return 8;
+    return 0;
+}
+
+template <typename CT, typename IT, typename OT, bool BWD, int VEC, int NTW, int KSMAX, bool DZIN = false>
 static int launch_rowtile_cfg(hipStream_t s, const RowTileParams& p) {
     const int stride = lds_stride_dw(p.Kpad * (int)sizeof(CT) / 4) * 4 / (int)sizeof(CT);
     const int ncols_pass = RT_WAVES * NTW * 16;
@@ -579,17 +609,23 @@ static int launch_rowtile_cfg(hipStream_t s, const RowTileParams& p) {
 // output tiles per wave: the smallest of {2,3,4} that covers NOUT in one pass (8 waves x NTW x 16 columns),
 // with as many K-steps of weight fragments resident in registers as ~128 VGPRs allow.  Rows that cannot be
 // read 16 bytes at a time (width not a multiple of 8, unaligned base) take the element-load instantiation.
-template <typename CT, typename IT, typename OT, bool BWD, bool DZIN = false>
-static int launch_rowtile(hipStream_t s, const RowTileParams& p) {
+template <typename CT, typename IT, typename OT, bool BWD, int VEC, bool DZIN>
+static int launch_rowtile_vec(hipStream_t s, const RowTileParams& p) {
     const int n_tiles = ceil_div(p.NOUT, 16);
-    if (!p.vec_in) return launch_rowtile_cfg<CT, IT, OT, BWD, false, 4, BWD ? 3 : 4, DZIN>(s, p);
     if (n_tiles <= RT_WAVES * 2) {
         // 13 k-steps = the C-GCN input width (2 x 200 BiLSTM states): one more resident k-step instead of a second load phase
-        if (p.Kpad / (sizeof(CT) == 2 ? 32 : 16) == 13) return launch_rowtile_cfg<CT, IT, OT, BWD, true, 2, 13, DZIN>(s, p);
-        return launch_rowtile_cfg<CT, IT, OT, BWD, true, 2, 12, DZIN>(s, p);
+        if (p.Kpad / (sizeof(CT) == 2 ? 32 : 16) == 13) return launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 2, 13, DZIN>(s, p);
+        return launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 2, 12, DZIN>(s, p);
     }
-    if (n_tiles <= RT_WAVES * 3) return launch_rowtile_cfg<CT, IT, OT, BWD, true, 3, 7, DZIN>(s, p);
-    return launch_rowtile_cfg<CT, IT, OT, BWD, true, 4, 5, DZIN>(s, p);
+    if (n_tiles <= RT_WAVES * 3) return launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 3, 7, DZIN>(s, p);
+    return launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 4, 5, DZIN>(s, p);
+}
+
+template <typename CT, typename IT, typename OT, bool BWD, bool DZIN = false>
+static int launch_rowtile(hipStream_t s, const RowTileParams& p) {
+    if (p.vec_in == 8) return launch_rowtile_vec<CT, IT, OT, BWD, 8, DZIN>(s, p);
+    if (p.vec_in == 4) return launch_rowtile_vec<CT, IT, OT, BWD, 4, DZIN>(s, p);
+    return launch_rowtile_cfg<CT, IT, OT, BWD, 0, 4, BWD ? 3 : 4, DZIN>(s, p);
 }
 
 template <bool BWD, bool DZIN = false>
@@ -620,8 +656,8 @@ extern "C" int gcnpt_layer_fwd(void* stream, const void* h, int h_dtype, const v
     p.g_row_ptr = row_ptr; p.g_col_idx = col_idx; p.g_ell = ell; p.d_ell = deg_ell ? deg_ell : ell; p.out = out;
     p.frag_out = s_frag;
     p.N = B * T; p.T = T; p.K = Din; p.NOUT = H; p.Kpad = round_up(Din, kstep_of(compute_dtype)); p.chunk_magic = 0xffffffffu / (unsigned)(p.Kpad / 8) + 1u;
-    p.vec_in = (Din % 8 == 0) && aligned16(h);
-    p.vec_out = ((H * esize(out_dtype)) % 16 == 0) && aligned16(out);
+    p.vec_in = vec_elems(Din, esize(h_dtype), h, nullptr);
+    p.vec_out = vec_bytes(H, esize(out_dtype), out, nullptr);
     p.drop_p = drop_p; p.scale = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
     p.drop_thresh16 = (unsigned)((double)drop_p * 65536.0);
     p.seed = seed; p.seed_dev = seed_dev;
@@ -646,11 +682,10 @@ extern "C" int gcnpt_layer_bwd_data(void* stream, const void* dY, const void* Y,
     p.frag_out = z_frag;
     p.zero_a = zero_dW; p.zero_a_n = H * Din; p.zero_b = zero_db; p.zero_b_n = H;
     p.N = B * T; p.T = T; p.K = H; p.NOUT = Din; p.Kpad = round_up(H, kstep_of(compute_dtype)); p.chunk_magic = 0xffffffffu / (unsigned)(p.Kpad / 8) + 1u;
-    p.vec_in = (H % 8 == 0) && aligned16(dY) && (src_is_dz || aligned16(Y));
-    p.vec_out = dh && ((Din * esize(dh_dtype)) % 16 == 0) && aligned16(dh);
+    p.vec_in = vec_elems(H, esize(g_dtype), dY, src_is_dz ? nullptr : Y);
+    p.vec_out = dh ? vec_bytes(Din, esize(dh_dtype), dh, relu_src) : 0;
     p.scale = scale; p.drop_p = 0.0f;
     p.relu_src = relu_src; p.next_scale = next_scale;
-    if (relu_src && !aligned16(relu_src)) p.vec_out = 0;
     if (src_is_dz) return dispatch_rowtile<true, true>((hipStream_t)stream, p, g_dtype, dh_dtype, compute_dtype);
     return dispatch_rowtile<true>((hipStream_t)stream, p, g_dtype, dh_dtype, compute_dtype);
 }

@@ -287,7 +287,7 @@ extern "C" size_t gcnpt_frag_bytes(int rows, int width, int dtype) {
 
 // fills p for one layer; returns the number of workgroups it takes (a multiple of 8)
 static int plan_weight_grad(WeightGradParams& p, const void* z_frag, const void* s_frag, int nks, int Din, int H, float* dW, float* db,
-                            int layers_in_launch) {
+                            int blocks_in_launch, int waves, int wg_budget) {
     p = WeightGradParams{};
     p.stamps = static_cast<unsigned long long*>(g_debug_stamps); p.knob = g_debug_knob;
     p.zf = static_cast<const uint4*>(z_frag); p.sf = static_cast<const uint4*>(s_frag);
@@ -299,7 +299,9 @@ static int plan_weight_grad(WeightGradParams& p, const void* z_frag, const void*
     // them: measured 2 us faster per step than letting each layer bring 256 of its own), with at least one k-step per wave;
     // slices is 1, 2, 4 or a multiple of 8 so that each slice maps onto whole XCD groups (rounded DOWN: one more
     // workgroup than CUs costs a second round)
-    int want = std::max(1, std::min(ceil_div(p.nks, layers_in_launch > 1 ? 8 : 4), 256 / (mb * nb * layers_in_launch)));
+    // (big batches, wg_budget 768: 4-wave workgroups, three per CU, so that every CU's L1 path streams fragments -- with one slice a
+    // 128 x 300-token batch ran on 135 workgroups for 121 us)
+    int want = std::max(1, std::min(ceil_div(p.nks, waves), wg_budget / std::max(blocks_in_launch, mb * nb)));
     int slices = want >= 8 ? want / 8 * 8 : (want >= 4 ? 4 : (want >= 2 ? 2 : 1));
     p.ks_per_wg = ceil_div(p.nks, slices);
     p.mb = mb; p.nb = nb; p.slices = slices;
@@ -316,9 +318,20 @@ static int launch_weight_grad_cfg(hipStream_t s, const WeightGradMulti& mp) {
     return GCNPT_OK;
 }
 
-static int launch_weight_grad(hipStream_t s, const WeightGradMulti& mp, int compute_dtype) {
-    if (compute_dtype == GCNPT_BF16) return mp.n > 1 ? launch_weight_grad_cfg<bf16_t, 8>(s, mp) : launch_weight_grad_cfg<bf16_t, 4>(s, mp);
-    return mp.n > 1 ? launch_weight_grad_cfg<float, 8>(s, mp) : launch_weight_grad_cfg<float, 4>(s, mp);
+// waves per workgroup / workgroups the launch may have: small batches are one latency chain per CU (8 waves when layers share the
+// CUs); from 512 k-steps (16 k rows) on the fragment stream through the CUs' L1 paths is what counts: 4-wave workgroups, 2 per CU
+static int wg_waves(int n_layers, int nks) { return (n_layers > 1 && nks < 512) ? 8 : 4; }
+static int wg_budget(int nks) { return nks < 512 ? 256 : 512; }
+// (4 x 3)-tile blocks of all layers of a launch: the budget is shared in proportion to them, so every workgroup gets the same k-steps
+static int wg_blocks(int n_layers, const int* Din, const int* H) {
+    int b = 0;
+    for (int l = 0; l < n_layers; ++l) b += ceil_div(ceil_div(H[l], 16), WG_MT) * ceil_div(ceil_div(Din[l], 16), WG_NT);
+    return b;
+}
+
+static int launch_weight_grad(hipStream_t s, const WeightGradMulti& mp, int compute_dtype, int waves) {
+    if (compute_dtype == GCNPT_BF16) return waves == 8 ? launch_weight_grad_cfg<bf16_t, 8>(s, mp) : launch_weight_grad_cfg<bf16_t, 4>(s, mp);
+    return waves == 8 ? launch_weight_grad_cfg<float, 8>(s, mp) : launch_weight_grad_cfg<float, 4>(s, mp);
 }
 
 extern "C" int gcnpt_layer_bwd_weight_multi(void* stream, int n_layers, const void* const* z_frag, const void* const* s_frag,
@@ -334,9 +347,10 @@ extern "C" int gcnpt_layer_bwd_weight_multi(void* stream, int n_layers, const vo
     for (int l = 0; l < n_layers; ++l) {
         GCNPT_REQUIRE(z_frag[l] && s_frag[l] && dW[l] && db[l], "layer_bwd_weight: null pointer (layer %d)", l);
         GCNPT_REQUIRE(Din[l] > 0 && H[l] > 0, "layer_bwd_weight: sizes must be positive (layer %d)", l);
-        mp.first[l + 1] = mp.first[l] + plan_weight_grad(mp.l[l], z_frag[l], s_frag[l], nks, Din[l], H[l], dW[l], db[l], n_layers);
+        mp.first[l + 1] = mp.first[l] + plan_weight_grad(mp.l[l], z_frag[l], s_frag[l], nks, Din[l], H[l], dW[l], db[l],
+                                                         wg_blocks(n_layers, Din, H), wg_waves(n_layers, nks), wg_budget(nks));
     }
-    return launch_weight_grad((hipStream_t)stream, mp, compute_dtype);
+    return launch_weight_grad((hipStream_t)stream, mp, compute_dtype, wg_waves(n_layers, nks));
 }
 
 extern "C" int gcnpt_layer_bwd_weight(void* stream, const void* z_frag, const void* s_frag, int B, int T, int Din, int H,
@@ -355,7 +369,9 @@ extern "C" int gcnpt_stack_bwd_weight(void* stream, int n_layers, const void* co
     mp.n = n_layers;
     for (int l = 0; l < n_layers; ++l) {
         GCNPT_REQUIRE(g_frag[l] && h_frag[l] && dW[l], "stack_bwd_weight: null pointer (layer %d)", l);
-        mp.first[l + 1] = mp.first[l] + plan_weight_grad(mp.l[l], g_frag[l], h_frag[l], nks, l == 0 ? Din : H, H, dW[l], nullptr, n_layers);
+        const int din_l[1] = {l == 0 ? Din : H}, h_l[1] = {H};
+        mp.first[l + 1] = mp.first[l] + plan_weight_grad(mp.l[l], g_frag[l], h_frag[l], nks, l == 0 ? Din : H, H, dW[l], nullptr,
+                                                         n_layers * wg_blocks(1, din_l, h_l), wg_waves(n_layers, nks), wg_budget(nks));
     }
-    return launch_weight_grad((hipStream_t)stream, mp, GCNPT_BF16);
+    return launch_weight_grad((hipStream_t)stream, mp, GCNPT_BF16, wg_waves(n_layers, nks));
 }

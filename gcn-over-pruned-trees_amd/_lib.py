@@ -33,6 +33,9 @@ SIGNATURES = {
     "gcnpt_layers_bwd": (_i, [_p, _i] + [_p] * 8 + [_i, _i] + [_p] * 4 + [_i] + [_p] * 5),
     "gcnpt_fused2_supported": (_i, [_i] * 6),
     "gcnpt_fused2_fwd": (_i, [_p] * 8 + [_i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p]),
+    "gcnpt_pack_trees": (_i, [_p] * 10 + [_i, _i, _i] + [_p] * 10 + [_i, _i, _p]),
+    "gcnpt_pack_rows": (_i, [_p, _p, _i, _p, _i, _i, _i, _p]),
+    "gcnpt_unpack_rows": (_i, [_p, _p, _i, _p, _i, _i, _i, _p]),
     "gcnpt_pool3_fwd": (_i, [_p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "gcnpt_pool3_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i]),
     "gcnpt_diag_layer_fwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p, _f, _u64, _p]),

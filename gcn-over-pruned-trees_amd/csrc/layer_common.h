@@ -195,6 +195,8 @@ template <typename T> struct dgio<T, 1> {    // any H / alignment: `n` = 1 when 
 };
 
 // host-side argument helpers of the C-ABI wrappers
+// rows of a batch: B sentences padded to T tokens, or -- T = 0 -- B token-packed rows whose pattern has absolute columns (include/gcnpt.h)
+static inline long long rows_of(int B, int T) { return T > 0 ? (long long)B * T : (long long)B; }
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline int kstep_of(int dtype) { return dtype == GCNPT_BF16 ? 32 : 16; }
 static inline size_t esize(int dtype) { return dtype == GCNPT_BF16 ? 2 : 4; }

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
     const size_t er = (size_t)min(r0 + erow, p.N - 1);
     const int4 ell_v = reinterpret_cast<const int4*>(p.g_ell)[er * 2 + ehalf];
     const int deg_v = p.d_ell[er * 8];                                                   // gcn.py:261
-    const int sb_v = (int)er / p.T * p.T;          // the one division by T, done while the loads are on their way
+    const int sb_v = p.T ? (int)er / p.T * p.T : 0;   // the one division by T, done while the loads are on their way (T = 0: packed rows, columns are absolute)
     float bias_v = 0.0f;                           // fwd: one bias element per thread, parked in LDS with the heads (registers are
     if constexpr (!BWD) bias_v = p.bias[min(tid, p.NOUT - 1)];      // too scarce to carry 4 per tile through the whole kernel)
 
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
                 if constexpr (decltype(from_lds)::value) {
                     c = (size_t)(sbase + rell[row * 8 + 1 + min(e0 + e, NB_INLINE - 1)]);
                 } else {                                            // > 7 entries: continue in the CSR
-                    const int beg = p.g_row_ptr[(size_t)(sbase / p.T) * (p.T + 1) + (rc - sbase)];
+                    const int beg = p.T ? p.g_row_ptr[(size_t)(sbase / p.T) * (p.T + 1) + (rc - sbase)] : p.g_row_ptr[rc];
                     c = (size_t)(sbase + p.g_col_idx[on ? beg + e0 + e : beg]);
                 }
                 c = on ? c : rc;
@@ -646,16 +646,16 @@ extern "C" int gcnpt_layer_fwd(void* stream, const void* h, int h_dtype, const v
                                int B, int T, int Din, int H, void* out, int out_dtype, int compute_dtype, float drop_p,
                                uint64_t seed, void* s_frag, const uint64_t* seed_dev) {
     GCNPT_REQUIRE(h && w_fwd && bias && row_ptr && col_idx && ell && out, "layer_fwd: null pointer");
-    GCNPT_REQUIRE(B > 0 && T > 0 && Din > 0 && H > 0, "layer_fwd: sizes must be positive");
+    GCNPT_REQUIRE(B > 0 && T >= 0 && Din > 0 && H > 0, "layer_fwd: sizes must be positive");
     GCNPT_REQUIRE(dtype_ok(h_dtype) && dtype_ok(out_dtype) && dtype_ok(compute_dtype), "layer_fwd: bad dtype");
     GCNPT_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "layer_fwd: drop_p=%f outside [0,1)", (double)drop_p);
-    if ((long long)B * T > 0x7fffffffLL / 2) return fail(GCNPT_E_UNSUPPORTED, "layer_fwd: B*T too large");
+    if (rows_of(B, T) > 0x7fffffffLL / 2) return fail(GCNPT_E_UNSUPPORTED, "layer_fwd: B*T too large");
     RowTileParams p{};
     p.stamps = static_cast<unsigned long long*>(g_debug_stamps); p.knob = g_debug_knob;
     p.src = h; p.yref = nullptr; p.wfrag = w_fwd; p.bias = bias;
     p.g_row_ptr = row_ptr; p.g_col_idx = col_idx; p.g_ell = ell; p.d_ell = deg_ell ? deg_ell : ell; p.out = out;
     p.frag_out = s_frag;
-    p.N = B * T; p.T = T; p.K = Din; p.NOUT = H; p.Kpad = round_up(Din, kstep_of(compute_dtype)); p.chunk_magic = 0xffffffffu / (unsigned)(p.Kpad / 8) + 1u;
+    p.N = (int)rows_of(B, T); p.T = T; p.K = Din; p.NOUT = H; p.Kpad = round_up(Din, kstep_of(compute_dtype)); p.chunk_magic = 0xffffffffu / (unsigned)(p.Kpad / 8) + 1u;
     p.vec_in = vec_elems(Din, esize(h_dtype), h, nullptr);
     p.vec_out = vec_bytes(H, esize(out_dtype), out, nullptr);
     p.drop_p = drop_p; p.scale = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
@@ -672,16 +672,16 @@ extern "C" int gcnpt_layer_bwd_data(void* stream, const void* dY, const void* Y,
     GCNPT_REQUIRE(dY && (Y || src_is_dz) && w_bwd && ell && rowT_ptr && colT_idx && ellT, "layer_bwd_data: null pointer");
     GCNPT_REQUIRE(!relu_src || dh, "layer_bwd_data: relu_src without dh");
     GCNPT_REQUIRE(dh || z_frag, "layer_bwd_data: nothing to produce (dh and z_frag both NULL)");
-    GCNPT_REQUIRE(B > 0 && T > 0 && Din > 0 && H > 0, "layer_bwd_data: sizes must be positive");
+    GCNPT_REQUIRE(B > 0 && T >= 0 && Din > 0 && H > 0, "layer_bwd_data: sizes must be positive");
     GCNPT_REQUIRE(dtype_ok(g_dtype) && dtype_ok(dh_dtype) && dtype_ok(compute_dtype), "layer_bwd_data: bad dtype");
-    if ((long long)B * T > 0x7fffffffLL / 2) return fail(GCNPT_E_UNSUPPORTED, "layer_bwd_data: B*T too large");
+    if (rows_of(B, T) > 0x7fffffffLL / 2) return fail(GCNPT_E_UNSUPPORTED, "layer_bwd_data: B*T too large");
     RowTileParams p{};
     p.stamps = static_cast<unsigned long long*>(g_debug_stamps); p.knob = g_debug_knob;
     p.src = dY; p.yref = Y; p.wfrag = w_bwd; p.bias = nullptr;
     p.g_row_ptr = rowT_ptr; p.g_col_idx = colT_idx; p.g_ell = ellT; p.d_ell = ell; p.out = dh;
     p.frag_out = z_frag;
     p.zero_a = zero_dW; p.zero_a_n = H * Din; p.zero_b = zero_db; p.zero_b_n = H;
-    p.N = B * T; p.T = T; p.K = H; p.NOUT = Din; p.Kpad = round_up(H, kstep_of(compute_dtype)); p.chunk_magic = 0xffffffffu / (unsigned)(p.Kpad / 8) + 1u;
+    p.N = (int)rows_of(B, T); p.T = T; p.K = H; p.NOUT = Din; p.Kpad = round_up(H, kstep_of(compute_dtype)); p.chunk_magic = 0xffffffffu / (unsigned)(p.Kpad / 8) + 1u;
     p.vec_in = vec_elems(H, esize(g_dtype), dY, src_is_dz ? nullptr : Y);
     p.vec_out = dh ? vec_bytes(Din, esize(dh_dtype), dh, relu_src) : 0;
     p.scale = scale; p.drop_p = 0.0f;

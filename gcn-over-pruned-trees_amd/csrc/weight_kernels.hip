@@ -339,9 +339,9 @@ extern "C" int gcnpt_layer_bwd_weight_multi(void* stream, int n_layers, const vo
                                             int compute_dtype) {
     GCNPT_REQUIRE(n_layers >= 1 && n_layers <= WG_MAX_LAYERS, "layer_bwd_weight: 1..%d layers per call", WG_MAX_LAYERS);
     GCNPT_REQUIRE(z_frag && s_frag && Din && H && dW && db, "layer_bwd_weight: null pointer");
-    GCNPT_REQUIRE(B > 0 && T > 0, "layer_bwd_weight: sizes must be positive");
+    GCNPT_REQUIRE(B > 0 && T >= 0, "layer_bwd_weight: sizes must be positive");
     GCNPT_REQUIRE(dtype_ok(compute_dtype), "layer_bwd_weight: bad dtype");
-    const int nks = ceil_div(B * T, 32) * (compute_dtype == GCNPT_BF16 ? 1 : 2);
+    const int nks = ceil_div((int)rows_of(B, T), 32) * (compute_dtype == GCNPT_BF16 ? 1 : 2);
     WeightGradMulti mp{};
     mp.n = n_layers;
     for (int l = 0; l < n_layers; ++l) {

@@ -18,7 +18,8 @@ the output MLP stay ordinary PyTorch-ROCm modules, as in the reference.
 New optional `opt` keys (defaults reproduce the reference): `gcn_dtype` = 'fp32' | 'bf16' (MFMA operand /
 activation storage type inside the layer stack), `gcn_fused` = False (bf16 only: run the whole stack with the
 sentence-resident one-launch-per-direction kernels when the shape fits; slower than one launch per layer at B=50), `gcn_check_trees` = True (synchronise once per forward to
-raise on malformed trees the way the reference does; False keeps the step free of host syncs), `gcn_graph_rng` = False
+raise on malformed trees the way the reference does; False keeps the step free of host syncs), `gcn_packed` = False (True: the
+layer loop runs on token-packed rows, sum(len) instead of B*T, padding only at the module boundary), `gcn_graph_rng` = False
 (True: dropout seeds that survive hipGraph capture -- with `gcn_check_trees=False` a whole training step of the no-LSTM
 model can be captured with torch.cuda.graph and replayed, see tests/test_gpu_parity.py::test_training_step_graph_capture).
 """
@@ -30,7 +31,19 @@ import torch.nn as nn
 
 from .. import _lib
 from ..utils import constant
-from .tree import CompactTrees, PrunedTrees, adj_to_csr, prune_to_csr
+from .tree import CompactTrees, PackedTrees, PrunedTrees, adj_to_csr, prune_to_csr
+
+
+def _row_dims(h, trees, what):
+    """(B, T) as the C-ABI wants them, rows, leading shape.  Padded: h is [B,T,W] and the trees are for [B,T].  Token-packed
+    (PackedTrees): h is [N,W]; the entry points then take B = N, T = 0 (include/gcnpt.h, gcnpt_pack_trees)."""
+    if getattr(trees, "packed", False):
+        if h.dim() != 2 or h.shape[0] != trees.N:
+            raise RuntimeError("%s: packed trees hold %d rows but the inputs are %s" % (what, trees.N, tuple(h.shape)))
+        return trees.N, 0, trees.N, (trees.N,)
+    if h.dim() != 3 or (h.shape[0], h.shape[1]) != (trees.B, trees.T):
+        raise RuntimeError("%s: inputs are %s but the adjacency is for [%d,%d]" % (what, tuple(h.shape), trees.B, trees.T))
+    return trees.B, trees.T, trees.B * trees.T, (trees.B, trees.T)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -41,12 +54,11 @@ class _GCNLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, weight, bias, trees, drop_p, seed, compute, out_dtype, no_adj, seed_dev=None):
-        B, T, Din = h.shape
+        B, T, rows, lead = _row_dims(h, trees, "GCN layer")
+        Din = h.shape[-1]
         H = weight.shape[0]
         if weight.shape[1] != Din:
             raise RuntimeError("GCN layer: input width %d does not match weight %s" % (Din, tuple(weight.shape)))
-        if (B, T) != (trees.B, trees.T):
-            raise RuntimeError("GCN layer: inputs are [%d,%d,*] but the adjacency is for [%d,%d]" % (B, T, trees.B, trees.T))
         L = _lib.lib()
         h = h.contiguous()
         w32 = weight.detach().to(torch.float32).contiguous()
@@ -55,11 +67,11 @@ class _GCNLayerFn(torch.autograd.Function):
         w_bwd = torch.empty((L.gcnpt_packed_bytes(Din, H, compute),), dtype=torch.uint8, device=h.device)
         st = _lib.stream()
         _lib.check(L.gcnpt_pack_weights(st, _lib.ptr(w32), H, Din, compute, _lib.ptr(w_fwd), _lib.ptr(w_bwd)))
-        out = torch.empty((B, T, H), dtype=out_dtype, device=h.device)
+        out = torch.empty(lead + (H,), dtype=out_dtype, device=h.device)
         g_ell = trees.empty_ell() if no_adj else trees.ell
         # the gathered tile S = (A+I)h is saved in MFMA fragment order for the weight gradient (include/gcnpt.h)
         want_wgrad = weight.requires_grad or bias.requires_grad
-        s_frag = torch.empty((L.gcnpt_frag_bytes(B * T, Din, compute),), dtype=torch.uint8, device=h.device) if want_wgrad else None
+        s_frag = torch.empty((L.gcnpt_frag_bytes(rows, Din, compute),), dtype=torch.uint8, device=h.device) if want_wgrad else None
         _lib.check(L.gcnpt_layer_fwd(st, _lib.ptr(h), _lib.dtype_code(h.dtype), _lib.ptr(w_fwd), _lib.ptr(b32),
                                      _lib.ptr(trees.row_ptr), _lib.ptr(trees.col_idx), _lib.ptr(g_ell), _lib.ptr(trees.ell), B, T, Din, H,
                                      _lib.ptr(out), _lib.dtype_code(out_dtype), compute, float(drop_p), int(seed), _lib.ptr(s_frag), _lib.ptr(seed_dev)))
@@ -68,6 +80,7 @@ class _GCNLayerFn(torch.autograd.Function):
         ctx.trees, ctx.no_adj, ctx.compute = trees, no_adj, compute
         ctx.scale = 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0
         ctx.dims = (B, T, Din, H)
+        ctx.rows, ctx.lead = rows, lead
         ctx.param_dtypes = (weight.dtype, bias.dtype)
         return out
 
@@ -83,9 +96,9 @@ class _GCNLayerFn(torch.autograd.Function):
         g_ellT = trees.empty_ell() if ctx.no_adj else trees.ellT
         want_w = (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and s_frag is not None
         if ctx.needs_input_grad[0]:
-            dh = torch.empty((B, T, Din), dtype=ctx.h_dtype, device=dev)
+            dh = torch.empty(ctx.lead + (Din,), dtype=ctx.h_dtype, device=dev)
         if want_w:
-            z_frag = torch.empty((L.gcnpt_frag_bytes(B * T, H, ctx.compute),), dtype=torch.uint8, device=dev)
+            z_frag = torch.empty((L.gcnpt_frag_bytes(ctx.rows, H, ctx.compute),), dtype=torch.uint8, device=dev)
             dW = torch.empty((H, Din), dtype=torch.float32, device=dev)     # cleared by bwd_data, filled by bwd_weight
             db = torch.empty((H,), dtype=torch.float32, device=dev)
         if dh is not None or want_w:
@@ -107,8 +120,8 @@ def gcn_layer(h, weight, bias, trees, drop_p=0.0, seed=0, compute_dtype=torch.fl
     bfloat16 = bf16 operands with fp32 accumulation.  seed_dev: optional int64 [1] CUDA tensor added to `seed` on the device
     (advance it between replays of a captured graph to get fresh dropout masks).
     """
-    if not isinstance(trees, PrunedTrees):
-        raise TypeError("trees must be a PrunedTrees (see model.tree.prune_to_csr / adj_to_csr)")
+    if not isinstance(trees, (PrunedTrees, PackedTrees)):
+        raise TypeError("trees must be a PrunedTrees (see model.tree.prune_to_csr / adj_to_csr) or a PackedTrees (PrunedTrees.pack)")
     compute = _lib.dtype_code(compute_dtype)
     _lib.require_gpu(h)
     if compute == _lib.F32 and h.dtype != torch.float32:
@@ -128,9 +141,8 @@ class _GCNLayersFn(torch.autograd.Function):
     def forward(ctx, x, trees, cfg, *params):
         Ws, bs = params[0::2], params[1::2]
         L = len(Ws)
-        B, T, Din = x.shape
-        if (B, T) != (trees.B, trees.T):
-            raise RuntimeError("GCN layers: inputs are [%d,%d,*] but the adjacency is for [%d,%d]" % (B, T, trees.B, trees.T))
+        B, T, rows, lead = _row_dims(x, trees, "GCN layers")
+        Din = x.shape[-1]
         dims = [tuple(w.shape) for w in Ws]                           # (H_l, Din_l)
         for l, (h, k) in enumerate(dims):
             if k != (Din if l == 0 else dims[l - 1][0]):
@@ -147,8 +159,8 @@ class _GCNLayersFn(torch.autograd.Function):
                                                 compute, _lib.ptr_array(wf), _lib.ptr_array(wb)))
         need_w = any(p.requires_grad for p in params)
         g_ell = trees.empty_ell() if cfg["no_adj"] else trees.ell
-        outs = [torch.empty((B, T, H), dtype=cfg["out_dtype"] if l == L - 1 else cfg["mid_dtype"], device=dev) for l, (H, _) in enumerate(dims)]
-        s_frag = [torch.empty((lib.gcnpt_frag_bytes(B * T, K, compute),), **u8) if need_w else None for _, K in dims]
+        outs = [torch.empty(lead + (H,), dtype=cfg["out_dtype"] if l == L - 1 else cfg["mid_dtype"], device=dev) for l, (H, _) in enumerate(dims)]
+        s_frag = [torch.empty((lib.gcnpt_frag_bytes(rows, K, compute),), **u8) if need_w else None for _, K in dims]
         # every layer's launch from ONE native call (gcnpt_layers_fwd): no interpreter time between the launches
         _lib.check(lib.gcnpt_layers_fwd(
             st, L, _lib.ptr(x), _lib.dtype_code(x.dtype), _lib.ptr_array(wf), _lib.ptr_array(b32), _lib.ptr(trees.row_ptr),
@@ -157,6 +169,7 @@ class _GCNLayersFn(torch.autograd.Function):
             (ctypes.c_uint64 * L)(*cfg["seed"]), _lib.ptr_array(s_frag), _lib.ptr(cfg.get("seed_dev"))))
         ctx.save_for_backward(*outs, *wb, *[f for f in s_frag if f is not None])
         ctx.trees, ctx.cfg, ctx.dims, ctx.shape, ctx.need_w = trees, cfg, dims, (B, T, Din, L), need_w
+        ctx.rows, ctx.lead = rows, lead
         ctx.x_dtype = x.dtype
         ctx.param_dtypes = [p.dtype for p in params]
         return outs[-1]
@@ -174,10 +187,10 @@ class _GCNLayersFn(torch.autograd.Function):
         z_frag, dWs, dbs = [None] * L, [None] * L, [None] * L
         g = gout.to(outs[-1].dtype).contiguous()
         in_dtypes = [ctx.x_dtype if l == 0 else outs[l - 1].dtype for l in range(L)]
-        dhs = [torch.empty((B, T, K), dtype=in_dtypes[l], device=dev) if (l > 0 or ctx.needs_input_grad[0]) else None
+        dhs = [torch.empty(ctx.lead + (K,), dtype=in_dtypes[l], device=dev) if (l > 0 or ctx.needs_input_grad[0]) else None
                for l, (_, K) in enumerate(dims)]
         if want_w:
-            z_frag = [torch.empty((lib.gcnpt_frag_bytes(B * T, H, compute),), **u8) for H, _ in dims]
+            z_frag = [torch.empty((lib.gcnpt_frag_bytes(ctx.rows, H, compute),), **u8) for H, _ in dims]
             dWs = [torch.empty((H, K), dtype=torch.float32, device=dev) for H, K in dims]       # cleared by bwd_data, filled at the end
             dbs = [torch.empty((H,), dtype=torch.float32, device=dev) for H, _ in dims]
         ints = lambda v: (ctypes.c_int * L)(*v)  # noqa: E731
@@ -206,8 +219,8 @@ def gcn_layers(x, weights, biases, trees, drop_p=None, seeds=None, compute_dtype
     layer l (0 for the last).  compute_dtype float32 = exact fp32 MFMA (activations stay float32), bfloat16 = bf16 operands
     and bf16 activations between the layers, fp32 accumulation; the last layer's output has out_dtype.
     """
-    if not isinstance(trees, PrunedTrees):
-        raise TypeError("trees must be a PrunedTrees (see model.tree.prune_to_csr / adj_to_csr)")
+    if not isinstance(trees, (PrunedTrees, PackedTrees)):
+        raise TypeError("trees must be a PrunedTrees (see model.tree.prune_to_csr / adj_to_csr) or a PackedTrees (PrunedTrees.pack)")
     _lib.require_gpu(x)
     L = len(weights)
     compute = _lib.dtype_code(compute_dtype)
@@ -428,11 +441,15 @@ class GCNRelationModel(nn.Module):
                 trees.check(expect_maxlen=head.shape[1])
             if self.opt.get('gcn_pooled_only', False):
                 trees = trees.compact()                    # one host sync for the width; a TreeCache avoids it
+            elif self.opt.get('gcn_packed', False) and self.adj_type == 'regular':
+                # token-packed rows: the layers run on sum(len) rows instead of B*T (one host sync for sum(len), where the
+                # reference syncs for the lengths anyway, gcn.py:96)
+                trees = trees.pack(masks.eq(0).sum(1))
         else:
             if (trees.B, trees.T) != tuple(head.shape):
                 raise ValueError("trees are for a [%d,%d] batch, the inputs are %s" % (trees.B, trees.T, tuple(head.shape)))
             if self.opt.get('gcn_check_trees', True):
-                trees.check(expect_maxlen=head.shape[1])
+                trees.check() if isinstance(trees, PackedTrees) else trees.check(expect_maxlen=head.shape[1])
         h, pool_mask = self.gcn(trees, inputs)
         if isinstance(trees, CompactTrees):
             # only the tokens of the pruned trees were computed ([B,Tc,H]); the three poolings never look at any other
@@ -637,10 +654,21 @@ class GCN(nn.Module):
         else:
             gcn_inputs = embs
 
+        packed = adj if isinstance(adj, PackedTrees) else None
+        if packed is not None and self.adj_type != 'regular':
+            adj = packed.padded                                  # the deprel variants run on the padded layout
         if self.adj_type == 'diagonal_deprel':
             return self._forward_diagonal(adj, gcn_inputs, deprel)
         if self.adj_type == 'full_deprel':
             return self._forward_full(adj, gcn_inputs, deprel, all_tokens=ct is not None)
+        if packed is not None:
+            # pad / unpad only here, at the module boundary: the layer loop sees [sum(len), width] rows, the caller [B,T,H] (gcn.py:395)
+            no_adj = bool(self.opt.get('no_adj', False))
+            ps, seeds, seed_dev = self._dropout_plan()
+            Ws, bs = [lin.weight for lin in self.W], [lin.bias for lin in self.W]
+            xp = packed.pack_rows(gcn_inputs if gcn_inputs.dtype in (torch.float32, torch.bfloat16) else gcn_inputs.float())
+            hp = gcn_layers(xp, Ws, bs, packed, ps, seeds, self.compute_dtype, torch.float32, no_adj, seed_dev)
+            return packed.unpack_rows(hp), packed.padded.pool_mask
         trees = adj if isinstance(adj, PrunedTrees) else adj_to_csr(adj, want_label=False)   # gcn.py:260-262
         no_adj = bool(self.opt.get('no_adj', False))                                           # gcn.py:264-265
         x = gcn_inputs

@@ -48,6 +48,8 @@ class PrunedTrees(object):
     status   int32 [B+1]       per-sentence code, [B] = longest sentence seen
     """
 
+    packed = False
+
     def __init__(self, B, T, cap, row_ptr, col_idx, label, rowT_ptr, colT_idx, ell, ellT, pool_mask, status):
         self.B, self.T, self.cap = B, T, cap
         self.row_ptr, self.col_idx, self.label = row_ptr, col_idx, label
@@ -108,12 +110,138 @@ class PrunedTrees(object):
             P(colT_idx), P(ell), P(ellT), P(pool_mask), P(status), P(tok), P(kept)))
         return CompactTrees(PrunedTrees(self.B, Tc, cap_c, *bufs), tok, kept, self.T)
 
+    def pack(self, lens, n_rows=None):
+        """
+        The same adjacency over TOKEN-PACKED rows (north_star "packed"; include/gcnpt.h gcnpt_pack_trees): sentence b's token i
+        becomes row cu_seqlens[b] + i, padding slots do not exist.  lens: tokens per sentence (int sequence / tensor; a host
+        list avoids the one sync that sizing the packed buffers otherwise needs -- the reference itself syncs for the lengths
+        at this point, model/gcn.py:96); n_rows: rows to allocate if the caller knows sum(lens).  Returns a PackedTrees.
+        """
+        dev = self.device
+        lens_dev = torch.as_tensor(lens, device=dev).to(torch.int32).contiguous()
+        if lens_dev.numel() != self.B:
+            raise ValueError("pack: %d lengths for %d sentences" % (lens_dev.numel(), self.B))
+        if n_rows is None:
+            n_rows = int(sum(int(v) for v in lens)) if not torch.is_tensor(lens) or not lens.is_cuda else int(lens_dev.clamp(max=self.T).sum().item())
+        n_rows = max(int(n_rows), 1)
+        nnz_cap = min(self.B * self.cap, max(3 * n_rows, 1)) if self.cap == 3 * self.T else self.B * self.cap
+        i32 = dict(dtype=torch.int32, device=dev)
+        tr = self.rowT_ptr is not None
+        cu = torch.empty((self.B + 1,), **i32)
+        row_ptr = torch.empty((n_rows + 1,), **i32)
+        col_idx = torch.empty((nnz_cap,), **i32)
+        label = torch.empty((nnz_cap,), **i32) if self.label is not None else None
+        rowT_ptr = torch.empty((n_rows + 1,), **i32) if tr else None
+        colT_idx = torch.empty((nnz_cap,), **i32) if tr else None
+        ell = torch.zeros((n_rows * 8,), **i32)
+        ellT = torch.zeros((n_rows * 8,), **i32) if tr else None
+        pool_mask = torch.ones((n_rows, 1), dtype=torch.bool, device=dev)
+        row_sent = torch.zeros((n_rows,), **i32)
+        status = torch.empty((2,), **i32)
+        P = _lib.ptr
+        _lib.check(_lib.lib().gcnpt_pack_trees(
+            _lib.stream(), P(self.row_ptr), P(self.col_idx), P(self.label), P(self.rowT_ptr), P(self.colT_idx), P(self.ell), P(self.ellT),
+            P(self.pool_mask), P(lens_dev), self.B, self.T, self.cap, P(cu), P(row_ptr), P(col_idx), P(label), P(rowT_ptr), P(colT_idx),
+            P(ell), P(ellT), P(pool_mask), P(row_sent), n_rows, nnz_cap, P(status)))
+        return PackedTrees(self, n_rows, nnz_cap, cu, row_ptr, col_idx, label, rowT_ptr, colT_idx, ell, ellT, pool_mask, row_sent, status)
+
     def to_dense(self):
         """float32 [B,T,T] with the labels tree_to_adj writes (deprel id, +42 for the reverse edge, 84 on the diagonal)."""
         adj = torch.empty((self.B, self.T, self.T), dtype=torch.float32, device=self.device)
         _lib.check(_lib.lib().gcnpt_csr_to_adj(_lib.stream(), _lib.ptr(self.row_ptr), _lib.ptr(self.col_idx),
                                                _lib.ptr(self.label), self.B, self.T, _lib.ptr(adj)))
         return adj
+
+
+class PackedTrees(object):
+    """
+    The batch adjacency over token-packed rows (PrunedTrees.pack; layout in include/gcnpt.h under gcnpt_pack_trees).
+
+    N rows = sum(len); cu_seqlens int32 [B+1]; row_ptr / rowT_ptr int32 [N+1]; col_idx / colT_idx / label with ABSOLUTE packed
+    row numbers; ell / ellT int32 [N*8]; pool_mask bool [N,1]; row_sent int32 [N]; status int32 [2].  `padded` is the [B,T]
+    PrunedTrees it was made from (its pool_mask is what GCN.forward returns).  The layer ops take it in place of a PrunedTrees
+    together with packed activations [N, width] (pack_rows / unpack_rows move between the layouts).
+    """
+    packed = True
+
+    def __init__(self, padded, n_rows, nnz_cap, cu_seqlens, row_ptr, col_idx, label, rowT_ptr, colT_idx, ell, ellT, pool_mask, row_sent, status):
+        self.padded, self.N, self.nnz_cap = padded, int(n_rows), int(nnz_cap)
+        self.B, self.T = padded.B, padded.T
+        self.cu_seqlens, self.row_ptr, self.col_idx, self.label = cu_seqlens, row_ptr, col_idx, label
+        self.rowT_ptr, self.colT_idx, self.ell, self.ellT = rowT_ptr, colT_idx, ell, ellT
+        self.pool_mask, self.row_sent, self.status = pool_mask, row_sent, status
+        self._empty = None
+
+    @property
+    def device(self):
+        return self.row_ptr.device
+
+    def empty_ell(self):
+        if self._empty is None:
+            self._empty = torch.zeros_like(self.ell)
+        return self._empty
+
+    def check(self):
+        """Synchronises: raises if the packed buffers were too small or sum(len) differs from the rows allocated."""
+        self.padded.check()
+        st = self.status.cpu()
+        if int(st[0]) != 0:
+            raise _lib.GcnptError(int(st[0]), "pack_trees: %d rows / %d entries allocated do not hold the batch (sum(len) = %d)"
+                                  % (self.N, self.nnz_cap, int(st[1])))
+        if int(st[1]) != self.N:
+            raise ValueError("pack_trees: sum(len) = %d but %d rows were allocated" % (int(st[1]), self.N))
+        return self
+
+    def pack_rows(self, t):
+        """[B,T,W] (or [B,T]) -> packed [N,W] ([N]); differentiable."""
+        return _PackRowsFn.apply(t, self)
+
+    def unpack_rows(self, t):
+        """packed [N,W] -> [B,T,W], zero in the slots past each sentence's end; differentiable."""
+        return _UnpackRowsFn.apply(t, self)
+
+
+def _move_rows(t, trees, unpack):
+    lib = _lib.lib()
+    if unpack:
+        W = t.shape[-1]
+        src = t.contiguous()
+        dst = torch.empty((trees.B, trees.T, W), dtype=t.dtype, device=t.device)
+        fn = lib.gcnpt_unpack_rows
+    else:
+        flat = t.dim() == 2
+        src = (t.unsqueeze(-1) if flat else t).contiguous()
+        W = src.shape[-1]
+        dst = torch.empty((trees.N, W), dtype=t.dtype, device=t.device)
+        fn = lib.gcnpt_pack_rows
+    if src.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("pack/unpack_rows: float32 or bfloat16 rows (integer fields: use PackedTrees.row_sent / cu_seqlens)")
+    _lib.check(fn(_lib.stream(), _lib.ptr(src), _lib.dtype_code(src.dtype), _lib.ptr(trees.cu_seqlens), trees.B, trees.T, W, _lib.ptr(dst)))
+    return dst
+
+
+class _PackRowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, trees):
+        ctx.trees, ctx.flat = trees, t.dim() == 2
+        out = _move_rows(t, trees, unpack=False)
+        return out.squeeze(-1) if ctx.flat else out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _move_rows(g.unsqueeze(-1) if ctx.flat else g, ctx.trees, unpack=True)
+        return (g.squeeze(-1) if ctx.flat else g), None
+
+
+class _UnpackRowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, trees):
+        ctx.trees = trees
+        return _move_rows(t, trees, unpack=True)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _move_rows(g, ctx.trees, unpack=False), None
 
 
 class CompactTrees(object):

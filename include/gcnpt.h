@@ -15,7 +15,8 @@
  *   - `stream` is a hipStream_t passed as void*.  Every call only ENQUEUES work on that stream and never
  *     synchronises, so calls can be captured into a hipGraph.
  *   - return value: 0 = enqueued, <0 = error (GCNPT_E_*); the text is in gcnpt_last_error() (thread-local).
- *   - a "row" is one token slot: row r = b*T + i of the padded [B,T,*] tensors the reference uses.
+ *   - a "row" is one token slot: row r = b*T + i of the padded [B,T,*] tensors the reference uses (or, with T = 0, a row of the
+ *     token-packed layout, see gcnpt_pack_trees).
  *
  * Pruned-tree adjacency in HBM ("CSR", shared by every kernel):
  *   row_ptr  int32 [B*(T+1)]   entries of row (b,i) are col_idx[row_ptr[b*(T+1)+i] .. row_ptr[b*(T+1)+i+1])
@@ -227,6 +228,31 @@ int gcnpt_stack_bwd(void* stream, int n_layers, const void* dY, const void* cons
                     void* const* g_frag, float* const* db);
 int gcnpt_stack_bwd_weight(void* stream, int n_layers, const void* const* g_frag, const void* const* h_frag, int B, int T,
                            int Din, int H, float* const* dW);
+
+/* ---- token-packed variable-length batches (north_star "packed") ----------------------------------------
+ * The reference pads every batch to its longest sentence (data/loader.py:109-121, model/gcn.py:96-97,106): B*T token rows of
+ * which only sum(len) are real.  The batch adjacency is block diagonal (model/tree.py:167-204), i.e. ONE sparse matrix over the
+ * packed rows r = cu_seqlens[b] + i.  gcnpt_pack_trees rewrites the [B,T] arrays of gcnpt_prune_to_csr / gcnpt_gather_trees /
+ * gcnpt_adj_to_csr into that form: same entries in the same order, columns = packed row numbers, offsets contiguous:
+ *   cu_seqlens int32 [B+1]   first packed row of each sentence (cu_seqlens[B] = sum(len) = N)
+ *   row_ptr / rowT_ptr int32 [N+1], col_idx / colT_idx / label int32 [nnz_cap], ell / ellT int32 [N*8], pool_mask uint8 [N],
+ *   row_sent int32 [N] (sentence of each packed row).   len [dev] int32 [B]: tokens per sentence (clamped to T).
+ *   n_rows = rows allocated (>= sum(len)), nnz_cap = entries allocated; status [dev] int32 [2]: [0] = 0 or GCNPT_E_CAPACITY when
+ *   either is too small (nothing usable is written then), [1] = sum(len) seen.
+ * EVERY layer entry point above takes the packed form with T = 0: then `B` is the number of packed rows N, the pattern's
+ * columns are absolute row numbers and row_ptr has N+1 entries (gcnpt_layer_fwd, gcnpt_layer_bwd_data, gcnpt_layer_bwd_weight[_multi],
+ * gcnpt_layers_fwd, gcnpt_layers_bwd; fragment images: gcnpt_frag_bytes(N, width, dtype)).  Rows keep their values: a packed row
+ * is bit-identical to the same token's row of the padded batch.
+ * gcnpt_pack_rows: src [B*T, W] -> dst [N, W] (dst[cu[b]+i] = src[b*T+i], i < len[b]); gcnpt_unpack_rows: the inverse, slots past a
+ * sentence's end are zero-filled (the reference leaves relu(pad-row . W + 2b) there; every consumer masks those slots,
+ * model/gcn.py:116-121).  dtype = element type of both (GCNPT_F32 / GCNPT_BF16). */
+int gcnpt_pack_trees(void* stream, const int32_t* src_row_ptr, const int32_t* src_col_idx, const int32_t* src_label,
+                     const int32_t* src_rowT_ptr, const int32_t* src_colT_idx, const int32_t* src_ell, const int32_t* src_ellT,
+                     const uint8_t* src_pool_mask, const int32_t* len, int B, int T, int cap, int32_t* cu_seqlens, int32_t* row_ptr,
+                     int32_t* col_idx, int32_t* label, int32_t* rowT_ptr, int32_t* colT_idx, int32_t* ell, int32_t* ellT,
+                     uint8_t* pool_mask, int32_t* row_sent, int n_rows, int nnz_cap, int32_t* status);
+int gcnpt_pack_rows(void* stream, const void* src, int dtype, const int32_t* cu_seqlens, int B, int T, int W, void* dst);
+int gcnpt_unpack_rows(void* stream, const void* src, int dtype, const int32_t* cu_seqlens, int B, int T, int W, void* dst);
 
 /* ---- N1: the consumer right after the path, model/gcn.py:116-121 + pool() 473-483 ---------------------------------
  * One pass over h [B*T,H] (h_dtype) produces out [B, 3H] float32 = [pool(h, pool_mask) | pool(h, subj_pos != 0) |

@@ -1,0 +1,190 @@
+"""
+Token-packed layout (north_star "the batch of variable-length pruned trees is packed"): the reference pads
+every batch to its longest sentence (data/loader.py:109-121, model/gcn.py:96-97,106), here the layer loop runs on sum(len) rows.
+
+  * gcnpt_pack_trees: the packed block-diagonal CSR / ELL heads hold exactly the reference's per-sentence matrices (integer: exact)
+  * the layer kernels on packed rows (T = 0): every real token's row is BIT-IDENTICAL to the padded path's, forward and dx;
+    fp32 forward <= 1e-5 and gradients <= 1e-4 against the CPU oracle (the tolerances of SURVEY.md 8c)
+  * pad / unpad only at the module boundary: GCNClassifier with opt['gcn_packed'] gives the reference's recorded logits
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import dense_from_coo, load_golden
+from helpers import FWD_RTOL, GRAD_RTOL, max_rel
+from gcn_over_pruned_trees_amd.utils import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu-marked tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def api():
+    from gcn_over_pruned_trees_amd import _lib
+    from gcn_over_pruned_trees_amd.model import gcn, tree
+    _lib.lib()
+    return gcn, tree
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def test_pack_trees_structure(api, dev):
+    gcn, tree = api
+    g = load_golden("trees_random.npz")
+    S, Ts = g["head"].shape
+    lens = g["lens"].astype(np.int64)
+    for K in (0, 2):
+        full = tree.prune_to_csr(_t(g["head"], dev), _t(g["subj_pos"], dev), _t(g["obj_pos"], dev), _t(g["deprel"], dev), K,
+                                 lens=_t(lens.astype(np.int32), dev)).check()
+        pk = full.pack(lens.tolist()).check()
+        N = int(lens.sum())
+        assert pk.N == N
+        cu = pk.cu_seqlens.cpu().numpy()
+        np.testing.assert_array_equal(cu, np.concatenate([[0], np.cumsum(lens)]))
+        ref = dense_from_coo(g["coo_k%d" % K], S, Ts)
+        for name_ptr, name_col, transpose in (("row_ptr", "col_idx", False), ("rowT_ptr", "colT_idx", True)):
+            rp = getattr(pk, name_ptr).cpu().numpy()
+            ci = getattr(pk, name_col).cpu().numpy()
+            lab = pk.label.cpu().numpy() if not transpose else None
+            ell = (pk.ellT if transpose else pk.ell).cpu().numpy().reshape(N, 8)
+            assert rp[0] == 0 and (np.diff(rp) >= 0).all()
+            for b in range(S):
+                n = int(lens[b])
+                want = ref[b, :n, :n].T if transpose else ref[b, :n, :n]
+                got = np.zeros((n, n), np.float32)
+                for i in range(n):
+                    r = cu[b] + i
+                    cols = ci[rp[r]:rp[r + 1]]
+                    assert ((cols >= cu[b]) & (cols < cu[b + 1])).all()                   # block diagonal: never leaves the sentence
+                    assert (np.diff(cols) > 0).all()                                       # ascending, as a dense -> CSR conversion gives
+                    got[i, cols - cu[b]] = lab[rp[r]:rp[r + 1]] if lab is not None else 1.0
+                    assert ell[r, 0] == len(cols)
+                    k = min(len(cols), 7)
+                    np.testing.assert_array_equal(ell[r, 1:1 + k], cols[:k])
+                    assert (ell[r, 1 + k:] == 0).all()
+                np.testing.assert_array_equal(got, want if lab is not None else (want != 0).astype(np.float32))
+            assert rp[N] == (ref != 0).sum()
+        pm = pk.pool_mask.cpu().numpy()[:, 0]
+        in_tree = (ref != 0).any(2) | (ref != 0).any(1)
+        np.testing.assert_array_equal(pm, np.concatenate([~in_tree[b, :lens[b]] for b in range(S)]))
+        np.testing.assert_array_equal(pk.row_sent.cpu().numpy(), np.repeat(np.arange(S), lens))
+    # too few rows allocated: reported, not overrun
+    small = full.pack(lens.tolist(), n_rows=N - 5)
+    with pytest.raises(Exception):
+        small.check()
+
+
+@pytest.mark.parametrize("width,dtype", [(360, torch.float32), (300, torch.bfloat16), (200, torch.bfloat16), (7, torch.float32)])
+def test_pack_unpack_rows_roundtrip(api, dev, width, dtype):
+    gcn, tree = api
+    tb = synthetic.random_tree_batch(3, 9, 40, "tacred")
+    tr = tree.prune_to_csr(*(_t(tb[k], dev) for k in ("head", "subj_pos", "obj_pos", "deprel")), 1, masks=_t(tb["masks"], dev), want_label=False)
+    pk = tr.pack(tb["lens"].tolist()).check()
+    x = torch.randn((9, 40, width), device=dev).to(dtype).requires_grad_()
+    xp = pk.pack_rows(x)
+    assert tuple(xp.shape) == (int(tb["lens"].sum()), width)
+    keep = ~_t(tb["masks"], dev)
+    assert torch.equal(xp, x[keep])
+    back = pk.unpack_rows(xp)
+    assert torch.equal(back[keep], x[keep]) and (back[~keep] == 0).all()
+    back.float().sum().backward()
+    assert torch.equal(x.grad[keep], torch.ones_like(x.grad[keep])) and (x.grad[~keep] == 0).all()
+
+
+def _stack(gcn, x, Ws, bs, trees, compute, drop=None, seeds=None):
+    xt = x.clone().requires_grad_()
+    Wt = [w.clone().requires_grad_() for w in Ws]
+    bt = [b.clone().requires_grad_() for b in bs]
+    h = gcn.gcn_layers(xt, Wt, bt, trees, drop, seeds, compute, torch.float32)
+    return xt, Wt, bt, h
+
+
+@pytest.mark.parametrize("shape", ["c2", "c5"])
+@pytest.mark.parametrize("compute", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_packed_layers_equal_padded_rows(api, dev, shape, compute):
+    """Same kernels, T = 0: a real token's row does not depend on the layout (values, dropout mask and all)."""
+    gcn, tree = api
+    B, T, Din, H, K = (50, 100, 360, 200, 1) if shape == "c2" else (12, 300, 600, 300, 2)
+    tb = synthetic.random_tree_batch(41, B, T, "tacred")
+    tr = tree.prune_to_csr(*(_t(tb[k], dev) for k in ("head", "subj_pos", "obj_pos", "deprel")), K, masks=_t(tb["masks"], dev), want_label=False)
+    tr.check(expect_maxlen=T)
+    pk = tr.pack(tb["lens"].tolist()).check()
+    Ws, bs = synthetic.layer_params(42, [Din, H, H])
+    Ws, bs = [_t(w, dev) for w in Ws], [_t(b, dev) for b in bs]
+    x = _t(synthetic.normal(43, (B, T, Din)), dev)
+    gy = _t(synthetic.normal(44, (B, T, H)), dev)
+    keep = ~_t(tb["masks"], dev)
+    drop, seeds = [0.5, 0.0], [1234567, 0]
+    # dropout hashes the ROW NUMBER, which differs between the layouts: compare without it, then check it separately
+    a = _stack(gcn, x, Ws, bs, tr, compute)
+    a[3].backward(gy * keep.unsqueeze(-1))                 # the padded path: no gradient into padding slots, as pooling guarantees
+    b = _stack(gcn, x[keep], Ws, bs, pk, compute)
+    b[3].backward(gy[keep])
+    torch.cuda.synchronize()
+    assert tuple(b[3].shape) == (int(tb["lens"].sum()), H)
+    assert torch.equal(a[3][keep], b[3]), "forward rows differ"
+    assert torch.equal(a[0].grad[keep], b[0].grad), "dx rows differ"
+    for l in range(2):                                     # float atomics reorder the row sums
+        assert max_rel(b[1][l].grad.cpu().numpy(), a[1][l].grad.cpu().numpy()) <= 1e-5
+        assert max_rel(b[2][l].grad.cpu().numpy(), a[2][l].grad.cpu().numpy()) <= 1e-5
+    if shape == "c2":
+        c = _stack(gcn, x[keep], Ws, bs, pk, compute, drop, seeds)
+        c[3].backward(gy[keep])
+        d = _stack(gcn, x[keep], Ws, bs, pk, compute, drop, seeds)
+        assert torch.equal(c[3], d[3]) and not torch.equal(c[3], b[3])
+
+
+def test_packed_layers_vs_oracle_fp32(api, dev):
+    """fp32 mode on packed rows against the CPU restatement of model/gcn.py:260-271, 390-393 and its autograd."""
+    from oracle import gcn_ref, prune_ref
+    gcn, tree = api
+    B, T, Din, H, K = 20, 64, 96, 80, 1
+    tb = synthetic.random_tree_batch(51, B, T, "tacred")
+    tr = tree.prune_to_csr(*(_t(tb[k], dev) for k in ("head", "subj_pos", "obj_pos", "deprel")), K, masks=_t(tb["masks"], dev), want_label=False)
+    pk = tr.pack(tb["lens"].tolist()).check()
+    Ws, bs = synthetic.layer_params(52, [Din, H, H])
+    x, gy = synthetic.normal(53, (B, T, Din)), synthetic.normal(54, (B, T, H))
+    keep = ~tb["masks"]
+    gy = gy * keep[..., None]
+    adj = prune_ref.batch_adj(tb["head"], tb["subj_pos"], tb["obj_pos"], tb["deprel"], tb["lens"], K)["adj"]
+    href, _ = gcn_ref.gcn_forward(adj, x, Ws, bs)
+    dx, dWs, dbs = gcn_ref.gcn_backward(adj, x, Ws, bs, gy)
+    xt, Wt, bt, h = _stack(gcn, _t(x[keep], dev), [_t(w, dev) for w in Ws], [_t(b, dev) for b in bs], pk, torch.float32)
+    h.backward(_t(gy[keep], dev))
+    assert max_rel(h.detach().cpu().numpy(), href[keep]) <= FWD_RTOL
+    assert max_rel(xt.grad.cpu().numpy(), dx[keep]) <= GRAD_RTOL
+    # the reference's padding rows also feed dW / db -- with zero upstream gradient here, so the packed sums are the reference's
+    for l in range(2):
+        assert max_rel(Wt[l].grad.cpu().numpy(), dWs[l]) <= GRAD_RTOL and max_rel(bt[l].grad.cpu().numpy(), dbs[l]) <= GRAD_RTOL
+
+
+@pytest.mark.parametrize("fixture", ["e2e_gcn.npz", "e2e_cgcn.npz", "e2e_avgpool.npz"])
+def test_classifier_packed_matches_golden_logits(api, dev, fixture):
+    """opt['gcn_packed']: the layer loop on packed rows, padding only at the module boundary -- the reference's recorded logits."""
+    gcn, tree = api
+    e = load_golden(fixture)
+    opt = json.loads(str(e["opt"]))
+    opt["cuda"] = True
+    outs = {}
+    for packed in (False, True):
+        model = gcn.GCNClassifier(dict(opt, gcn_packed=packed))
+        model.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in e.items() if k.startswith("sd:")}, strict=True)
+        model.to(dev).eval()
+        keys = ("words", "masks", "pos", "ner", "deprel", "head", "subj_pos", "obj_pos") if opt["dataset"] == "tacred" else \
+            ("words", "masks", "pos", "deprel", "head", "subj_pos", "obj_pos")
+        inputs = tuple(_t(e[k], dev) for k in keys)
+        with torch.no_grad():
+            logits, pooled = model(inputs)
+        outs[packed] = (logits.cpu().numpy(), pooled.cpu().numpy())
+    assert max_rel(outs[True][0], e["logits"]) <= 1e-4
+    assert max_rel(outs[True][0], outs[False][0]) <= 1e-5 and max_rel(outs[True][1], outs[False][1]) <= 1e-5

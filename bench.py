@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--prune-k", type=int, default=1)
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--lengths", choices=["full", "tacred"], default="full")
+    ap.add_argument("--layout", choices=["padded", "packed"], default="padded",
+                    help="padded: the reference's [B,T,*] rows (the BASELINE metric's shape); packed: token-packed sum(len) rows + cu_seqlens "
+                         "(gcnpt_pack_trees), what a variable-length batch costs without its padding (use with --lengths tacred)")
     ap.add_argument("--drop", type=float, default=0.5)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--fused", action="store_true",
@@ -87,7 +90,7 @@ N_BUCKETS = 4       # gradient buckets in flight for N > 1: the all-reduce of a 
 class Stack(object):
     """Device buffers of one rank's shard and the C-ABI calls of one step."""
 
-    def __init__(self, args, dev, seed, pooled_only=False):
+    def __init__(self, args, dev, seed, pooled_only=False, packed=False):
         from gcn_over_pruned_trees_amd import _lib
         from gcn_over_pruned_trees_amd.model import tree
         from gcn_over_pruned_trees_amd.utils import synthetic
@@ -117,16 +120,25 @@ class Stack(object):
             ct = self.trees.compact()
             self.trees, self.x, self.gy = ct.trees, ct.take(self.x).contiguous(), ct.take(self.gy).contiguous()
             self.T = T = ct.Tc
-        self.h1 = torch.empty((B, T, H), dtype=act, device=dev)
-        self.h2 = torch.empty((B, T, H), dtype=act, device=dev)
-        self.dh1 = torch.empty((B, T, H), dtype=act, device=dev)
-        self.dx = torch.empty((B, T, Din), dtype=act, device=dev)
+        self.rows = B * T
+        self.packed = packed
+        if packed:
+            # token-packed rows (north_star "packed"): sum(len) rows, pattern with absolute columns; the C-ABI then takes B = rows, T = 0
+            pk = self.trees.pack(tb["lens"].tolist())
+            keep = ~self.masks
+            self.trees, self.x, self.gy = pk, self.x[keep].contiguous(), self.gy[keep].contiguous()
+            self.rows = pk.N
+        R = self.rows
+        self.h1 = torch.empty((R, H), dtype=act, device=dev)
+        self.h2 = torch.empty((R, H), dtype=act, device=dev)
+        self.dh1 = torch.empty((R, H), dtype=act, device=dev)
+        self.dx = torch.empty((R, Din), dtype=act, device=dev)
         dims = [(H, Din), (H, H)]
         self.wf = [torch.empty((self.L.gcnpt_packed_bytes(h, d, self.compute),), dtype=torch.uint8, device=dev) for h, d in dims]
         self.wb = [torch.empty((self.L.gcnpt_packed_bytes(d, h, self.compute),), dtype=torch.uint8, device=dev) for h, d in dims]
         # saved operands in MFMA fragment order: S_l = (A+I)h_l written by fwd, dZ_l written by bwd_data
-        self.sf = [torch.empty((self.L.gcnpt_frag_bytes(B * T, d, self.compute),), dtype=torch.uint8, device=dev) for h, d in dims]
-        self.zf = [torch.empty((self.L.gcnpt_frag_bytes(B * T, h, self.compute),), dtype=torch.uint8, device=dev) for h, d in dims]
+        self.sf = [torch.empty((self.L.gcnpt_frag_bytes(R, d, self.compute),), dtype=torch.uint8, device=dev) for h, d in dims]
+        self.zf = [torch.empty((self.L.gcnpt_frag_bytes(R, h, self.compute),), dtype=torch.uint8, device=dev) for h, d in dims]
         # a ring of flat gradient buckets [dW0, db0, dW1, db1] so that the all-reduce of step i overlaps the following steps
         self.n_grad = H * Din + H + H * H + H
         self.buckets = [torch.zeros((self.n_grad,), dtype=torch.float32, device=dev) for _ in range(N_BUCKETS)]
@@ -138,11 +150,13 @@ class Stack(object):
         self.cache_idx = (torch.arange(B, device=dev) + B * (reps // 2)).to(torch.int64)
         self.scale = 1.0 / (1.0 - args.drop) if args.drop > 0 else 1.0
         self.side = torch.cuda.Stream(device=dev)
-        self.fused = args.fused and args.dtype == "bf16" and not pooled_only and bool(self.L.gcnpt_stack_supported(T, Din, H, 2, self.compute))
+        self.fused = args.fused and args.dtype == "bf16" and not pooled_only and not packed and bool(self.L.gcnpt_stack_supported(T, Din, H, 2, self.compute))
         if self.fused:       # fragment images with per-sentence k-steps: layer inputs h_l (fwd) and G_l = (A+I)^T dZ_l (bwd)
             fb = self.L.gcnpt_stack_frag_bytes
             self.hf = [torch.empty((fb(B, T, d),), dtype=torch.uint8, device=dev) for h, d in dims]
             self.gf = [torch.empty((fb(B, T, h),), dtype=torch.uint8, device=dev) for h, d in dims]
+        if packed:
+            self.B, self.T = self.rows, 0                   # what the C-ABI takes for packed rows (include/gcnpt.h, gcnpt_pack_trees)
 
     def grads(self, k):
         H, Din = self.H, self.Din
@@ -292,7 +306,7 @@ class Stack(object):
             (ctypes.c_uint64 * 2)(0x5eed, 0), A(self.sf), None))
 
     def two_layer_launches(self):
-        return (self.args.fused2 and len(self.W) == 2 and self.args.dtype == "bf16" and
+        return (self.args.fused2 and not self.packed and len(self.W) == 2 and self.args.dtype == "bf16" and
                 bool(self.L.gcnpt_fused2_supported(self.T, self.Din, self.H, self.H, self.act, self.compute)))
 
     def calls(self, k=0):
@@ -340,7 +354,7 @@ class Stack(object):
     # ---- algorithmic bytes per launch (DESIGN.md "Measurement") ----
     def algorithmic_bytes(self):
         e = 2 if self.args.dtype == "bf16" else 4
-        N, B, T = self.B * self.T, self.B, self.T
+        N, B, T = self.rows, self.B, self.T
         csr = 32 * N            # one ELL head (count + 7 columns) per row; the CSR arrays are only touched by rows with > 7 entries
         out = {}
         for l, (H, Din) in enumerate([tuple(w.shape) for w in self.W]):
@@ -373,7 +387,7 @@ class Stack(object):
         half reads dY, Y, W, CSR and writes dh, and the weight half reads h and writes dW, db.  Launches that cover several of these
         get their sum; `pack` covers none (0)."""
         e = 2 if self.args.dtype == "bf16" else 4
-        N = self.B * self.T
+        N = self.rows
         csr = 4 * (N + 1) + 4 * self.nnz
         per = {}
         for l, (H, Din) in enumerate([tuple(w.shape) for w in self.W]):
@@ -610,7 +624,7 @@ def main():
     # every rank draws its own shard of the global batch; GCNPT_BENCH_SAME_SHARD=1 (tests) gives all ranks rank 0's shard, so that
     # the all-reduced bucket must be exactly world x the one-rank bucket
     shard_seed = 1234 + (0 if os.environ.get("GCNPT_BENCH_SAME_SHARD") else 17 * rank)
-    stack = Stack(args, dev, seed=shard_seed)
+    stack = Stack(args, dev, seed=shard_seed, packed=args.layout == "packed")
     from gcn_over_pruned_trees_amd.shard import OverlappedAllReduce
 
     # ---- the timed step: layer stack fwd+bwd (+ overlapped gradient all-reduce when N > 1)
@@ -685,6 +699,8 @@ def main():
     if rank == 0:
         sent = args.batch * world * args.steps
         # second measurement on rank 0 only: tree build inside the step
+        if args.layout == "packed":
+            args.no_secondary = True                       # (the pruner's and the cache's arrays are [B,T]: not part of a packed step)
         if not args.no_secondary:
             run_p = runner(launch, with_prune=True)[0][0]
             wall_p, _ = timed(lambda i: run_p(), args.steps, min(args.warmup, 50), lambda: None)
@@ -696,8 +712,9 @@ def main():
             "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": "2-layer GCN stack fwd+bwd (no LSTM), batch=%d seq_len=%d Din=%d hidden=%d prune_k=%d, %s storage / fp32 accumulate, "
-                                   "synthetic TACRED-shaped random trees (lengths=%s), dropout %.1f between layers"
-                                   % (args.batch, args.seq, args.din, args.hidden, args.prune_k, args.dtype, args.lengths, args.drop),
+                                   "synthetic TACRED-shaped random trees (lengths=%s, layout=%s: %d rows), dropout %.1f between layers"
+                                   % (args.batch, args.seq, args.din, args.hidden, args.prune_k, args.dtype, args.lengths, args.layout, stack.rows,
+                                      args.drop),
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "parallelism": "dp%d" % world,
                        "world_size": dist.get_world_size() if multi else 1, "dist_backend": dist.get_backend() if multi else None,
                        "ranks_started_by": ("bench.py itself (--gpus N without a launcher)" if os.environ.get("GCNPT_BENCH_SELF_LAUNCHED")
@@ -735,7 +752,22 @@ def main():
                                   "steps": n32, "note": "rank 0, same step with fp32 activations and exact fp32 MFMA (v_mfma_f32_16x16x4_f32): the "
                                                         "reference's own arithmetic, the mode the 1e-5 / 1e-4 parity tests run in"}
                 del s32
-        if not stack.fused and not args.no_pooled_only:
+        if not stack.fused and not args.no_pooled_only and args.layout == "padded" and args.lengths == "tacred":
+            sp = Stack(args, dev, seed=shard_seed, packed=True)
+            if launch == "native":
+                run_q = sp.step_native
+                run_q()
+                torch.cuda.synchronize()
+            else:
+                run_q, _ = capture(lambda: sp.step(0), use_graph)
+            wall_q, _ = timed(lambda i: run_q(), args.steps, min(args.warmup, 50), lambda: None)
+            result["packed_rows"] = {
+                "value": args.batch * args.steps / wall_q, "unit": "sentences/s", "ms_per_step": wall_q / args.steps * 1e3,
+                "rows": sp.rows, "rows_full": sp.rows_full,
+                "note": "rank 0, the same step on token-packed rows (gcnpt_pack_trees: sum(len) rows, no padding slots); every real token's "
+                        "row is bit-identical to the padded batch's"}
+            del sp
+        if not stack.fused and not args.no_pooled_only and args.layout == "padded":
             sc = Stack(args, dev, seed=shard_seed, pooled_only=True)
             if launch == "native":
                 run_k = sc.step_native

@@ -440,7 +440,8 @@ class GCNRelationModel(nn.Module):
             if self.opt.get('gcn_check_trees', True):
                 trees.check(expect_maxlen=head.shape[1])
             if self.opt.get('gcn_pooled_only', False):
-                trees = trees.compact()                    # one host sync for the width; a TreeCache avoids it
+                # one host sync for the width (a TreeCache avoids it); entity tokens are kept even when the tree does not hold them
+                trees = trees.compact(also_keep=(subj_pos == 0) | (obj_pos == 0))
             elif self.opt.get('gcn_packed', False) and self.adj_type == 'regular':
                 # token-packed rows: the layers run on sum(len) rows instead of B*T (one host sync for sum(len), where the
                 # reference syncs for the lengths anyway, gcn.py:96)
@@ -452,8 +453,8 @@ class GCNRelationModel(nn.Module):
                 trees.check() if isinstance(trees, PackedTrees) else trees.check(expect_maxlen=head.shape[1])
         h, pool_mask = self.gcn(trees, inputs)
         if isinstance(trees, CompactTrees):
-            # only the tokens of the pruned trees were computed ([B,Tc,H]); the three poolings never look at any other
-            # (entity tokens are always kept, model/tree.py:96-128), so the pooled vectors are the full batch's
+            # only the tokens of the pruned trees and the entity tokens were computed ([B,Tc,H]); the three poolings never look at
+            # any other (gcn.py:116-119), so the pooled vectors are the full batch's
             subj_pos, obj_pos = trees.take(subj_pos, fill=150), trees.take(obj_pos, fill=150)      # 150: the loader's pad value (loader.py:120-121)
         # gcn.py:116-121: three masked poolings and the concat, one pass over h (masks straight from the position tensors)
         pooled = pool3(h, pool_mask, subj_pos, obj_pos, type=self.opt['pooling'])

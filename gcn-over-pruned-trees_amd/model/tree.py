@@ -88,15 +88,21 @@ class PrunedTrees(object):
         rp = self.row_ptr.view(self.B, self.T + 1)
         return (rp[:, -1] - rp[:, 0]).to(torch.int64)
 
-    def compact(self, Tc=None):
+    def compact(self, Tc=None, also_keep=None):
         """
         "Pooled-only" rows: the same pattern for a [B, Tc] batch that holds only the tokens of the pruned
         trees (pool_mask False), renumbered in token order -- see gcnpt_compact_trees in include/gcnpt.h.  Tc=None takes the
         most tokens any sentence keeps (ONE host sync; pass a fixed Tc, e.g. a TreeCache's, to stay asynchronous: a sentence
-        that keeps more gets status E_LENGTH).  Returns a CompactTrees.
+        that keeps more gets status E_LENGTH).  also_keep: bool [B,T], tokens to keep although they are outside the tree --
+        the subject / object tokens: the reference pools h over them through subj_mask / obj_mask whether or not they are in the
+        tree (gcn.py:116-119), and a one-node tree (tree.py:182-192 writes no self loop for a childless root) has NO token in
+        pool_mask's sense.  Such tokens get empty rows and stay excluded from the tree pooling.  Returns a CompactTrees.
         """
+        src_mask = self.pool_mask
+        if also_keep is not None:
+            src_mask = (self.pool_mask.view(self.B, self.T) & ~also_keep.view(self.B, self.T).bool()).view(self.B, self.T, 1).contiguous()
         if Tc is None:
-            Tc = max(int((~self.pool_mask.view(self.B, self.T)).sum(1).max()), 1)
+            Tc = max(int((~src_mask.view(self.B, self.T)).sum(1).max()), 1)
         Tc = int(Tc)
         cap_c = 3 * Tc if self.cap == 3 * self.T else min(self.cap, Tc * Tc)
         bufs = _alloc(self.B, Tc, cap_c, self.device, self.label is not None, self.rowT_ptr is not None)
@@ -106,8 +112,12 @@ class PrunedTrees(object):
         P = _lib.ptr
         _lib.check(_lib.lib().gcnpt_compact_trees(
             _lib.stream(), P(self.row_ptr), P(self.col_idx), P(self.label), P(self.rowT_ptr), P(self.colT_idx), P(self.ell), P(self.ellT),
-            P(self.pool_mask), P(self.status), self.B, self.T, self.cap, Tc, cap_c, P(row_ptr), P(col_idx), P(label), P(rowT_ptr),
+            P(src_mask), P(self.status), self.B, self.T, self.cap, Tc, cap_c, P(row_ptr), P(col_idx), P(label), P(rowT_ptr),
             P(colT_idx), P(ell), P(ellT), P(pool_mask), P(status), P(tok), P(kept)))
+        if also_keep is not None:
+            # the extra tokens are rows of the compact batch but NOT members of the tree: the mask GCN.forward returns stays the reference's
+            orig = torch.gather(self.pool_mask.view(self.B, self.T), 1, tok.clamp(min=0))
+            pool_mask.copy_((orig | (tok < 0)).view(self.B, Tc, 1))
         return CompactTrees(PrunedTrees(self.B, Tc, cap_c, *bufs), tok, kept, self.T)
 
     def pack(self, lens, n_rows=None):
@@ -379,7 +389,8 @@ class TreeCache(object):
         if lens is None:
             lens = (masks == 0).sum(1)
         lens = lens.to(device=head.device, dtype=torch.int32).contiguous()
-        return cls(trees, lens, prune_k, trees.compact() if compact else None)
+        # compact form: entity tokens are kept even when they are outside the tree (one-node trees), see PrunedTrees.compact
+        return cls(trees, lens, prune_k, trees.compact(also_keep=(subj_pos == 0) | (obj_pos == 0)) if compact else None)
 
     def batch(self, idx, T, want_label=None, compact=False, Tc=None):
         """idx: int64 [B] sentence numbers (CUDA tensor; repeats allowed); T: the width the batch tensors are padded to

@@ -65,15 +65,34 @@ class FlatGradBucket(object):
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros((n,), dtype=torch.float32, device=dev)
-        o = 0
+        self.views, o = [], 0
         for p in self.params:
-            p.grad = self.flat[o:o + p.numel()].view_as(p)
+            self.views.append(self.flat[o:o + p.numel()].view_as(p))
             o += p.numel()
+        self.attach()
+
+    def attach(self):
+        """(Re-)point every p.grad at its slice of the flat buffer."""
+        for p, v in zip(self.params, self.views):
+            p.grad = v
 
     def zero(self):
+        """Clear the gradients IN PLACE.  Use this (or zero_grad(set_to_none=False)) between steps: torch's default
+        optimizer.zero_grad() / model.zero_grad() sets p.grad = None, which detaches the parameters from the bucket."""
         self.flat.zero_()
+        self.attach()
 
     def all_reduce(self, dist, weight=None, async_op=False):
+        """One all-reduce of the flat buffer.  A parameter whose .grad no longer aliases its slice (zero_grad(set_to_none=True)
+        followed by backward() gives it a fresh tensor) would be left out silently, so that is checked here: its gradient is
+        copied into the slice and the alias restored."""
+        for p, v in zip(self.params, self.views):
+            g = p.grad
+            if g is None:
+                v.zero_()                                   # no gradient this step: contributes zeros
+            elif g.data_ptr() != v.data_ptr():
+                v.copy_(g)                                  # detached by set_to_none: fold it back in
+            p.grad = v
         world = dist.get_world_size()
         self.flat.mul_(weight if weight is not None else 1.0 / world)
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)

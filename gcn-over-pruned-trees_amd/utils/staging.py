@@ -42,37 +42,52 @@ class PinnedStager(object):
 
     def __init__(self, fields, max_batch, max_T, device):
         self.fields, self.device = dict(fields), torch.device(device)
-        self.host = [{k: torch.empty((max_batch, max_T), dtype=dt).pin_memory() for k, (dt, _) in self.fields.items()} for _ in range(2)]
-        self.host_mask = [torch.empty((max_batch, max_T), dtype=torch.bool).pin_memory() for _ in range(2)]
+        # FLAT pinned buffers: a batch's [B, T] staging area is the first B*T elements, i.e. contiguous whatever T is -- a
+        # [:B, :T] corner of a [max_batch, max_T] buffer is not, and a non-contiguous pinned source makes `.to(non_blocking=True)`
+        # go through a pageable temporary (the copy then blocks the host and nothing overlaps)
+        n = int(max_batch) * int(max_T)
+        self.host = [{k: torch.empty((n,), dtype=dt).pin_memory() for k, (dt, _) in self.fields.items()} for _ in range(2)]
+        self.host_mask = [torch.empty((n,), dtype=torch.bool).pin_memory() for _ in range(2)]
         self.stream = torch.cuda.Stream(device=self.device)
         self.done = [torch.cuda.Event(), torch.cuda.Event()]
         self.turn = 0
 
     def upload(self, dataset, idx):
         """dataset: {name: int array [S, Ts]} padded to the dataset's longest sentence, plus 'lens' [S]; idx: the batch.
-        Returns ({name: CUDA tensor [B, T]}, masks bool [B, T] CUDA, event); wait for `event` (or call .ready()) before use."""
+        Returns ({name: CUDA tensor [B, T]}, masks bool [B, T] CUDA, event); wait for `event` (or call .ready()) before use.
+        The tensors are allocated on the upload stream; they are marked as used by the stream that is current when upload() is
+        called (Tensor.record_stream), so the caching allocator does not hand their memory to a later upload while kernels of that
+        stream may still read them.  A consumer on yet another stream passes the tensors to ready()."""
         idx = np.asarray(idx)
         lens = np.asarray(dataset["lens"])[idx]
         B, T = len(idx), int(lens.max())
         slot = self.host[self.turn]
         self.done[self.turn].synchronize()                           # the copy that last used these buffers has finished
+        consumer = torch.cuda.current_stream(self.device)
+        pad_mask = torch.from_numpy(np.arange(T)[None, :] >= lens[:, None])
         out = {}
         with torch.cuda.stream(self.stream):
             for k, (dt, pad) in self.fields.items():
-                h = slot[k][:B, :T]
+                h = slot[k][:B * T].view(B, T)
                 h.copy_(torch.from_numpy(np.ascontiguousarray(dataset[k][idx, :T])))
                 if pad != 0:
-                    h[torch.from_numpy(np.arange(T)[None, :] >= lens[:, None])] = pad
+                    h[pad_mask] = pad
                 out[k] = h.to(self.device, non_blocking=True)
-            m = self.host_mask[self.turn][:B, :T]
-            m.copy_(torch.from_numpy(np.arange(T)[None, :] >= lens[:, None]))
+                out[k].record_stream(consumer)
+            m = self.host_mask[self.turn][:B * T].view(B, T)
+            m.copy_(pad_mask)
             masks = m.to(self.device, non_blocking=True)
+            masks.record_stream(consumer)
             self.done[self.turn].record(self.stream)
         ev = self.done[self.turn]
         self.turn ^= 1
         return out, masks, ev
 
     @staticmethod
-    def ready(event):
-        """Make the current stream wait for an upload (no host sync)."""
-        torch.cuda.current_stream().wait_event(event)
+    def ready(event, tensors=()):
+        """Make the current stream wait for an upload (no host sync).  tensors: the uploaded tensors, when the current stream is
+        not the one that was current at upload() -- they are then marked as used by this stream too."""
+        cur = torch.cuda.current_stream()
+        cur.wait_event(event)
+        for t in (tensors.values() if isinstance(tensors, dict) else tensors):
+            t.record_stream(cur)

@@ -866,6 +866,43 @@ def test_classifier_pooled_only_matches_golden_logits(api, dev, tag):
     assert max_rel(l2.cpu().numpy(), g["logits"]) <= 1e-4
 
 
+def test_pooled_only_keeps_entity_tokens_of_one_node_trees(api, dev):
+    """Subject == object == one leaf token: head_to_tree gives a ONE-node tree and tree_to_adj writes nothing for it (no self loop
+    for a childless root, tree.py:182-192), so pool_mask excludes every token -- but the reference still pools h at the entity
+    token through subj_mask / obj_mask (gcn.py:116-119).  The kept-token path must keep that token: same logits as the full batch."""
+    import json
+    gcn, tree = api
+    g = load_golden("e2e_gcn.npz")
+    opt = json.loads(str(g["opt"]))
+    opt["cuda"] = True
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd:")}
+    arr = {k: g[k].copy() for k in ("words", "masks", "pos", "ner", "deprel", "head", "subj_pos", "obj_pos")}
+    n0 = int((~arr["masks"][0]).sum())
+    leaf = [i for i in range(n0) if (i + 1) not in arr["head"][0, :n0]][0]
+    rel = np.arange(n0) - leaf
+    arr["subj_pos"][0, :n0] = rel
+    arr["obj_pos"][0, :n0] = rel
+    inputs = tuple(_t(arr[k], dev) for k in ("words", "masks", "pos", "ner", "deprel", "head", "subj_pos", "obj_pos"))
+    outs = []
+    for extra in ({}, {"gcn_pooled_only": True}):
+        m = gcn.GCNClassifier(dict(opt, **extra))
+        m.load_state_dict(sd, strict=True)
+        m.to(dev).eval()
+        with torch.no_grad():
+            logits, pooled = m(inputs)
+        outs.append((logits.cpu().numpy(), pooled.cpu().numpy()))
+    full_trees = tree.prune_to_csr(*(inputs[i] for i in (5, 6, 7, 4)), opt["prune_k"], masks=inputs[1], want_label=False).check()
+    assert bool(full_trees.pool_mask[0].all())                      # the whole sentence is outside the (one-node) tree
+    # (the reference's tree pooling of a fully masked sentence is -1e12, gcn.py:476: sentence 0's logits are huge in BOTH paths;
+    #  what the kept-token path must reproduce is the subject / object pooling next to it)
+    assert np.isfinite(outs[0][0]).all() and np.abs(outs[0][1][0]).max() > 1e11
+    for s0 in (slice(0, 1), slice(1, None)):
+        assert max_rel(outs[1][0][s0], outs[0][0][s0]) <= 1e-5 and max_rel(outs[1][1][s0], outs[0][1][s0]) <= 1e-5
+    cache = tree.TreeCache.build(inputs[5], inputs[6], inputs[7], inputs[4], opt["prune_k"], masks=inputs[1], compact=True)
+    ct = cache.batch(torch.arange(inputs[5].shape[0], device=dev), inputs[5].shape[1], compact=True)
+    assert int(ct.kept[0]) == 1 and int(ct.tok[0, 0]) == leaf and bool(ct.trees.pool_mask[0].all())
+
+
 # ---------------------------------------------------------------------------------------------------
 # N2: adj_type == 'diagonal_deprel' (gcnpt_diag_layer_fwd / bwd)
 # ---------------------------------------------------------------------------------------------------
@@ -1446,3 +1483,62 @@ def test_inputs_to_tree_reps_matches_reference_layout(api, dev):
     adj = tree.inputs_to_tree_reps(_t(g["head"][order], dev), None, g["lens"][order], 1, _t(g["subj_pos"][order], dev),
                                    _t(g["obj_pos"][order], dev), _t(g["deprel"][order], dev))
     np.testing.assert_array_equal(adj.cpu().numpy(), dense_from_coo(g["coo_k1"], B, T)[order])
+
+
+# ---------------------------------------------------------------------------------------------------
+# C3: the C-GCN model (BiLSTM in front of the layer stack) at the BASELINE shape, forward + backward
+# ---------------------------------------------------------------------------------------------------
+def test_cgcn_full_size_layer_stack_vs_oracle(api, dev):
+    """BASELINE.json configs[2]: GCNClassifier with rnn=True, batch 50 x 100 tokens, hidden 200, prune_k 1, full fwd+bwd through the
+    module.  The GCN part is checked in place: the oracle (model/gcn.py:260-271, 390-393 restated) is driven by the module's OWN
+    BiLSTM output and by the gradient the pooling / MLP head sends back, and must give the module's h, d(gcn_inputs), dW, db
+    (fp32: 1e-5 forward, 1e-4 gradients)."""
+    from gcn_over_pruned_trees_amd.utils import synthetic
+    from oracle import gcn_ref, prune_ref
+    gcn, tree = api
+    B, T, K = 50, 100, 1
+    opt = dict(vocab_size=500, emb_dim=300, pos_dim=30, ner_dim=30, hidden_dim=200, num_layers=2, input_dropout=0.0, gcn_dropout=0.0,
+               word_dropout=0.0, prune_k=K, pooling="max", mlp_layers=2, rnn=True, rnn_hidden=200, rnn_layers=1, rnn_dropout=0.0,
+               dataset="tacred", num_class=42, topn=10 ** 9, cuda=True, conv_l2=0.0, pooling_l2=0.003, adj_type="regular")
+    torch.manual_seed(5)
+    model = gcn.GCNClassifier(opt).to(dev).train()
+    tb = synthetic.random_tree_batch(61, B, T, "tacred")
+    rng = np.random.RandomState(62)
+    words = rng.randint(2, 500, size=(B, T)) * ~tb["masks"]
+    pos = rng.randint(2, 40, size=(B, T)) * ~tb["masks"]
+    ner = rng.randint(2, 8, size=(B, T)) * ~tb["masks"]
+    inputs = (_t(words, dev), _t(tb["masks"], dev), _t(pos, dev), _t(ner, dev), _t(tb["deprel"], dev), _t(tb["head"], dev),
+              _t(tb["subj_pos"], dev), _t(tb["obj_pos"], dev))
+    seen = {}
+
+    def keep_input(mod, args, out):
+        out.retain_grad()
+        seen["x"] = out
+
+    def keep_output(mod, args, out):
+        out[0].retain_grad()
+        seen["h"] = out[0]
+    h1 = model.gcn_model.gcn.rnn_drop.register_forward_hook(keep_input)
+    h2 = model.gcn_model.gcn.register_forward_hook(keep_output)
+    logits, pooled = model(inputs)
+    loss = torch.nn.functional.cross_entropy(logits, _t(rng.randint(0, 42, size=B), dev)) + 0.003 * (pooled ** 2).sum(1).mean()
+    loss.backward()
+    h1.remove()
+    h2.remove()
+    torch.cuda.synchronize()
+    x, h = seen["x"], seen["h"]
+    assert tuple(x.shape) == (B, T, 400) and tuple(h.shape) == (B, T, 200)
+    W = model.gcn_model.gcn.W
+    Ws = [W[l].weight.detach().cpu().numpy() for l in range(2)]
+    bs = [W[l].bias.detach().cpu().numpy() for l in range(2)]
+    adj = prune_ref.batch_adj(tb["head"], tb["subj_pos"], tb["obj_pos"], tb["deprel"], tb["lens"], K)["adj"]
+    xn, gyn = x.detach().cpu().numpy(), h.grad.cpu().numpy()
+    href, _ = gcn_ref.gcn_forward(adj, xn, Ws, bs)
+    assert max_rel(h.detach().cpu().numpy(), href) <= FWD_RTOL
+    assert np.abs(gyn).max() > 0
+    dx, dWs, dbs = gcn_ref.gcn_backward(adj, xn, Ws, bs, gyn, acts=[None, h.detach().cpu().numpy()] if False else None)
+    assert max_rel(x.grad.cpu().numpy(), dx) <= GRAD_RTOL
+    for l in range(2):
+        assert max_rel(W[l].weight.grad.cpu().numpy(), dWs[l]) <= GRAD_RTOL, l
+        assert max_rel(W[l].bias.grad.cpu().numpy(), dbs[l]) <= GRAD_RTOL, l
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in model.named_parameters() if "rnn" in n)

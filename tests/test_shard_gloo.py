@@ -77,6 +77,29 @@ def _dp_grads(rank, world, unequal):
         assert torch.allclose(p.grad, q.grad, atol=1e-6), (rank, (p.grad - q.grad).abs().max())
 
 
+def _dp_grads_after_set_to_none(rank, world):
+    """zero_grad(set_to_none=True) -- torch's default -- drops the aliases into the flat bucket; all_reduce() must notice."""
+    x, y = _data()
+    idx = [torch.arange(0, 5), torch.arange(5, 10)]
+    m = _model()
+    bucket = shard.FlatGradBucket(m.parameters())
+    for step in range(2):
+        m.zero_grad(set_to_none=True)                                         # after this p.grad is None: backward() makes fresh tensors
+        loss = ((m(x[idx[rank]]) - y[idx[rank]]) ** 2).sum(1).mean()
+        loss.backward()
+        assert all(p.grad.data_ptr() != v.data_ptr() for p, v in zip(bucket.params, bucket.views))
+        bucket.all_reduce(dist)
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views))
+    ref = _model()
+    ((ref(x) - y) ** 2).sum(1).mean().backward()
+    for p, q in zip(m.parameters(), ref.parameters()):
+        assert torch.allclose(p.grad, q.grad, atol=1e-6), (rank, (p.grad - q.grad).abs().max())
+
+
+def test_flat_bucket_survives_zero_grad_set_to_none():
+    _spawn(_dp_grads_after_set_to_none, 2)
+
+
 def test_flat_bucket_equals_single_process_equal_shards():
     _spawn(_dp_grads, 2, False)
 

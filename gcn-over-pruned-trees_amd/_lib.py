@@ -36,6 +36,8 @@ SIGNATURES = {
     "gcnpt_pack_trees": (_i, [_p] * 10 + [_i, _i, _i] + [_p] * 10 + [_i, _i, _p]),
     "gcnpt_pack_rows": (_i, [_p, _p, _i, _p, _i, _i, _i, _p]),
     "gcnpt_unpack_rows": (_i, [_p, _p, _i, _p, _i, _i, _i, _p]),
+    "gcnpt_full_agg_fwd": (_i, [_p] * 10 + [_i, _i, _i, _i, _p, _f, _u64, _p]),
+    "gcnpt_full_agg_bwd": (_i, [_p] * 9 + [_i, _i, _i, _i, _f, _p, _p, _p]),
     "gcnpt_pool3_fwd": (_i, [_p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "gcnpt_pool3_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i]),
     "gcnpt_diag_layer_fwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p, _f, _u64, _p]),

@@ -558,9 +558,13 @@ class GCN(nn.Module):
         """adj_type='full_deprel', gcn.py:296-388 + traverse_deprel / traverse_self_loop 400-434; fp32, or with
         opt['gcn_dtype']='bf16' the traversal's contraction on csrc/bilinear_kernels.hip (bf16 MFMA operands, fp32 accumulate).
         trav(x, e)[n] = sum_d e[n,d] (x[n] W3[d] + b3[d]) is only needed for tokens that sit in a pruned tree, so those are
-        compacted (one host sync for their number; none with CompactTrees, whose rows are those tokens already), their outer products e (x) x meet W3 as [D*Tin, H] in ONE library GEMM per
-        direction, and the results travel along the CSR entries of the device pruner (value ranges pick forward / reverse).
-        The reference materialises [B,T,D,Tin] for all tokens and multiplies dense [B,T,T] matrices instead."""
+        compacted (their number is read back together with the tree check's status word; with opt['gcn_check_trees']=False or
+        CompactTrees, whose rows are those tokens already, every row is traversed and there is no host sync at all).  In bf16 mode the
+        contraction runs on the hand-written kernels; in fp32 mode the outer products e (x) x meet W3 as [D*Tin, H] in ONE plain
+        library GEMM per direction.  Everything around it -- aggregation of the traversed rows over the forward / reverse entries of the
+        device pruner's CSR (picked by label range), edge dropout, the self-loop term, /(deg+1), ReLU, dropout -- is ONE kernel
+        (csrc/full_kernels.hip, gcnpt_full_agg_fwd / _bwd).  The reference materialises [B,T,D,Tin] for all tokens and multiplies
+        dense [B,T,T] matrices instead."""
         opt = self.opt
         trees = adj if isinstance(adj, PrunedTrees) else adj_to_csr(adj, want_label=True)
         if trees.label is None:
@@ -570,26 +574,19 @@ class GCN(nn.Module):
         dev = trees.device
         max_depth = opt.get('deprel_max_depth', 2)
         directed, self_loop = bool(opt.get('deprel_directed', False)), bool(opt.get('deprel_self_loop', True))
-        # CSR slots -> (row, column) token numbers; slots past a sentence's entries are invalid (no host sync)
-        rp = trees.row_ptr.view(B, T + 1).to(torch.int64)
-        slot = torch.arange(B * cap, device=dev).view(B, cap)
-        valid = (slot < rp[:, -1:]).view(-1)
-        base = (torch.arange(B, device=dev) * T).view(B, 1)
-        rows = (torch.searchsorted(rp[:, 1:].contiguous(), slot, right=True).clamp_(max=T - 1) + base).view(-1)
-        cols = (trees.col_idx.view(B, cap).to(torch.int64).clamp(0, T - 1) + base).view(-1)
-        lab = trees.label.view(-1)
-        fwd_e = valid & (lab > 0) & (lab < constant.DEPREL_FORWARD_BOUND)                        # gcn.py:308-311
-        rev_e = valid & (lab > constant.DEPREL_FORWARD_BOUND) & (lab < constant.DEPREL_REVERSE_BOUND)   # gcn.py:340-344
-        denom = (trees.ell.view(N, 8)[:, 0] + 1).to(torch.float32).unsqueeze(1)                  # gcn.py:261
-        if all_tokens:        # CompactTrees: the rows ARE the tokens of the pruned trees (plus a few empty slots): no compaction, no sync
-            tok = pos = torch.arange(N, device=dev)
+        if all_tokens or not opt.get('gcn_check_trees', True):
+            # no compaction, no sync: every row is traversed (CompactTrees: the rows ARE the tokens of the pruned trees)
+            tok = torch.arange(N, device=dev)
+            pos = tok.to(torch.int32)
         else:
             tok = torch.nonzero(~trees.pool_mask.view(-1)).squeeze(1)                            # tokens of the pruned trees
-            pos = torch.zeros((N,), dtype=torch.int64, device=dev)
-            pos[tok] = torch.arange(tok.numel(), device=dev)
+            pos = torch.full((N,), -1, dtype=torch.int32, device=dev)
+            pos[tok] = torch.arange(tok.numel(), device=dev, dtype=torch.int32)
+        M = int(tok.numel())
         deprel_tok = deprel.reshape(-1)[tok]
         b3 = self.W.bias.reshape(D, H)                                                            # gcn.py:303
         x = gcn_inputs.to(torch.float32)
+        ps, seeds, seed_dev = self._dropout_plan()
         for l in range(self.layers):
             Tin = x.shape[-1]
             if self.W.weight.shape[1] != Tin:       # the reference's einsum fails the same way when in_dim != mem_dim (layer 1)
@@ -599,32 +596,32 @@ class GCN(nn.Module):
             xf = x.reshape(N, Tin)
             xt = xf[tok]
             plain = l >= max_depth                                                                # gcn.py:323-324, 355-356, 371-374
-            agg = torch.zeros((N, H), dtype=torch.float32, device=dev)
-            for edges, shift, on in ((fwd_e, 0, True), (rev_e, constant.DEPREL_FORWARD_BOUND, not directed)):
-                if not on or tok.numel() == 0:
+            ys, keeps = [None, None], [None, None]
+            for k, (shift, on) in enumerate(((0, True), (constant.DEPREL_FORWARD_BOUND, not directed))):
+                if not on or M == 0:
                     continue
                 e = _embed(self.deprel_emb, deprel_tok + shift)
                 keep_prop = opt.get('deprel_keep_prop', 1.0)
                 if self.training and keep_prop < 1.0:                                             # maybe_forget_deprels, gcn.py:451-470
-                    kept = torch.empty((tok.numel(), 1), device=dev).bernoulli_(keep_prop) == 1
+                    kept = torch.empty((M, 1), device=dev).bernoulli_(keep_prop) == 1
                     e = torch.where(kept, e, torch.ones_like(e))
                 if plain:
                     e = torch.ones_like(e)
                 if self.compute_dtype == torch.bfloat16 and bilinear_supported(D, Tin, H):
-                    y = bilinear_traverse(xt, e, self.W.weight, self.W.bias)                      # hand-written MFMA contraction
-                else:
-                    y = torch.mm((e.unsqueeze(2) * xt.unsqueeze(1)).reshape(-1, D * Tin), Wk) + torch.mm(e, b3)     # gcn.py:408-414
-                w = edges.to(torch.float32)
+                    ys[k] = bilinear_traverse(xt, e, self.W.weight, self.W.bias)                  # hand-written MFMA contraction
+                else:                                                                             # one plain library GEMM, gcn.py:408-414
+                    ys[k] = torch.mm((e.unsqueeze(2) * xt.unsqueeze(1)).reshape(-1, D * Tin), Wk) + torch.mm(e, b3)
                 edge_keep = opt.get('edge_keep_prob', 1.0)
                 if self.training and edge_keep < 1.0:                                             # maybe_drop_edges, gcn.py:436-449
-                    w = w * torch.empty_like(w).bernoulli_(edge_keep)
-                agg.index_add_(0, rows, y[pos[cols]] * w.unsqueeze(1))                           # gcn.py:331, 362
-            if self_loop:                                                                         # gcn.py:366-385, 417-434
+                    keeps[k] = torch.empty((B * cap,), device=dev).bernoulli_(edge_keep).to(torch.uint8)
+            self_term = None
+            if self_loop:                                                                         # gcn.py:366-385, 417-434 (plain GEMMs)
                 se = torch.ones((D,), device=dev) if plain else self.deprel_emb.weight[constant.SELF_LOOP_INDEX]
-                agg = agg + torch.mm(xf, torch.mm(se.unsqueeze(0), self.W.weight.reshape(D, Tin * H)).reshape(Tin, H)) + torch.mv(b3.t(), se)
-            x = torch.relu(agg / denom).view(B, T, H)                                            # gcn.py:390-392
-            if l < self.layers - 1:
-                x = self.gcn_drop(x)                                                              # gcn.py:393
+                self_term = torch.mm(xf, torch.mm(se.unsqueeze(0), self.W.weight.reshape(D, Tin * H)).reshape(Tin, H)) + torch.mv(b3.t(), se)
+            if ys[0] is None:
+                ys[0] = torch.zeros((1, H), dtype=torch.float32, device=dev)                      # no token sits in a tree
+            x = _FullAggFn.apply(ys[0], ys[1], self_term, trees, pos, keeps[0], keeps[1], M if M > 0 else 0, ps[l], seeds[l], seed_dev)
+            x = x.view(B, T, H)
         return x, trees.pool_mask
 
     def forward(self, adj, inputs):
@@ -682,6 +679,42 @@ class GCN(nn.Module):
             return gcn_stack(x, Ws, bs, trees, ps, seeds, torch.float32, no_adj, seed_dev), trees.pool_mask
         x = gcn_layers(x, Ws, bs, trees, ps, seeds, self.compute_dtype, torch.float32, no_adj, seed_dev)
         return x, trees.pool_mask
+
+
+class _FullAggFn(torch.autograd.Function):
+    """Aggregation + self loop + /(deg+1) + ReLU + dropout of a full_deprel layer in one kernel (csrc/full_kernels.hip); reference
+    model/gcn.py:308-311, 331, 340-344, 362, 385, 390-393."""
+
+    @staticmethod
+    def forward(ctx, yf, yr, self_term, trees, pos, keep_f, keep_r, M, drop_p, seed, seed_dev):
+        B, T = trees.B, trees.T
+        H = yf.shape[1]
+        P = _lib.ptr
+        yf = yf.to(torch.float32).contiguous()
+        yr = yr.to(torch.float32).contiguous() if yr is not None else None
+        st = self_term.to(torch.float32).contiguous() if self_term is not None else None
+        out = torch.empty((B * T, H), dtype=torch.float32, device=yf.device)
+        _lib.check(_lib.lib().gcnpt_full_agg_fwd(_lib.stream(), P(yf), P(yr), P(st), P(pos), P(trees.row_ptr), P(trees.col_idx), P(trees.label),
+                                                 P(keep_f), P(keep_r), B, T, H, int(M), P(out), float(drop_p), int(seed), P(seed_dev)))
+        ctx.save_for_backward(out, pos, keep_f, keep_r)
+        ctx.trees, ctx.M, ctx.rows = trees, int(M), (yf.shape[0], yr is not None, st is not None)
+        ctx.scale = 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        out, pos, keep_f, keep_r = ctx.saved_tensors
+        trees = ctx.trees
+        B, T, H = trees.B, trees.T, out.shape[1]
+        rows, has_r, has_self = ctx.rows
+        P = _lib.ptr
+        g = g.to(torch.float32).contiguous()
+        dagg = torch.empty_like(out)
+        dyf = torch.zeros((rows, H), dtype=torch.float32, device=out.device)
+        dyr = torch.zeros((rows, H), dtype=torch.float32, device=out.device) if has_r else None
+        _lib.check(_lib.lib().gcnpt_full_agg_bwd(_lib.stream(), P(g), P(out), P(pos), P(trees.row_ptr), P(trees.col_idx), P(trees.label),
+                                                 P(keep_f), P(keep_r), B, T, H, ctx.M, ctx.scale, P(dagg), P(dyf), P(dyr)))
+        return dyf, dyr, (dagg if has_self else None), None, None, None, None, None, None, None, None
 
 
 class _BilinearFn(torch.autograd.Function):

@@ -348,6 +348,21 @@ int gcnpt_bilinear_de_planes(int M, int D, int Tin, int H);
 int gcnpt_bilinear_bwd_e(void* stream, const void* x, const float* gy, const void* w_img, int M, int D, int Tin, int H,
                          float* de_planes);
 
+/* ---- N3, the layer AROUND the traversal: model/gcn.py:308-311 + 331, 340-344 + 362 (aggregation of the traversed encodings over the
+ * forward / reverse edges, picked by value ranges of the labelled adjacency), 366-385 (self loop), 390-393 (normalise, ReLU, dropout) ----
+ *   out[r] = dropout(relu((sum_{k in row r, 0 < label_k < 42} keep_f[k] * yf[pos[col_k]] + sum_{k, 42 < label_k < 84} keep_r[k] * yr[pos[col_k]]
+ *                          + self_term[r]) / (deg[r] + 1)))
+ * yf / yr [dev] float32 [M,H]: the traversal of the M tokens that sit in a pruned tree (gcnpt_bilinear_fwd + bias term, or the host's GEMM);
+ * yr NULL = deprel_directed; pos [dev] int32 [B*T]: token -> its row of yf / yr; self_term [dev] float32 [B*T,H] or NULL; keep_f / keep_r
+ * [dev] uint8, one flag per CSR slot, or NULL (training-time edge dropout, gcn.py:436-449); row_ptr / col_idx / label as the pruner writes
+ * them.  gcnpt_full_agg_bwd: dagg [B*T,H] = dY * 1[y > 0] * scale / (deg + 1) (= the gradient of self_term) is written completely and
+ * ACCUMULATED into dyf / dyr [M,H] along the same entries (float atomics; the caller clears them). */
+int gcnpt_full_agg_fwd(void* stream, const float* yf, const float* yr, const float* self_term, const int32_t* pos, const int32_t* row_ptr,
+                       const int32_t* col_idx, const int32_t* label, const uint8_t* keep_f, const uint8_t* keep_r, int B, int T, int H, int M,
+                       float* out, float drop_p, uint64_t seed, const uint64_t* seed_dev);
+int gcnpt_full_agg_bwd(void* stream, const float* dy, const float* y, const int32_t* pos, const int32_t* row_ptr, const int32_t* col_idx,
+                       const int32_t* label, const uint8_t* keep_f, const uint8_t* keep_r, int B, int T, int H, int M, float scale,
+                       float* dagg, float* dyf, float* dyr);
 
 #ifdef __cplusplus
 }

@@ -110,11 +110,15 @@ struct WeightGradMulti {
 
 // WG_WAVES waves split a workgroup's k-steps: 4 when a layer has the launch to itself (its slices are short), 8 when several
 // layers share the CUs (twice the k-steps per workgroup: 8 waves still take them in ONE batch of loads each)
-template <typename CT, int WG_WAVES>
+// Block shape: (WG_MT x NT) output tiles per workgroup, KB k-steps of loads in flight per wave.  (4 x 3, 5) for small batches (one
+// latency chain per CU: as many loads in flight as the registers hold); (4 x 6, 2) for big ones, where the fragment stream through
+// the CU's L1 path is the bound: 10 fragment loads feed 24 MFMAs instead of 7 feeding 12.
+template <typename CT, int WG_WAVES, int NT, int KB>
 __global__ __launch_bounds__(WG_WAVES * WAVE, 2) void weight_grad_kernel(const WeightGradMulti mp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
-    typedef f32x4_t RedTile[WG_MT * WG_NT][WAVE];
-    RedTile* red = reinterpret_cast<RedTile*>(wg_smem);                                   // [WG_WAVES] per-wave partial tiles, 12 KiB each
+    constexpr int RT = WG_MT * NT, RH = RT > 12 ? RT / 2 : RT;                             // tiles reduced per LDS round (12 KiB per wave each)
+    typedef f32x4_t RedTile[RH][WAVE];
+    RedTile* red = reinterpret_cast<RedTile*>(wg_smem);                                   // [WG_WAVES] per-wave partial tiles
     typedef float DbTile[WG_MT][16];
     DbTile* dbred = reinterpret_cast<DbTile*>(wg_smem + sizeof(RedTile) * WG_WAVES);     // [WG_WAVES]
 
@@ -132,28 +136,28 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 2) void weight_grad_kernel(const W
     else                     { const int gp = 8 / p.slices;  slice = xg % p.slices;       blk = rest * gp + xg / p.slices; }
     if (blk >= p.mb * p.nb) return;
     const int bm = blk % p.mb, bn = blk / p.mb;
-    const int m0 = bm * WG_MT, n0 = bn * WG_NT;
+    const int m0 = bm * WG_MT, n0 = bn * NT;
     const int ks_lo = slice * p.ks_per_wg, ks_hi = min(p.nks, ks_lo + p.ks_per_wg);
     const bool want_db = bn == 0 && p.db != nullptr;
     GCNPT_STAMP_REAL(p.stamps);
     GCNPT_STAMP(p.stamps, 0);
 
-    f32x4_t acc[WG_MT][WG_NT];
+    f32x4_t acc[WG_MT][NT];
     float dbp[WG_MT];
 #pragma unroll
     for (int i = 0; i < WG_MT; ++i) {
         dbp[i] = 0.0f;
 #pragma unroll
-        for (int j = 0; j < WG_NT; ++j) acc[i][j] = (f32x4_t){0, 0, 0, 0};
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4_t){0, 0, 0, 0};
     }
 
     // Every load below is unconditional (clamped indices): a load behind a runtime condition gets its own basic
     // block and an s_waitcnt vmcnt(0) from hipcc, which would turn this batch into 35 serial round trips.
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
-    for (int base = ks_lo + wave; base < ks_hi; base += WG_WAVES * WG_KB) {
-        uint4 a[WG_KB][WG_MT], b[WG_KB][WG_NT];
+    for (int base = ks_lo + wave; base < ks_hi; base += WG_WAVES * KB) {
+        uint4 a[KB][WG_MT], b[KB][NT];
 #pragma unroll
-        for (int u = 0; u < WG_KB; ++u) {
+        for (int u = 0; u < KB; ++u) {
             int ks = min(base + WG_WAVES * u, p.nks - 1);
 #ifdef GCNPT_STAMPS
             if (p.knob & 2) ks = 0;                                       // experiment: every load hits the same lines
@@ -161,10 +165,10 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 2) void weight_grad_kernel(const W
 #pragma unroll
             for (int i = 0; i < WG_MT; ++i) a[u][i] = p.zf[((size_t)min(m0 + i, p.m_tiles - 1) * p.nks + ks) * 64 + lane];
 #pragma unroll
-            for (int j = 0; j < WG_NT; ++j) b[u][j] = p.sf[((size_t)min(n0 + j, p.n_tiles - 1) * p.nks + ks) * 64 + lane];
+            for (int j = 0; j < NT; ++j) b[u][j] = p.sf[((size_t)min(n0 + j, p.n_tiles - 1) * p.nks + ks) * 64 + lane];
         }
 #pragma unroll
-        for (int u = 0; u < WG_KB; ++u) {
+        for (int u = 0; u < KB; ++u) {
             const bool live = base + WG_WAVES * u < ks_hi;                       // past the slice: contributes zeros
 #pragma unroll
             for (int i = 0; i < WG_MT; ++i) {
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 2) void weight_grad_kernel(const W
                 // summing only in the blocks that store db (a branch here makes every wait in the batch a full drain, +1.8 us)
                 dbp[i] += frag_sum<CT>(av);
 #pragma unroll
-                for (int j = 0; j < WG_NT; ++j) {
+                for (int j = 0; j < NT; ++j) {
                     if constexpr (sizeof(CT) == 2) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, av),
                                                                              __builtin_bit_cast(bf16x8_t, b[u][j]), acc[i][j], 0, 0, 0);
@@ -190,11 +194,7 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 2) void weight_grad_kernel(const W
     }
 
     GCNPT_STAMP(p.stamps, 1);
-    // waves meet in LDS; wave w then owns tiles w, w+4, w+8 of the block
-#pragma unroll
-    for (int i = 0; i < WG_MT; ++i)
-#pragma unroll
-        for (int j = 0; j < WG_NT; ++j) red[wave][i * WG_NT + j][lane] = acc[i][j];
+    // waves meet in LDS (RH tiles per round); wave w then owns tiles w, w + WG_WAVES, ... of the round
     if (want_db) {
 #pragma unroll
         for (int i = 0; i < WG_MT; ++i) {
@@ -204,22 +204,34 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 2) void weight_grad_kernel(const W
             if (lane < 16) dbred[wave][i][lane] = v;
         }
     }
-    __syncthreads();
-    GCNPT_STAMP(p.stamps, 2);
-    for (int tt = wave; tt < WG_MT * WG_NT; tt += WG_WAVES) {
-        const int i = tt / WG_NT, j = tt - i * WG_NT;
-        if (m0 + i >= p.m_tiles || n0 + j >= p.n_tiles) continue;
-        f32x4_t v = red[0][tt][lane];
 #pragma unroll
-        for (int w = 1; w < WG_WAVES; ++w) v += red[w][tt][lane];
+    for (int r0t = 0; r0t < RT; r0t += RH) {
+        if (r0t > 0) __syncthreads();
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int m = (m0 + i) * 16 + (lane >> 4) * 4 + g;
-            const int n = (n0 + j) * 16 + (lane & 15);
+        for (int i = 0; i < WG_MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int tt = i * NT + j;                                   // compile-time after unrolling
+                if (tt >= r0t && tt < r0t + RH) red[wave][tt - r0t][lane] = acc[i][j];
+            }
+        __syncthreads();
+        if (r0t == 0) GCNPT_STAMP(p.stamps, 2);
+        for (int tl = wave; tl < RH; tl += WG_WAVES) {
+            const int tt = r0t + tl;
+            const int i = tt / NT, j = tt - i * NT;
+            if (m0 + i >= p.m_tiles || n0 + j >= p.n_tiles) continue;
+            f32x4_t v = red[0][tl][lane];
+#pragma unroll
+            for (int w = 1; w < WG_WAVES; ++w) v += red[w][tl][lane];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int m = (m0 + i) * 16 + (lane >> 4) * 4 + g;
+                const int n = (n0 + j) * 16 + (lane & 15);
 #ifdef GCNPT_STAMPS
-            if (p.knob & 4) { if (m < p.H && n < p.Din) p.dW[(size_t)m * p.Din + n] = v[g]; continue; }     // experiment: stores for atomics
+                if (p.knob & 4) { if (m < p.H && n < p.Din) p.dW[(size_t)m * p.Din + n] = v[g]; continue; }     // experiment: stores for atomics
 #endif
-            if (m < p.H && n < p.Din) atomicAdd(p.dW + (size_t)m * p.Din + n, v[g]);
+                if (m < p.H && n < p.Din) atomicAdd(p.dW + (size_t)m * p.Din + n, v[g]);
+            }
         }
     }
     if (want_db && tid < WG_MT * 16) {
@@ -287,14 +299,14 @@ extern "C" size_t gcnpt_frag_bytes(int rows, int width, int dtype) {
 
 // fills p for one layer; returns the number of workgroups it takes (a multiple of 8)
 static int plan_weight_grad(WeightGradParams& p, const void* z_frag, const void* s_frag, int nks, int Din, int H, float* dW, float* db,
-                            int blocks_in_launch, int waves, int wg_budget) {
+                            int blocks_in_launch, int waves, int wg_budget, int nt) {
     p = WeightGradParams{};
     p.stamps = static_cast<unsigned long long*>(g_debug_stamps); p.knob = g_debug_knob;
     p.zf = static_cast<const uint4*>(z_frag); p.sf = static_cast<const uint4*>(s_frag);
     p.dW = dW; p.db = db; p.H = H; p.Din = Din;
     p.m_tiles = ceil_div(H, 16); p.n_tiles = ceil_div(Din, 16);
     p.nks = nks;
-    const int mb = ceil_div(p.m_tiles, WG_MT), nb = ceil_div(p.n_tiles, WG_NT);
+    const int mb = ceil_div(p.m_tiles, WG_MT), nb = ceil_div(p.n_tiles, nt);
     // split the contraction so that the launch as a whole has ~256 workgroups, one per CU (the layers of a launch share
     // them: measured 2 us faster per step than letting each layer bring 256 of its own), with at least one k-step per wave;
     // slices is 1, 2, 4 or a multiple of 8 so that each slice maps onto whole XCD groups (rounded DOWN: one more
@@ -309,11 +321,11 @@ static int plan_weight_grad(WeightGradParams& p, const void* z_frag, const void*
     return 8 * per_group;
 }
 
-template <typename CT, int NW>
+template <typename CT, int NW, int NT, int KB>
 static int launch_weight_grad_cfg(hipStream_t s, const WeightGradMulti& mp) {
-    const size_t lds = (sizeof(f32x4_t) * WG_MT * WG_NT * WAVE + sizeof(float) * WG_MT * 16) * NW;      // 49 / 98 KiB
-    GCNPT_LDS_ATTR_ONCE((weight_grad_kernel<CT, NW>), 160 * 1024);
-    hipLaunchKernelGGL((weight_grad_kernel<CT, NW>), dim3(mp.first[mp.n]), dim3(NW * WAVE), lds, s, mp);
+    const size_t lds = (sizeof(f32x4_t) * 12 * WAVE + sizeof(float) * WG_MT * 16) * NW;      // 49 / 98 KiB
+    GCNPT_LDS_ATTR_ONCE((weight_grad_kernel<CT, NW, NT, KB>), 160 * 1024);
+    hipLaunchKernelGGL((weight_grad_kernel<CT, NW, NT, KB>), dim3(mp.first[mp.n]), dim3(NW * WAVE), lds, s, mp);
     GCNPT_HIP_CHECK(hipGetLastError());
     return GCNPT_OK;
 }
@@ -323,15 +335,20 @@ static int launch_weight_grad_cfg(hipStream_t s, const WeightGradMulti& mp) {
 static int wg_waves(int n_layers, int nks) { return (n_layers > 1 && nks < 512) ? 8 : 4; }
 static int wg_budget(int nks) { return nks < 512 ? 256 : 512; }
 // (4 x 3)-tile blocks of all layers of a launch: the budget is shared in proportion to them, so every workgroup gets the same k-steps
-static int wg_blocks(int n_layers, const int* Din, const int* H) {
+static int wg_nt(int nks) { return nks < 512 ? WG_NT : 6; }       // output tiles per block row: wide blocks for big batches (see the kernel)
+static int wg_blocks(int n_layers, const int* Din, const int* H, int nt) {
     int b = 0;
-    for (int l = 0; l < n_layers; ++l) b += ceil_div(ceil_div(H[l], 16), WG_MT) * ceil_div(ceil_div(Din[l], 16), WG_NT);
+    for (int l = 0; l < n_layers; ++l) b += ceil_div(ceil_div(H[l], 16), WG_MT) * ceil_div(ceil_div(Din[l], 16), nt);
     return b;
 }
 
-static int launch_weight_grad(hipStream_t s, const WeightGradMulti& mp, int compute_dtype, int waves) {
-    if (compute_dtype == GCNPT_BF16) return waves == 8 ? launch_weight_grad_cfg<bf16_t, 8>(s, mp) : launch_weight_grad_cfg<bf16_t, 4>(s, mp);
-    return waves == 8 ? launch_weight_grad_cfg<float, 8>(s, mp) : launch_weight_grad_cfg<float, 4>(s, mp);
+static int launch_weight_grad(hipStream_t s, const WeightGradMulti& mp, int compute_dtype, int waves, int nt) {
+    if (compute_dtype == GCNPT_BF16) {
+        if (nt == 6) return launch_weight_grad_cfg<bf16_t, 4, 6, 2>(s, mp);
+        return waves == 8 ? launch_weight_grad_cfg<bf16_t, 8, WG_NT, WG_KB>(s, mp) : launch_weight_grad_cfg<bf16_t, 4, WG_NT, WG_KB>(s, mp);
+    }
+    if (nt == 6) return launch_weight_grad_cfg<float, 4, 6, 2>(s, mp);
+    return waves == 8 ? launch_weight_grad_cfg<float, 8, WG_NT, WG_KB>(s, mp) : launch_weight_grad_cfg<float, 4, WG_NT, WG_KB>(s, mp);
 }
 
 extern "C" int gcnpt_layer_bwd_weight_multi(void* stream, int n_layers, const void* const* z_frag, const void* const* s_frag,
@@ -348,9 +365,9 @@ extern "C" int gcnpt_layer_bwd_weight_multi(void* stream, int n_layers, const vo
         GCNPT_REQUIRE(z_frag[l] && s_frag[l] && dW[l] && db[l], "layer_bwd_weight: null pointer (layer %d)", l);
         GCNPT_REQUIRE(Din[l] > 0 && H[l] > 0, "layer_bwd_weight: sizes must be positive (layer %d)", l);
         mp.first[l + 1] = mp.first[l] + plan_weight_grad(mp.l[l], z_frag[l], s_frag[l], nks, Din[l], H[l], dW[l], db[l],
-                                                         wg_blocks(n_layers, Din, H), wg_waves(n_layers, nks), wg_budget(nks));
+                                                         wg_blocks(n_layers, Din, H, wg_nt(nks)), wg_waves(n_layers, nks), wg_budget(nks), wg_nt(nks));
     }
-    return launch_weight_grad((hipStream_t)stream, mp, compute_dtype, wg_waves(n_layers, nks));
+    return launch_weight_grad((hipStream_t)stream, mp, compute_dtype, wg_waves(n_layers, nks), wg_nt(nks));
 }
 
 extern "C" int gcnpt_layer_bwd_weight(void* stream, const void* z_frag, const void* s_frag, int B, int T, int Din, int H,
@@ -371,7 +388,7 @@ extern "C" int gcnpt_stack_bwd_weight(void* stream, int n_layers, const void* co
         GCNPT_REQUIRE(g_frag[l] && h_frag[l] && dW[l], "stack_bwd_weight: null pointer (layer %d)", l);
         const int din_l[1] = {l == 0 ? Din : H}, h_l[1] = {H};
         mp.first[l + 1] = mp.first[l] + plan_weight_grad(mp.l[l], g_frag[l], h_frag[l], nks, l == 0 ? Din : H, H, dW[l], nullptr,
-                                                         n_layers * wg_blocks(1, din_l, h_l), wg_waves(n_layers, nks), wg_budget(nks));
+                                                         n_layers * wg_blocks(1, din_l, h_l, wg_nt(nks)), wg_waves(n_layers, nks), wg_budget(nks), wg_nt(nks));
     }
-    return launch_weight_grad((hipStream_t)stream, mp, GCNPT_BF16, wg_waves(n_layers, nks));
+    return launch_weight_grad((hipStream_t)stream, mp, GCNPT_BF16, wg_waves(n_layers, nks), wg_nt(nks));
 }

@@ -18,34 +18,35 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 
 def short(name):
-    m = re.search(r"(rowtile_kernel<[^>]*>|weight_grad_kernel<[^>]*>|pack_weights_kernel<[^>]*>|prune_to_csr_kernel)", name)
+    m = re.search(r"(rowtile_kernel<[^>]*>|weight_grad_kernel<[^>]*>|pack_weights_kernel<[^>]*>|prune_to_csr_kernel|fused_fwd_kernel<[^>]*>)", name)
     return (m.group(1) if m else name[:50]).replace("unsigned short", "bf16")
 
 
 def bench_names(rows):
-    """Map dispatches to bench.py kernel names by template name and order inside a step."""
+    """Map dispatches to bench.py kernel names by template arguments: rowtile_kernel<CT, IT, OT, BWD, VEC, NTW, KSMAX, DZIN>."""
     seen = collections.Counter()
     out = []
     for r in rows:
         n = short(r["Kernel_Name"])
-        if n.startswith("rowtile") and ", false," in n:
-            k = "fwd%d" % (seen["fwd"] % 2); seen["fwd"] += 1
-        elif n.startswith("rowtile") and ", 3, " in n:
-            k = "bwd_data0"
-        elif n.startswith("rowtile"):
-            k = "bwd_data1"
+        k = None
+        if n.startswith("rowtile"):
+            args = [a.strip() for a in n[n.index("<") + 1:n.rindex(">")].split(",")]
+            bwd, dzin = args[3] == "true", args[-1] == "true"
+            if not bwd:
+                k = "fwd%d" % (seen["fwd"] % 2)
+                seen["fwd"] += 1
+            else:
+                k = "bwd_data0" if dzin else "bwd_data1"          # the top layer derives dZ itself, the layer below receives it
         elif n.startswith("weight_grad"):
             k = "bwd_weight"                                   # one launch per step serves both layers
         elif n.startswith("pack"):
             k = "pack"
         elif n.startswith("prune"):
             k = "prune"
-        else:
-            k = None
         out.append(k)
     return out
 
@@ -76,6 +77,10 @@ if stats:
 stats = glob.glob(os.path.join(SRC, "trace_graph", "*", "*kernel_stats.csv"))
 if stats:
     shutil.copy(max(stats, key=os.path.getmtime), os.path.join(ROOT, "profiles", "%s_kernel_stats_graph.csv" % tag))
+for run, name in (("trace_c5", "c5_kernel_stats"), ("trace_c5_packed", "c5_packed_kernel_stats")):
+    stats = glob.glob(os.path.join(SRC, run, "*", "*kernel_stats.csv"))
+    if stats:
+        shutil.copy(max(stats, key=os.path.getmtime), os.path.join(ROOT, "profiles", "%s_%s.csv" % (tag, name)))
 merged = collections.defaultdict(dict)
 for run in ("fetch", "write", "sq", "mfma"):
     for k, cs in per_kernel(run).items():
@@ -88,7 +93,11 @@ with open(os.path.join(ROOT, "profiles", "%s_pmc_per_kernel.csv" % tag), "w") as
         w.writerow([k] + ["%.1f" % merged[k][c] if c in merged[k] else "" for c in cols])
 traffic = {k: int(2 * cs.get("FETCH_SIZE", 0) * 1024 + cs.get("WRITE_SIZE", 0) * 1024)
            for k, cs in merged.items() if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs}
-json.dump(traffic, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+# bench.py quotes these bytes only for the workload they were recorded on (tools/profile_round.sh profiles the default bench command)
+sha = os.popen("git -C %s rev-parse --short HEAD 2>/dev/null" % ROOT).read().strip() or "?"
+meta = dict(batch=50, seq=100, din=360, hidden=200, prune_k=1, dtype="bf16", lengths="full",
+            kernels=["pack", "fwd0", "fwd1", "bwd_data1", "bwd_data0", "bwd_weight"], git_sha="%s (%s)" % (sha, tag))
+json.dump(dict(meta=meta, traffic=traffic), open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(traffic))
 for k in sorted(merged):
     cs = merged[k]

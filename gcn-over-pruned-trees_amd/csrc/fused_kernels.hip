@@ -96,25 +96,6 @@ __device__ __forceinline__ uint4 pack_bf16x8(const float (&v)[8]) {
     return u;
 }
 
-// the tile's 32 rows of an LDS bf16 tile X (stride in elements) as a fragment image (include/gcnpt.h): row-contraction
-// operand of the weight gradient, 8 consecutive rows per lane, read transposed with ds_read_b64_tr_b16
-__device__ __forceinline__ void emit_frag_image(uint4* F, const bf16_t* X, int stride, int width, int wave, int lane, size_t nks, size_t blk) {
-    const int w_tiles = ceil_div(width, 16);
-    const int i = lane & 15, g = lane >> 4, q4 = i >> 2, pp = i & 3;
-    for (int t = wave; t < w_tiles; t += FU_WAVES) {
-        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4_t*)(X + (size_t)(8 * g + q4) * stride + 16 * t + 4 * pp));
-        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4_t*)(X + (size_t)(8 * g + 4 + q4) * stride + 16 * t + 4 * pp));
-        uint4 u;
-        u.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
-        u.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
-        u.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
-        u.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
-        F[((size_t)t * nks + blk) * 64 + lane] = u;
-    }
-}
-
 // =====================================================================================================
 // forward: h1 = layer0(x), h2 = layer1(h1)
 // =====================================================================================================
@@ -346,7 +327,7 @@ __global__ __launch_bounds__(FU_THREADS, 2) void fused_fwd_kernel(const FusedPar
         GCNPT_STAMP(p.stamps, 4);
         __syncthreads();
         GCNPT_STAMP(p.stamps, 5);
-        if (p.fragA) emit_frag_image(p.fragA, S, L.strideA, p.KA, wave, lane, gridDim.x, blockIdx.x);
+        if (p.fragA) emit_frag_image(p.fragA, S, L.strideA, p.KA, wave, FU_WAVES, lane, gridDim.x, blockIdx.x);
         GCNPT_STAMP(p.stamps, 6);
         // MFMA with swapped operands (weights as A): a lane ends up with 4 consecutive output columns of one row
         const int n_mt = ceil_div(min(FU_PASS, n_list), 16);
@@ -467,7 +448,7 @@ __global__ __launch_bounds__(FU_THREADS, 2) void fused_fwd_kernel(const FusedPar
     }
     __syncthreads();
     GCNPT_STAMP(p.stamps, 10);
-    if (p.fragB) emit_frag_image(p.fragB, S1, L.strideB, p.KB, wave, lane, gridDim.x, blockIdx.x);
+    if (p.fragB) emit_frag_image(p.fragB, S1, L.strideB, p.KB, wave, FU_WAVES, lane, gridDim.x, blockIdx.x);
     GCNPT_STAMP(p.stamps, 11);
     {
         f32x4_t acc[2][FU_NTW];

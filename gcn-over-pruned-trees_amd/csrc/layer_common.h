@@ -194,6 +194,25 @@ template <typename T> struct dgio<T, 1> {    // any H / alignment: `n` = 1 when 
     static __device__ __forceinline__ void st(T* p, int n, const float (&v)[1]) { if (n) io<T>::store1(p, v[0]); }
 };
 
+// the tile's 32 rows of an LDS bf16 tile X (stride in elements) as a fragment image (include/gcnpt.h): row-contraction
+// operand of the weight gradient, 8 consecutive rows per lane, read transposed with ds_read_b64_tr_b16
+__device__ __forceinline__ void emit_frag_image(uint4* F, const bf16_t* X, int stride, int width, int wave, int n_waves, int lane, size_t nks, size_t blk) {
+    const int w_tiles = ceil_div(width, 16);
+    const int i = lane & 15, g = lane >> 4, q4 = i >> 2, pp = i & 3;
+    for (int t = wave; t < w_tiles; t += n_waves) {
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4_t*)(X + (size_t)(8 * g + q4) * stride + 16 * t + 4 * pp));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4_t*)(X + (size_t)(8 * g + 4 + q4) * stride + 16 * t + 4 * pp));
+        uint4 u;
+        u.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
+        u.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
+        u.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
+        u.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
+        F[((size_t)t * nks + blk) * 64 + lane] = u;
+    }
+}
+
 // host-side argument helpers of the C-ABI wrappers
 // rows of a batch: B sentences padded to T tokens, or -- T = 0 -- B token-packed rows whose pattern has absolute columns (include/gcnpt.h)
 static inline long long rows_of(int B, int T) { return T > 0 ? (long long)B * T : (long long)B; }

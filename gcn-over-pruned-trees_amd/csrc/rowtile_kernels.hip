@@ -641,6 +641,17 @@ static int dispatch_rowtile(hipStream_t s, const RowTileParams& p, int in_dtype,
     return launch_rowtile<bf16_t, bf16_t, bf16_t, BWD, DZIN>(s, p);
 }
 
+// big batches: the streaming kernels of rowstream_kernels.hip (1 = taken, 0 = does not apply, < 0 = error)
+int rowstream_try_fwd(hipStream_t s, const void* h, int h_dtype, const void* w_fwd, const float* bias, const int32_t* row_ptr,
+                      const int32_t* col_idx, const int32_t* ell, const int32_t* deg_ell, int N, int T, int Din, int H, void* out,
+                      int out_dtype, float drop_p, uint64_t seed, void* s_frag, const uint64_t* seed_dev, int vec_in, int vec_out);
+int rowstream_try_bwd(hipStream_t s, const void* dZ, int g_dtype, const void* w_bwd, const int32_t* ell, const int32_t* rowT_ptr,
+                      const int32_t* colT_idx, const int32_t* ellT, int N, int T, int Din, int H, void* dh, int dh_dtype, float* zero_dW,
+                      float* zero_db, const void* relu_src, float next_scale, int vec_in, int vec_out);
+bool rowstream_enabled();
+int launch_dz_rows(hipStream_t s, const void* dY, const void* Y, int dtype, const int32_t* ell, int N, int H, float scale, void* dz, void* z_frag,
+                   int mask);
+
 extern "C" int gcnpt_layer_fwd(void* stream, const void* h, int h_dtype, const void* w_fwd, const float* bias,
                                const int32_t* row_ptr, const int32_t* col_idx, const int32_t* ell, const int32_t* deg_ell,
                                int B, int T, int Din, int H, void* out, int out_dtype, int compute_dtype, float drop_p,
@@ -661,6 +672,11 @@ extern "C" int gcnpt_layer_fwd(void* stream, const void* h, int h_dtype, const v
     p.drop_p = drop_p; p.scale = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
     p.drop_thresh16 = (unsigned)((double)drop_p * 65536.0);
     p.seed = seed; p.seed_dev = seed_dev;
+    if (compute_dtype == GCNPT_BF16) {
+        const int rc = rowstream_try_fwd((hipStream_t)stream, h, h_dtype, w_fwd, bias, row_ptr, col_idx, ell, deg_ell, p.N, T, Din, H, out, out_dtype,
+                                         drop_p, seed, s_frag, seed_dev, p.vec_in, p.vec_out);
+        if (rc != 0) return rc < 0 ? rc : GCNPT_OK;
+    }
     return dispatch_rowtile<false>((hipStream_t)stream, p, h_dtype, out_dtype, compute_dtype);
 }
 
@@ -686,6 +702,13 @@ extern "C" int gcnpt_layer_bwd_data(void* stream, const void* dY, const void* Y,
     p.vec_out = dh ? vec_bytes(Din, esize(dh_dtype), dh, relu_src) : 0;
     p.scale = scale; p.drop_p = 0.0f;
     p.relu_src = relu_src; p.next_scale = next_scale;
+    if (src_is_dz && compute_dtype == GCNPT_BF16 && dh) {
+        const int rc = rowstream_try_bwd((hipStream_t)stream, dY, g_dtype, w_bwd, ell, rowT_ptr, colT_idx, ellT, p.N, T, Din, H, dh, dh_dtype, zero_dW,
+                                         zero_db, relu_src, next_scale, p.vec_in, p.vec_out);
+        if (rc < 0) return rc;
+        if (rc == 1)       // the streaming kernel does not keep its input rows in LDS: their fragment image comes from a re-layout pass
+            return z_frag ? launch_dz_rows((hipStream_t)stream, dY, nullptr, g_dtype, ell, p.N, H, 1.0f, nullptr, z_frag, 0) : GCNPT_OK;
+    }
     if (src_is_dz) return dispatch_rowtile<true, true>((hipStream_t)stream, p, g_dtype, dh_dtype, compute_dtype);
     return dispatch_rowtile<true>((hipStream_t)stream, p, g_dtype, dh_dtype, compute_dtype);
 }
@@ -730,7 +753,28 @@ extern "C" int gcnpt_layers_bwd(void* stream, int n_layers, const void* gy, cons
         GCNPT_REQUIRE(dh[l] && dh_dtype[l] == y_dtype[l - 1], "layers_bwd: dh[%d] must exist and have the dtype of Y[%d]", l, l - 1);
     }
     const void* g = gy;
+    // Big batches: the top layer's dZ = gy * 1[Y > 0] * scale / (deg + 1) is written out once (into the memory of dh[0], which is only
+    // written by the LAST launch of the sweep and is at least as large) so that the top layer, too, gathers ready-made rows on the
+    // streaming kernel (rowstream_kernels.hip) instead of deriving three loads per neighbour
+    const int top = n_layers - 1;
+    bool top_is_dz = false;
+    if (rowstream_enabled() && n_layers >= 2 && compute_dtype == GCNPT_BF16 && rows_of(B, T) >= 16384 && dh[0] && dh[top] &&
+        (size_t)Din[0] * esize(dh_dtype[0]) >= (size_t)H[top] * esize(y_dtype[top]) && aligned16(dh[0])) {
+        const int rc = launch_dz_rows((hipStream_t)stream, gy, Y[top], y_dtype[top], ell, (int)rows_of(B, T), H[top], scale[top], dh[0],
+                                      z_frag ? z_frag[top] : nullptr, 1);
+        if (rc != GCNPT_OK) return rc;
+        g = dh[0];
+        top_is_dz = true;
+    }
     for (int l = n_layers - 1; l >= 0; --l) {
+        if (l == top && top_is_dz) {
+            const int rc = gcnpt_layer_bwd_data(stream, g, Y[l], y_dtype[l], w_bwd[l], ell, rowT_ptr, colT_idx, ellT, B, T, Din[l], H[l], dh[l],
+                                                dh_dtype[l], compute_dtype, scale[l], nullptr, z_frag ? dW[l] : nullptr, z_frag ? db[l] : nullptr,
+                                                Y[l - 1], scale[l - 1], 1);
+            if (rc != GCNPT_OK) return rc;
+            g = dh[l];
+            continue;
+        }
         if (dh[l] || z_frag) {
             // every layer but the bottom one hands the layer below its dZ ready-made (dh[l] then holds dZ of layer l-1), and every
             // layer but the top one receives it: one load per neighbour in the gather instead of three

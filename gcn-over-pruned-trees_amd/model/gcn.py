@@ -16,7 +16,7 @@ direction, reached through the C-ABI of include/gcnpt.h.  Embeddings, the option
 the output MLP stay ordinary PyTorch-ROCm modules, as in the reference.
 
 New optional `opt` keys (defaults reproduce the reference): `gcn_dtype` = 'fp32' | 'bf16' (MFMA operand /
-activation storage type inside the layer stack), `gcn_fused` = False (bf16 only: run the whole stack with the
+activation storage type inside the layer stack), `gcn_fused` (bf16 only, default: batches of >= 256 sentences: run the whole stack with the
 sentence-resident one-launch-per-direction kernels when the shape fits; slower than one launch per layer at B=50), `gcn_check_trees` = True (synchronise once per forward to
 raise on malformed trees the way the reference does; False keeps the step free of host syncs), `gcn_packed` = False (True: the
 layer loop runs on token-packed rows, sum(len) instead of B*T, padding only at the module boundary), `gcn_graph_rng` = False
@@ -152,11 +152,20 @@ class _GCNLayersFn(torch.autograd.Function):
         w32 = [w.detach().to(torch.float32).contiguous() for w in Ws]
         b32 = [b.detach().to(torch.float32).contiguous() for b in bs]
         u8 = dict(dtype=torch.uint8, device=dev)
-        wf = [torch.empty((lib.gcnpt_packed_bytes(h, k, compute),), **u8) for h, k in dims]
-        wb = [torch.empty((lib.gcnpt_packed_bytes(k, h, compute),), **u8) for h, k in dims]
         ints = lambda v: (ctypes.c_int * L)(*v)  # noqa: E731
-        _lib.check(lib.gcnpt_pack_weights_multi(st, L, _lib.ptr_array(w32), ints([h for h, _ in dims]), ints([k for _, k in dims]),
-                                                compute, _lib.ptr_array(wf), _lib.ptr_array(wb)))
+        # the fragment-order images only change when an optimizer step (or a load_state_dict) rewrites a weight in place, which bumps
+        # the tensor's version counter: a module passes its cache and eval() / gradient-accumulation forwards skip the pack launch
+        cache = None if torch.cuda.is_current_stream_capturing() else cfg.get("wcache")     # (a captured step must contain its pack)
+        key = (compute, str(dev)) + tuple((w.data_ptr(), w._version, tuple(w.shape)) for w in Ws)
+        if cache is not None and cache.get("key") == key:
+            wf, wb = cache["wf"], cache["wb"]
+        else:
+            wf = [torch.empty((lib.gcnpt_packed_bytes(h, k, compute),), **u8) for h, k in dims]
+            wb = [torch.empty((lib.gcnpt_packed_bytes(k, h, compute),), **u8) for h, k in dims]
+            _lib.check(lib.gcnpt_pack_weights_multi(st, L, _lib.ptr_array(w32), ints([h for h, _ in dims]), ints([k for _, k in dims]),
+                                                    compute, _lib.ptr_array(wf), _lib.ptr_array(wb)))
+            if cache is not None:
+                cache.update(key=key, wf=wf, wb=wb)
         need_w = any(p.requires_grad for p in params)
         g_ell = trees.empty_ell() if cfg["no_adj"] else trees.ell
         outs = [torch.empty(lead + (H,), dtype=cfg["out_dtype"] if l == L - 1 else cfg["mid_dtype"], device=dev) for l, (H, _) in enumerate(dims)]
@@ -212,11 +221,12 @@ class _GCNLayersFn(torch.autograd.Function):
 
 
 def gcn_layers(x, weights, biases, trees, drop_p=None, seeds=None, compute_dtype=torch.float32, out_dtype=torch.float32, no_adj=False,
-               seed_dev=None):
+               seed_dev=None, wcache=None):
     """
     The reference's whole layer loop (model/gcn.py:266-393) over the per-layer kernels.  x [B,T,Din] float32/bfloat16 CUDA;
     weights / biases: lists of the nn.Linear parameters (any widths that chain); drop_p[l]: dropout applied to the output of
-    layer l (0 for the last).  compute_dtype float32 = exact fp32 MFMA (activations stay float32), bfloat16 = bf16 operands
+    layer l (0 for the last); wcache: an empty dict the caller keeps -- the packed weight images are reused while the weights'
+    version counters stand still.  compute_dtype float32 = exact fp32 MFMA (activations stay float32), bfloat16 = bf16 operands
     and bf16 activations between the layers, fp32 accumulation; the last layer's output has out_dtype.
     """
     if not isinstance(trees, (PrunedTrees, PackedTrees)):
@@ -228,7 +238,7 @@ def gcn_layers(x, weights, biases, trees, drop_p=None, seeds=None, compute_dtype
         x, out_dtype = (x.float() if x.dtype != torch.float32 else x), torch.float32
     cfg = dict(drop_p=[float(p) for p in (drop_p or [0.0] * L)], seed=[int(s) for s in (seeds or [0] * L)], compute=compute,
                mid_dtype=torch.float32 if compute == _lib.F32 else torch.bfloat16, out_dtype=out_dtype, no_adj=bool(no_adj),
-               seed_dev=seed_dev)
+               seed_dev=seed_dev, wcache=wcache)
     params = [t for wb in zip(weights, biases) for t in wb]
     return _GCNLayersFn.apply(x, trees, cfg, *params)
 
@@ -497,6 +507,7 @@ class GCN(nn.Module):
         if kind not in ('fp32', 'bf16'):
             raise ValueError("gcn_dtype must be 'fp32' or 'bf16'")
         self.compute_dtype = torch.float32 if kind == 'fp32' else torch.bfloat16
+        self._wcache = {}             # packed weight images, valid while the weights' version counters stand still
         # graph-safe dropout: a by-value seed is frozen into a captured hipGraph, so with opt['gcn_graph_rng'] the per-layer
         # seeds are fixed at construction and a device counter (advanced by one captured op per forward) is added in the kernel
         self.graph_rng = bool(opt.get('gcn_graph_rng', False))
@@ -665,7 +676,7 @@ class GCN(nn.Module):
             ps, seeds, seed_dev = self._dropout_plan()
             Ws, bs = [lin.weight for lin in self.W], [lin.bias for lin in self.W]
             xp = packed.pack_rows(gcn_inputs if gcn_inputs.dtype in (torch.float32, torch.bfloat16) else gcn_inputs.float())
-            hp = gcn_layers(xp, Ws, bs, packed, ps, seeds, self.compute_dtype, torch.float32, no_adj, seed_dev)
+            hp = gcn_layers(xp, Ws, bs, packed, ps, seeds, self.compute_dtype, torch.float32, no_adj, seed_dev, self._wcache)
             return packed.unpack_rows(hp), packed.padded.pool_mask
         trees = adj if isinstance(adj, PrunedTrees) else adj_to_csr(adj, want_label=False)   # gcn.py:260-262
         no_adj = bool(self.opt.get('no_adj', False))                                           # gcn.py:264-265
@@ -673,11 +684,12 @@ class GCN(nn.Module):
         B, T, Din = x.shape
         ps, seeds, seed_dev = self._dropout_plan()
         Ws, bs = [lin.weight for lin in self.W], [lin.bias for lin in self.W]
-        if (self.compute_dtype == torch.bfloat16 and self.opt.get('gcn_fused', False)
+        # the sentence-resident kernels win from ~256 sentences per batch on (profiles/r02_stack_vs_layers.json): default there
+        if (self.compute_dtype == torch.bfloat16 and self.opt.get('gcn_fused', B >= 256)
                 and gcn_stack_supported(T, Din, self.mem_dim, self.layers)):
             # whole stack in one launch per direction (sentence-resident kernels)
             return gcn_stack(x, Ws, bs, trees, ps, seeds, torch.float32, no_adj, seed_dev), trees.pool_mask
-        x = gcn_layers(x, Ws, bs, trees, ps, seeds, self.compute_dtype, torch.float32, no_adj, seed_dev)
+        x = gcn_layers(x, Ws, bs, trees, ps, seeds, self.compute_dtype, torch.float32, no_adj, seed_dev, self._wcache)
         return x, trees.pool_mask
 
 

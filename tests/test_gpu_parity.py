@@ -1542,3 +1542,32 @@ def test_cgcn_full_size_layer_stack_vs_oracle(api, dev):
         assert max_rel(W[l].weight.grad.cpu().numpy(), dWs[l]) <= GRAD_RTOL, l
         assert max_rel(W[l].bias.grad.cpu().numpy(), dbs[l]) <= GRAD_RTOL, l
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in model.named_parameters() if "rnn" in n)
+
+
+def test_packed_weight_cache_follows_weight_versions(api, dev):
+    """The module keeps the MFMA-order weight images while the weights' version counters stand still (eval(), gradient accumulation)
+    and re-packs after an in-place update (optimizer step, load_state_dict): outputs always belong to the CURRENT weights."""
+    from gcn_over_pruned_trees_amd.utils import synthetic
+    gcn, tree = api
+    B, T, K = 6, 40, 1
+    opt = dict(vocab_size=60, emb_dim=24, pos_dim=4, ner_dim=4, hidden_dim=32, num_layers=2, input_dropout=0.0, gcn_dropout=0.0,
+               prune_k=K, pooling="max", mlp_layers=1, rnn=False, dataset="tacred", num_class=5, topn=10 ** 9, cuda=True, adj_type="regular")
+    torch.manual_seed(3)
+    model = gcn.GCNClassifier(opt).to(dev).eval()
+    tb = synthetic.random_tree_batch(71, B, T, "tacred")
+    rng = np.random.RandomState(72)
+    ids = lambda hi: _t(rng.randint(2, hi, size=(B, T)) * ~tb["masks"], dev)  # noqa: E731
+    inputs = (ids(60), _t(tb["masks"], dev), ids(40), ids(8), _t(tb["deprel"], dev), _t(tb["head"], dev), _t(tb["subj_pos"], dev), _t(tb["obj_pos"], dev))
+    g = model.gcn_model.gcn
+    with torch.no_grad():
+        a, _ = model(inputs)
+        key1 = g._wcache["key"]
+        b, _ = model(inputs)
+        assert g._wcache["key"] == key1 and torch.equal(a, b)                 # second forward: no pack, same images, same bits
+        g.W[0].weight.mul_(1.5)                                               # what an optimizer step does: in place, version + 1
+        c, _ = model(inputs)
+        assert g._wcache["key"] != key1 and not torch.allclose(a, c)
+        fresh = gcn.GCNClassifier(opt).to(dev).eval()
+        fresh.load_state_dict(model.state_dict())
+        d, _ = fresh(inputs)
+        assert torch.equal(c, d)                                              # = a model that never had a cache

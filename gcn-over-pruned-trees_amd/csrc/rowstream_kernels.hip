@@ -45,7 +45,8 @@ constexpr int RS_KU = 3;                    // weight k-steps in flight per matr
 constexpr int RS_NBU = 7;                   // entries fetched with a row in ONE round trip: all an ELL head carries (a later trip per
                                             // extra entry, item after item, made the gather 30 k cycles per tile)
 constexpr int RS_NB_INLINE = 7;
-constexpr int RS_META_INTS = RS_ROWS * 10;  // per tile: ELL heads [64][8], deg+1 [64] (float), sentence base [64]
+constexpr int RS_META_INTS = RS_ROWS * 12 + 4;  // per tile: ELL heads [64][8], deg+1 [64] (float), sentence base [64], the rows that
+                                                // aggregate something / that are plain copies, compacted [64] + [64], and their two counts
 
 struct StreamParams {
     const void* src;            // fwd: h [N,K]    bwd: dZ [N,K]
@@ -111,24 +112,68 @@ __global__ __launch_bounds__(RS_THREADS) void rowstream_kernel(const StreamParam
             const size_t er = (size_t)min(r0 + row, p.N - 1);
             reinterpret_cast<float*>(m)[8 * RS_ROWS + row] = (float)(p.d_ell[er * 8] + 1);   // gcn.py:261
             m[9 * RS_ROWS + row] = p.T ? (int)er / p.T * p.T : 0;
+        } else if (tid < 4 * RS_ROWS) {
+            // one wave splits the tile's rows into those that aggregate entries and those that are plain copies of their own row
+            // (a pruned tree keeps a minority of the tokens): the gather handles the two kinds in separate, dense item lists
+            const int row = tid - 3 * RS_ROWS;
+            const bool agg = r0 + row < p.N && p.g_ell[(size_t)min(r0 + row, p.N - 1) * 8] > 0;
+            const unsigned long long ma = __ballot(agg), below = (1ull << row) - 1ull;
+            if (agg) m[10 * RS_ROWS + __popcll(ma & below)] = row;
+            else m[11 * RS_ROWS + __popcll(~ma & below)] = row;
+            if (row == 0) { m[12 * RS_ROWS] = __popcll(ma); m[12 * RS_ROWS + 1] = RS_ROWS - __popcll(ma); }
         }
     };
     auto div_chunk = [&](int x) { return (int)__umulhi((unsigned)x, p.chunk_magic); };
 
-    // S[row] = src[row] + sum over the row's entries (gcn.py:269 + the explicit W(h) term of gcn.py:271), 64 rows, by the loaders
-    constexpr int ITB = sizeof(IT) == 2 ? 3 : 1;                             // (row, 8-column chunk) items in flight per thread
+    // S[row] = src[row] + sum over the row's entries (gcn.py:269 + the explicit W(h) term of gcn.py:271), 64 rows, by the loaders.
+    // Two dense item lists (item = one 8-column chunk of one row): plain rows are raw copies, ITA of them in flight per thread; rows
+    // that aggregate fetch their own chunk and all (<= 7) ELL entries in ONE round trip, ITB items in flight per thread.
+    constexpr int ITA = sizeof(IT) == 2 ? 4 : 2;
+    constexpr int ITB = sizeof(IT) == 2 ? 3 : 1;
+    // (a) plain rows: by the MATRIX waves, right after their MFMA phase (they finish a tile long before the loaders have gathered the
+    //     next one, and raw copies need few registers); nthr threads numbered t
+    auto gather_plain = [&](int i, int t, int nthr) {
+        const int* m = meta + (i % 3) * RS_META_INTS;
+        bf16_t* S = s_buf(i);
+        const int r0 = tile_of(i) * RS_ROWS;
+        const int n_plain = m[12 * RS_ROWS + 1];
+        for (int it0 = t; it0 < n_plain * nchunk; it0 += nthr * ITA) {
+            raw8<IT> own[ITA];
+#pragma unroll
+            for (int u = 0; u < ITA; ++u) {
+                const int it = min(it0 + u * nthr, n_plain * nchunk - 1);
+                const int li = div_chunk(it), row = m[11 * RS_ROWS + li];
+                ld8((size_t)min(r0 + row, p.N - 1), min((it - li * nchunk) * 8, kmax8), own[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < ITA; ++u) {
+                const int it = it0 + u * nthr;
+                if (it >= n_plain * nchunk) continue;
+                const int li = div_chunk(it), row = m[11 * RS_ROWS + li], k0 = (it - li * nchunk) * 8;
+                const bool live = r0 + row < p.N && k0 < p.K;
+                if constexpr (sizeof(IT) == 2) {
+                    *reinterpret_cast<uint4*>(S + (size_t)row * p.strideS + k0) = live ? own[u].a : make_uint4(0, 0, 0, 0);
+                } else {
+                    float acc[8];
+                    unpack8<IT>(own[u], live, acc);
+                    tile<bf16_t>::put8(S + (size_t)row * p.strideS + k0, acc);
+                }
+            }
+        }
+    };
+    // (b) rows that aggregate: by the loader waves
     auto gather = [&](int i, int tid) {
         const int* m = meta + (i % 3) * RS_META_INTS;
         bf16_t* S = s_buf(i);
         const int r0 = tile_of(i) * RS_ROWS;
-        const int n_items = RS_ROWS * nchunk;
+        const int n_items = m[12 * RS_ROWS] * nchunk;
         for (int it0 = tid; it0 < n_items; it0 += RS_LD_THREADS * ITB) {
             raw8<IT> own[ITB], nb[ITB][RS_NBU];
 #pragma unroll
             for (int u = 0; u < ITB; ++u) {
                 const int it = min(it0 + u * RS_LD_THREADS, n_items - 1);
-                const int row = div_chunk(it), k0c = min((it - row * nchunk) * 8, kmax8);
-                const size_t gr = (size_t)min(r0 + row, p.N - 1);
+                const int li = div_chunk(it), row = m[10 * RS_ROWS + li], k0c = min((it - li * nchunk) * 8, kmax8);
+                const size_t gr = (size_t)(r0 + row);
                 const int n_ell = min(m[row * 8], RS_NB_INLINE), base = m[9 * RS_ROWS + row];
                 ld8(gr, k0c, own[u]);
 #pragma unroll
@@ -142,9 +187,9 @@ __global__ __launch_bounds__(RS_THREADS) void rowstream_kernel(const StreamParam
             for (int u = 0; u < ITB; ++u) {
                 const int it = it0 + u * RS_LD_THREADS;
                 if (it >= n_items) continue;
-                const int row = div_chunk(it), k0 = (it - row * nchunk) * 8, k0c = min(k0, kmax8);
+                const int li = div_chunk(it), row = m[10 * RS_ROWS + li], k0 = (it - li * nchunk) * 8, k0c = min(k0, kmax8);
                 const int grow = r0 + row;
-                const bool live = grow < p.N && k0 < p.K;
+                const bool live = k0 < p.K;
                 const int cnt = m[row * 8], n_ell = min(cnt, RS_NB_INLINE), base = m[9 * RS_ROWS + row];
                 float acc[8];
                 unpack8<IT>(own[u], live, acc);
@@ -174,13 +219,17 @@ __global__ __launch_bounds__(RS_THREADS) void rowstream_kernel(const StreamParam
 
     // ---- prologue: adjacency of the first two tiles, bias, the first tile's gather
     if (loader) {
+        __builtin_amdgcn_s_setprio(1);          // the gather is the longer side of every tile: the loaders win the issue arbitration
         load_meta(0);
         load_meta(1);
     } else if (!BWD) {
         for (int c = tid - RS_LD_THREADS; c < round_up(p.NOUT, 16); c += RS_THREADS - RS_LD_THREADS) sbias[c] = p.bias[min(c, p.NOUT - 1)];
     }
     __syncthreads();
-    if (loader && my_tiles > 0) gather(0, tid);
+    if (my_tiles > 0) {
+        if (loader) gather(0, tid);
+        else gather_plain(0, tid - RS_LD_THREADS, RS_THREADS - RS_LD_THREADS);
+    }
     __syncthreads();
 
     const int mw = wave - RS_LD_WAVES;
@@ -255,6 +304,8 @@ __global__ __launch_bounds__(RS_THREADS) void rowstream_kernel(const StreamParam
                 }
             }
             if (st) RS_STAMP(p.stamps, RS_LD_THREADS, 9);
+            if (!loader && pass == 0 && i + 1 < my_tiles) gather_plain(i + 1, tid - RS_LD_THREADS, RS_THREADS - RS_LD_THREADS);
+            if (st) RS_STAMP(p.stamps, RS_LD_THREADS, 7);
             __syncthreads();                                                     // S fully read (the out tile may alias it), next tile gathered
             if (st) { RS_STAMP(p.stamps, 0, 3); RS_STAMP(p.stamps, RS_LD_THREADS, 10); }
             asm volatile("" : "+v"(tid));                                        // (a fresh thread index per phase, see above)
@@ -451,7 +502,8 @@ bool rowstream_enabled() { return rowstream_wanted(1 << 30); }
 
 template <typename IT, typename OT, bool BWD>
 static int launch_rowstream(hipStream_t s, const StreamParams& p, size_t lds, int vec_in) {
-    const int grid = std::min(p.n_tiles_rows, 256);
+    // as many workgroups as give every one the same number of tiles (600 tiles: 200 workgroups of 3, not 256 of 2-3)
+    const int grid = ceil_div(p.n_tiles_rows, ceil_div(p.n_tiles_rows, 256));
     if (vec_in == 8) {
         auto kern = rowstream_kernel<IT, OT, BWD, 8>;
         GCNPT_LDS_ATTR_ONCE(kern, 160 * 1024);

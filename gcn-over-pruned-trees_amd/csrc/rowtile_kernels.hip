@@ -89,7 +89,12 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
 
     // `wave` through readfirstlane: the compiler then knows it is uniform and does every wave-dependent address in SALU
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r0 = blockIdx.x * ROWS;
+    // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one), each with its own L2, and a row's neighbours
+    // sit in its own sentence, i.e. in the adjacent tiles: XCD x takes a CONTIGUOUS run of tiles, so that the neighbour rows a tile
+    // gathers are rows the same L2 serves to the tiles next to it (speed only; any placement gives the same values)
+    const int xg = blockIdx.x & 7, xq = gridDim.x >> 3, xr = gridDim.x & 7;
+    const int tile_id = xg * xq + min(xg, xr) + (blockIdx.x >> 3);
+    const int r0 = tile_id * ROWS;
     const IT* src = static_cast<const IT*>(p.src);
     const IT* yref = static_cast<const IT*>(p.yref);
     const uint4* wfrag = static_cast<const uint4*>(p.wfrag);
@@ -362,7 +367,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
                 u.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
                 u.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
                 u.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
-                F[((size_t)t * nks + blockIdx.x) * 64 + lane] = u;
+                F[((size_t)t * nks + tile_id) * 64 + lane] = u;
             }
         } else {
             const int i = lane & 15, g = lane >> 4;
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
                 u.y = __float_as_uint(X[(size_t)(16 * kk + 4 * g + 1) * stride + 16 * t + i]);
                 u.z = __float_as_uint(X[(size_t)(16 * kk + 4 * g + 2) * stride + 16 * t + i]);
                 u.w = __float_as_uint(X[(size_t)(16 * kk + 4 * g + 3) * stride + 16 * t + i]);
-                F[((size_t)t * nks + 2 * blockIdx.x + kk) * 64 + lane] = u;
+                F[((size_t)t * nks + 2 * tile_id + kk) * 64 + lane] = u;
             }
         }
     }

@@ -274,6 +274,31 @@ class Stack(object):
         if rc:
             self._lib.check(rc)
 
+    def step_with_pooling(self, handover, k=0):
+        """The step with its consumer inside (model/gcn.py:116-121): pack, layers forward, the three poolings, their backward, the backward
+        sweep.  handover: the pooling's backward writes dZ of the top layer (gcnpt_pool3_bwd_dz + gcnpt_layers_bwd_dz) instead of dh."""
+        pack, fwd, bwd = self._native_args(k)
+        P, st, L = self._lib.ptr, self._lib.stream(), self.L
+        if not hasattr(self, "pooled"):
+            B, H = self.B, self.H
+            self.pooled = torch.empty((B, 3 * H), dtype=torch.float32, device=self.dev)
+            self.gpool = torch.randn((B, 3 * H), dtype=torch.float32, device=self.dev)
+            self.amax = torch.empty((B, 3, H), dtype=torch.int32, device=self.dev)
+            self.dtop = torch.empty_like(self.h2)
+        tr = self.trees
+        bwd = (bwd[0], P(self.dtop)) + bwd[2:]
+        rc = (L.gcnpt_pack_weights_multi(st, *pack) or L.gcnpt_layers_fwd(st, *fwd)
+              or L.gcnpt_pool3_fwd(st, P(self.h2), self.act, P(tr.pool_mask), P(self.subj), P(self.obj), self.B, self.T, self.H, 0, P(self.pooled),
+                                   P(self.amax)))
+        if rc == 0 and handover:
+            rc = (L.gcnpt_pool3_bwd_dz(st, P(self.gpool), P(self.amax), P(tr.pool_mask), P(self.subj), P(self.obj), self.B, self.T, self.H, 0,
+                                       P(self.h2), P(tr.ell), 1.0, P(self.dtop), self.act) or L.gcnpt_layers_bwd_dz(st, *bwd))
+        elif rc == 0:
+            rc = (L.gcnpt_pool3_bwd(st, P(self.gpool), P(self.amax), P(tr.pool_mask), P(self.subj), P(self.obj), self.B, self.T, self.H, 0,
+                                    P(self.dtop), self.act) or L.gcnpt_layers_bwd(st, *bwd))
+        if rc:
+            self._lib.check(rc)
+
     # ---- sentence-resident stack: every layer in one launch per direction ----
     def stack_fwd(self, k=0):
         P, A, tr, L = self._lib.ptr, self._lib.ptr_array, self.trees, 2
@@ -752,6 +777,23 @@ def main():
                                   "steps": n32, "note": "rank 0, same step with fp32 activations and exact fp32 MFMA (v_mfma_f32_16x16x4_f32): the "
                                                         "reference's own arithmetic, the mode the 1e-5 / 1e-4 parity tests run in"}
                 del s32
+        if not stack.fused and not args.no_secondary and args.layout == "padded":
+            # the step with the reference's consumer in it (max pooling x3, gcn.py:116-121), with and without the dZ hand-over
+            wp = {}
+            for name, ho in (("two_ops", False), ("handover", True)):
+                if launch == "native":
+                    run_h = lambda ho=ho: stack.step_with_pooling(ho)  # noqa: E731
+                    run_h()
+                    torch.cuda.synchronize()
+                else:
+                    run_h, _ = capture(lambda ho=ho: stack.step_with_pooling(ho), use_graph)
+                n_h = max(args.steps // 4, 50)
+                wall_h, _ = timed(lambda i: run_h(), n_h, min(args.warmup, 50), lambda: None)
+                wp[name] = wall_h / n_h * 1e3
+            result["with_pooling"] = {"ms_per_step_pool3_then_layers_bwd": wp["two_ops"], "ms_per_step_pool3_bwd_dz_handover": wp["handover"],
+                                      "note": "rank 0, the step plus the consumer's three max poolings forward and backward (gcnpt_pool3_fwd / _bwd); "
+                                              "handover: the pooling's backward writes dZ of the top layer (gcnpt_pool3_bwd_dz, gcnpt_layers_bwd_dz), "
+                                              "which then gathers one row per neighbour instead of dY, Y and the degree"}
         if not stack.fused and not args.no_pooled_only and args.layout == "padded" and args.lengths == "tacred":
             sp = Stack(args, dev, seed=shard_seed, packed=True)
             if launch == "native":

@@ -40,6 +40,8 @@ SIGNATURES = {
     "gcnpt_full_agg_bwd": (_i, [_p] * 9 + [_i, _i, _i, _i, _f, _p, _p, _p]),
     "gcnpt_pool3_fwd": (_i, [_p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "gcnpt_pool3_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i]),
+    "gcnpt_pool3_bwd_dz": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _f, _p, _i]),
+    "gcnpt_layers_bwd_dz": (_i, [_p, _i] + [_p] * 8 + [_i, _i] + [_p] * 4 + [_i] + [_p] * 5),
     "gcnpt_diag_layer_fwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p, _f, _u64, _p]),
     "gcnpt_diag_layer_bwd": (_i, [_p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _f]),
     "gcnpt_gather_trees": (_i, [_p] * 11 + [_i, _i, _i, _p, _i, _i, _i] + [_p] * 9),

@@ -129,7 +129,8 @@ template <typename T, int CPL>
 __global__ __launch_bounds__(POOL_THREADS) void pool3_bwd_kernel(const float* __restrict__ g, const int32_t* __restrict__ argmax,
                                                                 const uint8_t* __restrict__ pool_mask, const int64_t* __restrict__ subj_pos,
                                                                 const int64_t* __restrict__ obj_pos, int Tn, int H, int type,
-                                                                T* __restrict__ dh) {
+                                                                T* __restrict__ dh, const T* __restrict__ y, const int32_t* __restrict__ d_ell,
+                                                                float scale) {
     extern __shared__ int mbits[];
     __shared__ int s_cnt[3];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -174,6 +175,15 @@ __global__ __launch_bounds__(POOL_THREADS) void pool3_bwd_kernel(const float* __
                 s[j] += on ? gk[k][j] : 0.0f;
             }
         }
+        if (y) {
+            // hand-over to the layer stack (gcnpt_pool3_bwd_dz): the pooled rows are the top GCN layer's output, so its
+            // dZ = dh * 1[Y > 0] * scale / (deg + 1) (gcn.py:390-393 differentiated) leaves from here, where dh is at hand
+            float yv[CPL];
+            dgio<T, CPL>::ld(y + ((size_t)b * Tn + t) * H + cc, live, yv);
+            const float f = scale / (float)(d_ell[((size_t)b * Tn + t) * 8] + 1);
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) s[j] = yv[j] > 0.0f ? s[j] * f : 0.0f;
+        }
         if (live) dgio<T, CPL>::st(dh + ((size_t)b * Tn + t) * H + cc, live, s);
     }
 }
@@ -202,22 +212,35 @@ extern "C" int gcnpt_pool3_fwd(void* stream, const void* h, int h_dtype, const u
     return GCNPT_OK;
 }
 
-extern "C" int gcnpt_pool3_bwd(void* stream, const float* g, const int32_t* argmax, const uint8_t* pool_mask, const int64_t* subj_pos,
-                               const int64_t* obj_pos, int B, int T, int H, int type, void* dh, int dh_dtype) {
-    GCNPT_REQUIRE(g && pool_mask && subj_pos && obj_pos && dh, "pool3_bwd: null pointer");
-    GCNPT_REQUIRE(B > 0 && T > 0 && H > 0 && dtype_ok(dh_dtype) && type >= 0 && type <= 2, "pool3_bwd: bad argument");
-    GCNPT_REQUIRE(type != 0 || argmax, "pool3_bwd: max pooling needs the argmax buffer");
+static int pool3_bwd_launch(void* stream, const float* g, const int32_t* argmax, const uint8_t* pool_mask, const int64_t* subj_pos,
+                            const int64_t* obj_pos, int B, int T, int H, int type, void* dh, int dh_dtype, const void* y, const int32_t* ell,
+                            float scale, const char* what) {
+    GCNPT_REQUIRE(g && pool_mask && subj_pos && obj_pos && dh, "%s: null pointer", what);
+    GCNPT_REQUIRE(B > 0 && T > 0 && H > 0 && dtype_ok(dh_dtype) && type >= 0 && type <= 2, "%s: bad argument", what);
+    GCNPT_REQUIRE(type != 0 || argmax, "%s: max pooling needs the argmax buffer", what);
     hipStream_t s = (hipStream_t)stream;
-    const bool vec = H % 4 == 0 && aligned16(dh) && aligned16(g);
+    const bool vec = H % 4 == 0 && aligned16(dh) && aligned16(g) && (!y || aligned16(y));
     const dim3 grid(B, ceil_div(H, POOL_LANES * (vec ? 4 : 1)));
     const size_t lds = sizeof(int) * T;
     if (dh_dtype == GCNPT_F32) {
-        if (vec) hipLaunchKernelGGL((pool3_bwd_kernel<float, 4>), grid, dim3(POOL_THREADS), lds, s, g, argmax, pool_mask, subj_pos, obj_pos, T, H, type, (float*)dh);
-        else hipLaunchKernelGGL((pool3_bwd_kernel<float, 1>), grid, dim3(POOL_THREADS), lds, s, g, argmax, pool_mask, subj_pos, obj_pos, T, H, type, (float*)dh);
+        if (vec) hipLaunchKernelGGL((pool3_bwd_kernel<float, 4>), grid, dim3(POOL_THREADS), lds, s, g, argmax, pool_mask, subj_pos, obj_pos, T, H, type, (float*)dh, (const float*)y, ell, scale);
+        else hipLaunchKernelGGL((pool3_bwd_kernel<float, 1>), grid, dim3(POOL_THREADS), lds, s, g, argmax, pool_mask, subj_pos, obj_pos, T, H, type, (float*)dh, (const float*)y, ell, scale);
     } else {
-        if (vec) hipLaunchKernelGGL((pool3_bwd_kernel<bf16_t, 4>), grid, dim3(POOL_THREADS), lds, s, g, argmax, pool_mask, subj_pos, obj_pos, T, H, type, (bf16_t*)dh);
-        else hipLaunchKernelGGL((pool3_bwd_kernel<bf16_t, 1>), grid, dim3(POOL_THREADS), lds, s, g, argmax, pool_mask, subj_pos, obj_pos, T, H, type, (bf16_t*)dh);
+        if (vec) hipLaunchKernelGGL((pool3_bwd_kernel<bf16_t, 4>), grid, dim3(POOL_THREADS), lds, s, g, argmax, pool_mask, subj_pos, obj_pos, T, H, type, (bf16_t*)dh, (const bf16_t*)y, ell, scale);
+        else hipLaunchKernelGGL((pool3_bwd_kernel<bf16_t, 1>), grid, dim3(POOL_THREADS), lds, s, g, argmax, pool_mask, subj_pos, obj_pos, T, H, type, (bf16_t*)dh, (const bf16_t*)y, ell, scale);
     }
     GCNPT_HIP_CHECK(hipGetLastError());
     return GCNPT_OK;
+}
+
+extern "C" int gcnpt_pool3_bwd(void* stream, const float* g, const int32_t* argmax, const uint8_t* pool_mask, const int64_t* subj_pos,
+                               const int64_t* obj_pos, int B, int T, int H, int type, void* dh, int dh_dtype) {
+    return pool3_bwd_launch(stream, g, argmax, pool_mask, subj_pos, obj_pos, B, T, H, type, dh, dh_dtype, nullptr, nullptr, 1.0f, "pool3_bwd");
+}
+
+extern "C" int gcnpt_pool3_bwd_dz(void* stream, const float* g, const int32_t* argmax, const uint8_t* pool_mask, const int64_t* subj_pos,
+                                  const int64_t* obj_pos, int B, int T, int H, int type, const void* y, const int32_t* ell, float scale, void* dz,
+                                  int dtype) {
+    GCNPT_REQUIRE(y && ell, "pool3_bwd_dz: null pointer");
+    return pool3_bwd_launch(stream, g, argmax, pool_mask, subj_pos, obj_pos, B, T, H, type, dz, dtype, y, ell, scale, "pool3_bwd_dz");
 }

@@ -745,11 +745,11 @@ extern "C" int gcnpt_layers_fwd(void* stream, int n_layers, const void* x, int x
     return GCNPT_OK;
 }
 
-extern "C" int gcnpt_layers_bwd(void* stream, int n_layers, const void* gy, const void* const* Y, const int* y_dtype,
-                                const void* const* w_bwd, const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
-                                const int32_t* ellT, int B, int T, const int* Din, const int* H, void* const* dh,
-                                const int* dh_dtype, int compute_dtype, const float* scale, void* const* z_frag,
-                                const void* const* s_frag, float* const* dW, float* const* db) {
+static int layers_bwd_impl(void* stream, int n_layers, const void* gy, const void* const* Y, const int* y_dtype,
+                           const void* const* w_bwd, const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
+                           const int32_t* ellT, int B, int T, const int* Din, const int* H, void* const* dh,
+                           const int* dh_dtype, int compute_dtype, const float* scale, void* const* z_frag,
+                           const void* const* s_frag, float* const* dW, float* const* db, bool gy_is_dz) {
     GCNPT_REQUIRE(n_layers >= 1 && n_layers <= LAYERS_MAX, "layers_bwd: 1..%d layers per call", LAYERS_MAX);
     GCNPT_REQUIRE(gy && Y && y_dtype && w_bwd && Din && H && dh && dh_dtype && scale, "layers_bwd: null pointer");
     GCNPT_REQUIRE(!z_frag || (s_frag && dW && db), "layers_bwd: weight gradients need z_frag, s_frag, dW and db");
@@ -763,7 +763,7 @@ extern "C" int gcnpt_layers_bwd(void* stream, int n_layers, const void* gy, cons
     // streaming kernel (rowstream_kernels.hip) instead of deriving three loads per neighbour
     const int top = n_layers - 1;
     bool top_is_dz = false;
-    if (rowstream_enabled() && n_layers >= 2 && compute_dtype == GCNPT_BF16 && rows_of(B, T) >= 16384 && dh[0] && dh[top] &&
+    if (!gy_is_dz && rowstream_enabled() && n_layers >= 2 && compute_dtype == GCNPT_BF16 && rows_of(B, T) >= 16384 && dh[0] && dh[top] &&
         (size_t)Din[0] * esize(dh_dtype[0]) >= (size_t)H[top] * esize(y_dtype[top]) && aligned16(dh[0])) {
         const int rc = launch_dz_rows((hipStream_t)stream, gy, Y[top], y_dtype[top], ell, (int)rows_of(B, T), H[top], scale[top], dh[0],
                                       z_frag ? z_frag[top] : nullptr, 1);
@@ -783,7 +783,7 @@ extern "C" int gcnpt_layers_bwd(void* stream, int n_layers, const void* gy, cons
         if (dh[l] || z_frag) {
             // every layer but the bottom one hands the layer below its dZ ready-made (dh[l] then holds dZ of layer l-1), and every
             // layer but the top one receives it: one load per neighbour in the gather instead of three
-            const bool hand_down = l > 0, handed = l < n_layers - 1;
+            const bool hand_down = l > 0, handed = l < n_layers - 1 || gy_is_dz;
             const int rc = gcnpt_layer_bwd_data(stream, g, Y[l], y_dtype[l], w_bwd[l], ell, rowT_ptr, colT_idx, ellT, B, T, Din[l], H[l],
                                                 dh[l], dh_dtype[l], compute_dtype, scale[l], z_frag ? z_frag[l] : nullptr,
                                                 z_frag ? dW[l] : nullptr, z_frag ? db[l] : nullptr, hand_down ? Y[l - 1] : nullptr,
@@ -794,4 +794,24 @@ extern "C" int gcnpt_layers_bwd(void* stream, int n_layers, const void* gy, cons
     }
     if (!z_frag) return GCNPT_OK;
     return gcnpt_layer_bwd_weight_multi(stream, n_layers, z_frag, s_frag, B, T, Din, H, dW, db, compute_dtype);
+}
+
+extern "C" int gcnpt_layers_bwd(void* stream, int n_layers, const void* gy, const void* const* Y, const int* y_dtype,
+                                const void* const* w_bwd, const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
+                                const int32_t* ellT, int B, int T, const int* Din, const int* H, void* const* dh,
+                                const int* dh_dtype, int compute_dtype, const float* scale, void* const* z_frag,
+                                const void* const* s_frag, float* const* dW, float* const* db) {
+    return layers_bwd_impl(stream, n_layers, gy, Y, y_dtype, w_bwd, ell, rowT_ptr, colT_idx, ellT, B, T, Din, H, dh, dh_dtype, compute_dtype, scale,
+                           z_frag, s_frag, dW, db, false);
+}
+
+// the same sweep when the caller already holds dZ of the TOP layer (gcnpt_pool3_bwd_dz leaves it): the top layer then gathers one
+// row per neighbour like the layers below it, instead of dY, Y and a degree
+extern "C" int gcnpt_layers_bwd_dz(void* stream, int n_layers, const void* dz_top, const void* const* Y, const int* y_dtype,
+                                   const void* const* w_bwd, const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
+                                   const int32_t* ellT, int B, int T, const int* Din, const int* H, void* const* dh,
+                                   const int* dh_dtype, int compute_dtype, const float* scale, void* const* z_frag,
+                                   const void* const* s_frag, float* const* dW, float* const* db) {
+    return layers_bwd_impl(stream, n_layers, dz_top, Y, y_dtype, w_bwd, ell, rowT_ptr, colT_idx, ellT, B, T, Din, H, dh, dh_dtype, compute_dtype,
+                           scale, z_frag, s_frag, dW, db, true);
 }

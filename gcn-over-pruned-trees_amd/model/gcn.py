@@ -176,12 +176,26 @@ class _GCNLayersFn(torch.autograd.Function):
             _lib.ptr(trees.col_idx), _lib.ptr(g_ell), _lib.ptr(trees.ell), B, T, ints([k for _, k in dims]), ints([h for h, _ in dims]),
             _lib.ptr_array(outs), ints([_lib.dtype_code(o.dtype) for o in outs]), compute, (ctypes.c_float * L)(*cfg["drop_p"]),
             (ctypes.c_uint64 * L)(*cfg["seed"]), _lib.ptr_array(s_frag), _lib.ptr(cfg.get("seed_dev"))))
-        ctx.save_for_backward(*outs, *wb, *[f for f in s_frag if f is not None])
         ctx.trees, ctx.cfg, ctx.dims, ctx.shape, ctx.need_w = trees, cfg, dims, (B, T, Din, L), need_w
         ctx.rows, ctx.lead = rows, lead
         ctx.x_dtype = x.dtype
         ctx.param_dtypes = [p.dtype for p in params]
-        return outs[-1]
+        pool = cfg.get("pool")
+        if pool is None:
+            ctx.save_for_backward(*outs, *wb, *[f for f in s_frag if f is not None])
+            return outs[-1]
+        # the consumer of the stack, fused into the op (gcn.py:114-121): the three masked poolings in one pass over h_L.  Its backward
+        # then hands the top layer dZ instead of dh (gcnpt_pool3_bwd_dz), and that layer gathers one row per neighbour, not three
+        sp, op, kind = pool
+        H = dims[-1][0]
+        pm = trees.pool_mask.contiguous()
+        pooled = torch.empty((B, 3 * H), dtype=torch.float32, device=dev)
+        argmax = torch.empty((B, 3, H), dtype=torch.int32, device=dev) if kind == 0 else None
+        _lib.check(lib.gcnpt_pool3_fwd(st, _lib.ptr(outs[-1]), _lib.dtype_code(outs[-1].dtype), _lib.ptr(pm), _lib.ptr(sp), _lib.ptr(op), B, T, H, kind,
+                                       _lib.ptr(pooled), _lib.ptr(argmax)))
+        ctx.save_for_backward(*outs, *wb, *[f for f in s_frag if f is not None])
+        ctx.pool = (pm, sp, op, argmax, kind)
+        return pooled
 
     @staticmethod
     def backward(ctx, gout):
@@ -194,7 +208,17 @@ class _GCNLayersFn(torch.autograd.Function):
         g_ellT = trees.empty_ell() if cfg["no_adj"] else trees.ellT
         u8 = dict(dtype=torch.uint8, device=dev)
         z_frag, dWs, dbs = [None] * L, [None] * L, [None] * L
-        g = gout.to(outs[-1].dtype).contiguous()
+        scales = [1.0 / (1.0 - p) if p > 0 else 1.0 for p in cfg["drop_p"]]
+        pool = getattr(ctx, "pool", None) if cfg.get("pool") is not None else None
+        if pool is None:
+            g = gout.to(outs[-1].dtype).contiguous()
+        else:
+            pm, sp, op, argmax, kind = pool
+            H = dims[-1][0]
+            g = torch.empty_like(outs[-1])                       # dZ of the top layer, straight from the pooling's backward
+            _lib.check(lib.gcnpt_pool3_bwd_dz(st, _lib.ptr(gout.to(torch.float32).contiguous()), _lib.ptr(argmax), _lib.ptr(pm), _lib.ptr(sp),
+                                              _lib.ptr(op), B, T, H, kind, _lib.ptr(outs[-1]), _lib.ptr(trees.ell), scales[-1], _lib.ptr(g),
+                                              _lib.dtype_code(g.dtype)))
         in_dtypes = [ctx.x_dtype if l == 0 else outs[l - 1].dtype for l in range(L)]
         dhs = [torch.empty(ctx.lead + (K,), dtype=in_dtypes[l], device=dev) if (l > 0 or ctx.needs_input_grad[0]) else None
                for l, (_, K) in enumerate(dims)]
@@ -203,9 +227,8 @@ class _GCNLayersFn(torch.autograd.Function):
             dWs = [torch.empty((H, K), dtype=torch.float32, device=dev) for H, K in dims]       # cleared by bwd_data, filled at the end
             dbs = [torch.empty((H,), dtype=torch.float32, device=dev) for H, _ in dims]
         ints = lambda v: (ctypes.c_int * L)(*v)  # noqa: E731
-        scales = [1.0 / (1.0 - p) if p > 0 else 1.0 for p in cfg["drop_p"]]
-        # the backward sweep and all weight gradients from ONE native call (gcnpt_layers_bwd)
-        _lib.check(lib.gcnpt_layers_bwd(
+        # the backward sweep and all weight gradients from ONE native call (gcnpt_layers_bwd; _dz: its first tensor already is dZ)
+        _lib.check((lib.gcnpt_layers_bwd if pool is None else lib.gcnpt_layers_bwd_dz)(
             st, L, _lib.ptr(g), _lib.ptr_array(list(outs)), ints([_lib.dtype_code(o.dtype) for o in outs]), _lib.ptr_array(list(wb)),
             _lib.ptr(trees.ell), _lib.ptr(trees.rowT_ptr), _lib.ptr(trees.colT_idx), _lib.ptr(g_ellT), B, T, ints([k for _, k in dims]),
             ints([h for h, _ in dims]), _lib.ptr_array(dhs), ints([_lib.dtype_code(t) for t in in_dtypes]), compute,
@@ -221,12 +244,12 @@ class _GCNLayersFn(torch.autograd.Function):
 
 
 def gcn_layers(x, weights, biases, trees, drop_p=None, seeds=None, compute_dtype=torch.float32, out_dtype=torch.float32, no_adj=False,
-               seed_dev=None, wcache=None):
+               seed_dev=None, wcache=None, pool=None):
     """
     The reference's whole layer loop (model/gcn.py:266-393) over the per-layer kernels.  x [B,T,Din] float32/bfloat16 CUDA;
     weights / biases: lists of the nn.Linear parameters (any widths that chain); drop_p[l]: dropout applied to the output of
     layer l (0 for the last); wcache: an empty dict the caller keeps -- the packed weight images are reused while the weights'
-    version counters stand still.  compute_dtype float32 = exact fp32 MFMA (activations stay float32), bfloat16 = bf16 operands
+    version counters stand still; pool: see below.  compute_dtype float32 = exact fp32 MFMA (activations stay float32), bfloat16 = bf16 operands
     and bf16 activations between the layers, fp32 accumulation; the last layer's output has out_dtype.
     """
     if not isinstance(trees, (PrunedTrees, PackedTrees)):
@@ -238,7 +261,14 @@ def gcn_layers(x, weights, biases, trees, drop_p=None, seeds=None, compute_dtype
         x, out_dtype = (x.float() if x.dtype != torch.float32 else x), torch.float32
     cfg = dict(drop_p=[float(p) for p in (drop_p or [0.0] * L)], seed=[int(s) for s in (seeds or [0] * L)], compute=compute,
                mid_dtype=torch.float32 if compute == _lib.F32 else torch.bfloat16, out_dtype=out_dtype, no_adj=bool(no_adj),
-               seed_dev=seed_dev, wcache=wcache)
+               seed_dev=seed_dev, wcache=wcache, pool=None)
+    if pool is not None:
+        # pool = (subj_pos, obj_pos, 'max' | 'avg' | 'sum'): the op returns float32 [B, 3H] = pool3(h_L, trees.pool_mask, subj_pos, obj_pos)
+        # instead of h_L (padded layout only)
+        if getattr(trees, "packed", False):
+            raise ValueError("gcn_layers(pool=...) needs the padded layout")
+        sp, op, kind = pool
+        cfg["pool"] = (sp.contiguous(), op.contiguous(), 0 if kind == 'max' else (1 if kind == 'avg' else 2))
     params = [t for wb in zip(weights, biases) for t in wb]
     return _GCNLayersFn.apply(x, trees, cfg, *params)
 
@@ -461,15 +491,32 @@ class GCNRelationModel(nn.Module):
                 raise ValueError("trees are for a [%d,%d] batch, the inputs are %s" % (trees.B, trees.T, tuple(head.shape)))
             if self.opt.get('gcn_check_trees', True):
                 trees.check() if isinstance(trees, PackedTrees) else trees.check(expect_maxlen=head.shape[1])
-        h, pool_mask = self.gcn(trees, inputs)
+        # regular adjacency on the padded layout: the GCN returns the three pooled vectors itself (stack + pooling as ONE autograd op, so the
+        # pooling's backward hands the top layer its dZ); opt['gcn_pool_handover'] = False keeps the two ops apart
+        handover = (self.adj_type == 'regular' and isinstance(trees, (PrunedTrees, CompactTrees)) and self.opt.get('gcn_pool_handover', True))
         if isinstance(trees, CompactTrees):
-            # only the tokens of the pruned trees and the entity tokens were computed ([B,Tc,H]); the three poolings never look at
+            # only the tokens of the pruned trees and the entity tokens are computed ([B,Tc,H]); the three poolings never look at
             # any other (gcn.py:116-119), so the pooled vectors are the full batch's
             subj_pos, obj_pos = trees.take(subj_pos, fill=150), trees.take(obj_pos, fill=150)      # 150: the loader's pad value (loader.py:120-121)
+        self.gcn._pool_req = (subj_pos, obj_pos, self.opt['pooling']) if handover else None
+        try:
+            h, pool_mask = self.gcn(trees, inputs)
+        finally:
+            self.gcn._pool_req = None
+        if isinstance(h, _Pooled):
+            pooled = h.value
+            return self.out_mlp(pooled), pooled[:, :self.opt['hidden_dim']]
         # gcn.py:116-121: three masked poolings and the concat, one pass over h (masks straight from the position tensors)
         pooled = pool3(h, pool_mask, subj_pos, obj_pos, type=self.opt['pooling'])
         h_out = pooled[:, :self.opt['hidden_dim']]
         return self.out_mlp(pooled), h_out
+
+
+class _Pooled(object):
+    """Marker: GCN.forward was asked (by GCNRelationModel) for pool3(h_L, ...) and returns it in place of h_L."""
+
+    def __init__(self, value):
+        self.value = value
 
 
 class GCN(nn.Module):
@@ -689,6 +736,11 @@ class GCN(nn.Module):
                 and gcn_stack_supported(T, Din, self.mem_dim, self.layers)):
             # whole stack in one launch per direction (sentence-resident kernels)
             return gcn_stack(x, Ws, bs, trees, ps, seeds, torch.float32, no_adj, seed_dev), trees.pool_mask
+        req = getattr(self, "_pool_req", None)
+        if req is not None:
+            # GCNRelationModel asked for the pooled vectors directly (it would pool h next, gcn.py:116-121): stack + pooling as one op
+            return _Pooled(gcn_layers(x, Ws, bs, trees, ps, seeds, self.compute_dtype, torch.float32, no_adj, seed_dev, self._wcache, pool=req)), \
+                trees.pool_mask
         x = gcn_layers(x, Ws, bs, trees, ps, seeds, self.compute_dtype, torch.float32, no_adj, seed_dev, self._wcache)
         return x, trees.pool_mask
 

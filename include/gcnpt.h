@@ -263,6 +263,19 @@ int gcnpt_pool3_fwd(void* stream, const void* h, int h_dtype, const uint8_t* poo
                     const int64_t* obj_pos, int B, int T, int H, int type, float* out, int32_t* argmax);
 int gcnpt_pool3_bwd(void* stream, const float* g, const int32_t* argmax, const uint8_t* pool_mask, const int64_t* subj_pos,
                     const int64_t* obj_pos, int B, int T, int H, int type, void* dh, int dh_dtype);
+/* Hand-over from the pooling to the layer stack (model/gcn.py:114-121: the pooled tensor IS the top GCN layer's output): instead of dh
+ * the pooling's backward leaves dz = dh * 1[y > 0] * scale / (deg + 1), i.e. dZ of that layer (gcn.py:390-393 differentiated), with y
+ * [dev] [B*T,H] = the layer's stored output (same dtype as dz), ell = the forward pattern's ELL head (degrees), scale = 1/(1-p) of the
+ * dropout applied to y.  gcnpt_layers_bwd_dz then runs the backward sweep from it: same arguments and results as gcnpt_layers_bwd, but
+ * its first tensor is that dZ, so the top layer gathers ONE row per neighbour (as the layers below it do) instead of dY, Y and a degree. */
+int gcnpt_pool3_bwd_dz(void* stream, const float* g, const int32_t* argmax, const uint8_t* pool_mask, const int64_t* subj_pos,
+                       const int64_t* obj_pos, int B, int T, int H, int type, const void* y, const int32_t* ell, float scale, void* dz,
+                       int dtype);
+int gcnpt_layers_bwd_dz(void* stream, int n_layers, const void* dz_top, const void* const* Y, const int* y_dtype,
+                        const void* const* w_bwd, const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
+                        const int32_t* ellT, int B, int T, const int* Din, const int* H, void* const* dh, const int* dh_dtype,
+                        int compute_dtype, const float* scale, void* const* z_frag, const void* const* s_frag, float* const* dW,
+                        float* const* db);
 
 /* ---- N2: adj_type == 'diagonal_deprel', model/gcn.py:272-294 (+ 390-393) -------------------------------------------
  * No weight matrix: out[r] = dropout(relu((sum_{c: 0<adj[r,c]<42} E[deprel[c]]*h[c] + sum_{c: 42<adj[r,c]<84}

@@ -1571,3 +1571,76 @@ def test_packed_weight_cache_follows_weight_versions(api, dev):
         fresh.load_state_dict(model.state_dict())
         d, _ = fresh(inputs)
         assert torch.equal(c, d)                                              # = a model that never had a cache
+
+
+# ---------------------------------------------------------------------------------------------------
+# pooling's backward hands the top layer dZ (gcnpt_pool3_bwd_dz + gcnpt_layers_bwd_dz)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("compute", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind", ["max", "avg", "sum"])
+def test_pool_handover_op_matches_two_ops(api, dev, compute, kind):
+    """gcn_layers(pool=...) (stack + the three poolings as one op; backward: pooled gradient -> dZ of the top layer, one gather per
+    neighbour in that layer instead of three) against pool3(gcn_layers(...)): same seeds, dropout on BOTH layers so the top
+    layer's 1/(1-p) reaches the hand-over.  fp32: same arithmetic, only the summation order of the weight gradient's atomics moves."""
+    from gcn_over_pruned_trees_amd.utils import synthetic
+    gcn, tree = api
+    B, T, din, hid = 23, 61, 88, 72
+    tb = synthetic.random_tree_batch(77, B, T, "tacred")
+    head, subj, obj, deprel, masks = (_t(tb[k], dev) for k in ("head", "subj_pos", "obj_pos", "deprel", "masks"))
+    trees = tree.prune_to_csr(head, subj, obj, deprel, 1, masks=masks)
+    Wn, bn = synthetic.layer_params(5, [din, hid, hid])
+    x0 = _t(synthetic.normal(6, (B, T, din)), dev)
+    gp = _t(synthetic.normal(7, (B, 3 * hid)), dev)
+    res = []
+    for handover in (False, True):
+        Ws = [_t(w, dev).requires_grad_() for w in Wn]
+        bs = [_t(b, dev).requires_grad_() for b in bn]
+        x = x0.clone().requires_grad_()
+        kw = dict(drop_p=[0.3, 0.4], seeds=[11, 12], compute_dtype=compute, out_dtype=torch.float32)
+        if handover:
+            pooled = gcn.gcn_layers(x, Ws, bs, trees, pool=(subj, obj, kind), **kw)
+        else:
+            pooled = gcn.pool3(gcn.gcn_layers(x, Ws, bs, trees, **kw), trees.pool_mask, subj, obj, type=kind)
+        pooled.backward(gp)
+        res.append([pooled.detach()] + [t.grad for t in [x] + Ws + bs])
+    tol = 2e-5 if compute == torch.float32 else 2e-2
+    for a, b in zip(*res):
+        assert torch.isfinite(b).all()
+        assert max_rel(b.float().cpu().numpy(), a.float().cpu().numpy()) <= tol
+    assert torch.equal(res[0][0], res[1][0])                      # the forward is the same kernels
+
+
+@pytest.mark.parametrize("variant", ["gcn", "cgcn", "pooled_only", "bf16"])
+def test_pool_handover_classifier_same_update(api, dev, variant):
+    """GCNClassifier with the hand-over (default) and without (opt['gcn_pool_handover']=False): same logits and the same gradient
+    for every parameter in training mode (same generator seeds)."""
+    import json
+    gcn, _ = api
+    g = load_golden("e2e_%s.npz" % ("cgcn" if variant == "cgcn" else "gcn"))
+    opt = json.loads(str(g["opt"]))
+    opt["cuda"] = True
+    if variant == "pooled_only":
+        opt["gcn_pooled_only"] = True
+    if variant == "bf16":
+        opt.update(gcn_dtype="bf16", gcn_fused=False)
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd:")}
+    inputs = tuple(_t(g[k], dev) for k in ("words", "masks", "pos", "ner", "deprel", "head", "subj_pos", "obj_pos"))
+    out = []
+    for handover in (False, True):
+        model = gcn.GCNClassifier(dict(opt, gcn_pool_handover=handover))
+        model.load_state_dict(sd, strict=True)
+        model.to(dev).eval()
+        with torch.no_grad():
+            le, _ = model(inputs)
+        assert max_rel(le.cpu().numpy(), g["logits"]) <= (3e-2 if variant == "bf16" else 1e-4)
+        model.train()
+        torch.manual_seed(99)
+        logits, pooled = model(inputs)
+        (logits.logsumexp(1).mean() + 0.003 * (pooled ** 2).sum(1).mean() + 1e-3 * model.conv_l2()).backward()
+        out.append((logits.detach(), {n: p.grad for n, p in model.named_parameters() if p.grad is not None}))
+    (la, ga), (lb, gb) = out
+    tol = 2e-2 if variant == "bf16" else 1e-4
+    assert max_rel(lb.cpu().numpy(), la.cpu().numpy()) <= tol
+    assert set(ga) == set(gb) and len(ga) > 4
+    for n in ga:
+        assert max_rel(gb[n].cpu().numpy(), ga[n].cpu().numpy()) <= tol, n

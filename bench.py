@@ -149,6 +149,11 @@ class Stack(object):
                                           masks=rep(self.masks), want_label=False)
         self.cache_idx = (torch.arange(B, device=dev) + B * (reps // 2)).to(torch.int64)
         self.scale = 1.0 / (1.0 - args.drop) if args.drop > 0 else 1.0
+        # big batches: scratch for the gather + matrix form of a layer (csrc/rowsplit_kernels.hip); 0 bytes below 16 384 rows
+        Bc, Tc = (self.rows, 0) if packed else (B, T)
+        nws = self.L.gcnpt_layers_workspace_bytes(2, Bc, Tc, (ctypes.c_int * 2)(Din, H), (ctypes.c_int * 2)(H, H), self.act)
+        self.ws = torch.empty((nws,), dtype=torch.uint8, device=dev) if nws else None
+        self.ws_n = nws
         self.side = torch.cuda.Stream(device=dev)
         self.fused = args.fused and args.dtype == "bf16" and not pooled_only and not packed and bool(self.L.gcnpt_stack_supported(T, Din, H, 2, self.compute))
         if self.fused:       # fragment images with per-sentence k-steps: layer inputs h_l (fwd) and G_l = (A+I)^T dZ_l (bwd)
@@ -199,8 +204,9 @@ class Stack(object):
         src, dst = (self.x, self.h1) if l == 0 else (self.h1, self.h2)
         H, Din = self.W[l].shape
         p = self.args.drop if l == 0 else 0.0
-        self._lib.check(self.L.gcnpt_layer_fwd(self._lib.stream(), P(src), self.act, P(self.wf[l]), P(self.b[l]), P(tr.row_ptr), P(tr.col_idx),
-                                               P(tr.ell), None, self.B, self.T, Din, H, P(dst), self.act, self.compute, p, 0x5eed, P(self.sf[l]), None))
+        self._lib.check(self.L.gcnpt_layer_fwd_ws(self._lib.stream(), P(src), self.act, P(self.wf[l]), P(self.b[l]), P(tr.row_ptr), P(tr.col_idx),
+                                                  P(tr.ell), None, self.B, self.T, Din, H, P(dst), self.act, self.compute, p, 0x5eed, P(self.sf[l]), None,
+                                                  P(self.ws), self.ws_n))
 
     def _dw_db(self, l, k):
         g = self.grads(k)
@@ -215,9 +221,9 @@ class Stack(object):
         dW, db = self._dw_db(l, k)
         # the hand-over gcnpt_layers_bwd uses: layer 1 leaves dZ of layer 0 in dh1 (it has h1's rows at hand), layer 0 takes it as is
         relu, nsc, is_dz = (self.h1, self.scale, 0) if l == 1 else (None, 1.0, 1)
-        self._lib.check(self.L.gcnpt_layer_bwd_data(self._lib.stream(), P(dy), P(y), self.act, P(self.wb[l]), P(tr.ell), P(tr.rowT_ptr),
-                                                    P(tr.colT_idx), P(tr.ellT), self.B, self.T, Din, H, P(dst), self.act, self.compute, sc,
-                                                    P(self.zf[l]), P(dW), P(db), P(relu), nsc, is_dz))
+        self._lib.check(self.L.gcnpt_layer_bwd_data_ws(self._lib.stream(), P(dy), P(y), self.act, P(self.wb[l]), P(tr.ell), P(tr.rowT_ptr),
+                                                       P(tr.colT_idx), P(tr.ellT), self.B, self.T, Din, H, P(dst), self.act, self.compute, sc,
+                                                       P(self.zf[l]), P(dW), P(db), P(relu), nsc, is_dz, P(self.ws), self.ws_n))
 
     def bwd_weight(self, l, k=0):
         P = self._lib.ptr
@@ -247,10 +253,10 @@ class Stack(object):
             act = ints([self.act] * n)
             fwd = (n, P(self.x), self.act, A(self.wf), A(self.b), P(tr.row_ptr), P(tr.col_idx), P(tr.ell), None, self.B, self.T, Din, H,
                    A([self.h1, self.h2]), act, self.compute, (ctypes.c_float * n)(self.args.drop, 0.0), (ctypes.c_uint64 * n)(0x5eed, 0),
-                   A(self.sf), None)
+                   A(self.sf), None, P(self.ws), self.ws_n)
             bwd = (n, P(self.gy), A([self.h1, self.h2]), act, A(self.wb), P(tr.ell), P(tr.rowT_ptr), P(tr.colT_idx), P(tr.ellT), self.B, self.T,
                    Din, H, A([self.dx, self.dh1]), act, self.compute, (ctypes.c_float * n)(self.scale, 1.0), A(self.zf), A(self.sf),
-                   A([g[0], g[2]]), A([g[1], g[3]]))
+                   A([g[0], g[2]]), A([g[1], g[3]]), 0, P(self.ws), self.ws_n)
             vp = ctypes.c_void_p
             pack = (n, (vp * n)(*[w.data_ptr() for w in self.W]), H, Din, self.compute, A(self.wf), A(self.wb))
             self._nargs[k] = (pack, fwd, bwd)
@@ -270,7 +276,7 @@ class Stack(object):
             for _, call in self.calls(k):
                 call()
             return
-        rc = L.gcnpt_pack_weights_multi(st, *pack) or L.gcnpt_layers_fwd(st, *fwd) or L.gcnpt_layers_bwd(st, *bwd)
+        rc = L.gcnpt_pack_weights_multi(st, *pack) or L.gcnpt_layers_fwd_ws(st, *fwd) or L.gcnpt_layers_bwd_ws(st, *bwd)
         if rc:
             self._lib.check(rc)
 
@@ -286,16 +292,16 @@ class Stack(object):
             self.amax = torch.empty((B, 3, H), dtype=torch.int32, device=self.dev)
             self.dtop = torch.empty_like(self.h2)
         tr = self.trees
-        bwd = (bwd[0], P(self.dtop)) + bwd[2:]
-        rc = (L.gcnpt_pack_weights_multi(st, *pack) or L.gcnpt_layers_fwd(st, *fwd)
+        bwd = (bwd[0], P(self.dtop)) + bwd[2:-3] + (1 if handover else 0,) + bwd[-2:]
+        rc = (L.gcnpt_pack_weights_multi(st, *pack) or L.gcnpt_layers_fwd_ws(st, *fwd)
               or L.gcnpt_pool3_fwd(st, P(self.h2), self.act, P(tr.pool_mask), P(self.subj), P(self.obj), self.B, self.T, self.H, 0, P(self.pooled),
                                    P(self.amax)))
         if rc == 0 and handover:
             rc = (L.gcnpt_pool3_bwd_dz(st, P(self.gpool), P(self.amax), P(tr.pool_mask), P(self.subj), P(self.obj), self.B, self.T, self.H, 0,
-                                       P(self.h2), P(tr.ell), 1.0, P(self.dtop), self.act) or L.gcnpt_layers_bwd_dz(st, *bwd))
+                                       P(self.h2), P(tr.ell), 1.0, P(self.dtop), self.act) or L.gcnpt_layers_bwd_ws(st, *bwd))
         elif rc == 0:
             rc = (L.gcnpt_pool3_bwd(st, P(self.gpool), P(self.amax), P(tr.pool_mask), P(self.subj), P(self.obj), self.B, self.T, self.H, 0,
-                                    P(self.dtop), self.act) or L.gcnpt_layers_bwd(st, *bwd))
+                                    P(self.dtop), self.act) or L.gcnpt_layers_bwd_ws(st, *bwd))
         if rc:
             self._lib.check(rc)
 
@@ -745,8 +751,10 @@ def main():
                        "ranks_started_by": ("bench.py itself (--gpus N without a launcher)" if os.environ.get("GCNPT_BENCH_SELF_LAUNCHED")
                                             else "torch.distributed.run / caller") if world > 1 else None,
                        "ms_per_step_by_rank": [round(t, 6) for t in rank_ms], "grad_bucket_abs_sum": grad_abs_sum,
-                       "launch": "hipGraph replay" if graphed else ("eager launches from 3 native calls per step (pack, gcnpt_layers_fwd, gcnpt_layers_bwd)"
+                       "launch": "hipGraph replay" if graphed else ("eager launches from 3 native calls per step (pack, gcnpt_layers_fwd_ws, gcnpt_layers_bwd_ws)"
                                                                      if launch == "native" else "eager"),
+                       "layer_form": ("gather + matrix launch per layer and direction (csrc/rowsplit_kernels.hip, %d B workspace)" % stack.ws_n) if stack.ws_n and not stack.fused
+                                     else "one row-tile launch per layer and direction",
                        "allreduce_stream_waits": reducer.stream_waits if reducer else None,
                        "launch_trial_us_per_step": {m: round(t * 1e6, 2) for m, t in trial.items()} or None, "nnz_per_batch": stack.nnz,
                        "grad_allreduce": ("flat fp32 bucket %d B per step over RCCL, " % (4 * stack.n_grad)) +

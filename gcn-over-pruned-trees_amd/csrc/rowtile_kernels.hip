@@ -657,10 +657,18 @@ bool rowstream_enabled();
 int launch_dz_rows(hipStream_t s, const void* dY, const void* Y, int dtype, const int32_t* ell, int N, int H, float scale, void* dz, void* z_frag,
                    int mask);
 
-extern "C" int gcnpt_layer_fwd(void* stream, const void* h, int h_dtype, const void* w_fwd, const float* bias,
-                               const int32_t* row_ptr, const int32_t* col_idx, const int32_t* ell, const int32_t* deg_ell,
-                               int B, int T, int Din, int H, void* out, int out_dtype, int compute_dtype, float drop_p,
-                               uint64_t seed, void* s_frag, const uint64_t* seed_dev) {
+// big batches with a caller-provided workspace: the two-launch layer of rowsplit_kernels.hip (1 = taken, 0 = does not apply, < 0 = error)
+int rowsplit_layer(hipStream_t s, bool bwd, const void* src, int src_dtype, const void* wfrag, const float* bias, const int32_t* g_row_ptr,
+                   const int32_t* g_col_idx, const int32_t* g_ell, const int32_t* d_ell, int N, int T, int K, int NOUT, void* out, int out_dtype,
+                   float drop_p, uint64_t seed, const uint64_t* seed_dev, void* frag_out, float* zero_a, int zero_a_n, float* zero_b, int zero_b_n,
+                   const void* relu_src, float next_scale, void* ws, size_t ws_bytes);
+size_t rowsplit_agg_bytes(long long rows, int width);
+bool rowsplit_wanted(long long rows);
+
+static int layer_fwd_impl(void* stream, const void* h, int h_dtype, const void* w_fwd, const float* bias,
+                          const int32_t* row_ptr, const int32_t* col_idx, const int32_t* ell, const int32_t* deg_ell,
+                          int B, int T, int Din, int H, void* out, int out_dtype, int compute_dtype, float drop_p,
+                          uint64_t seed, void* s_frag, const uint64_t* seed_dev, void* ws, size_t ws_bytes) {
     GCNPT_REQUIRE(h && w_fwd && bias && row_ptr && col_idx && ell && out, "layer_fwd: null pointer");
     GCNPT_REQUIRE(B > 0 && T >= 0 && Din > 0 && H > 0, "layer_fwd: sizes must be positive");
     GCNPT_REQUIRE(dtype_ok(h_dtype) && dtype_ok(out_dtype) && dtype_ok(compute_dtype), "layer_fwd: bad dtype");
@@ -677,6 +685,11 @@ extern "C" int gcnpt_layer_fwd(void* stream, const void* h, int h_dtype, const v
     p.drop_p = drop_p; p.scale = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
     p.drop_thresh16 = (unsigned)((double)drop_p * 65536.0);
     p.seed = seed; p.seed_dev = seed_dev;
+    if (compute_dtype == GCNPT_BF16 && ws && !rowstream_enabled()) {
+        const int rc = rowsplit_layer((hipStream_t)stream, false, h, h_dtype, w_fwd, bias, row_ptr, col_idx, ell, p.d_ell, p.N, T, Din, H, out, out_dtype,
+                                      drop_p, seed, seed_dev, s_frag, nullptr, 0, nullptr, 0, nullptr, 1.0f, ws, ws_bytes);
+        if (rc != 0) return rc < 0 ? rc : GCNPT_OK;
+    }
     if (compute_dtype == GCNPT_BF16) {
         const int rc = rowstream_try_fwd((hipStream_t)stream, h, h_dtype, w_fwd, bias, row_ptr, col_idx, ell, deg_ell, p.N, T, Din, H, out, out_dtype,
                                          drop_p, seed, s_frag, seed_dev, p.vec_in, p.vec_out);
@@ -685,11 +698,27 @@ extern "C" int gcnpt_layer_fwd(void* stream, const void* h, int h_dtype, const v
     return dispatch_rowtile<false>((hipStream_t)stream, p, h_dtype, out_dtype, compute_dtype);
 }
 
-extern "C" int gcnpt_layer_bwd_data(void* stream, const void* dY, const void* Y, int g_dtype, const void* w_bwd,
-                                    const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
-                                    const int32_t* ellT, int B, int T, int Din, int H, void* dh, int dh_dtype,
-                                    int compute_dtype, float scale, void* z_frag, float* zero_dW, float* zero_db,
-                                    const void* relu_src, float next_scale, int src_is_dz) {
+extern "C" int gcnpt_layer_fwd_ws(void* stream, const void* h, int h_dtype, const void* w_fwd, const float* bias,
+                                  const int32_t* row_ptr, const int32_t* col_idx, const int32_t* ell, const int32_t* deg_ell,
+                                  int B, int T, int Din, int H, void* out, int out_dtype, int compute_dtype, float drop_p,
+                                  uint64_t seed, void* s_frag, const uint64_t* seed_dev, void* workspace, size_t workspace_bytes) {
+    return layer_fwd_impl(stream, h, h_dtype, w_fwd, bias, row_ptr, col_idx, ell, deg_ell, B, T, Din, H, out, out_dtype, compute_dtype, drop_p, seed,
+                          s_frag, seed_dev, workspace, workspace_bytes);
+}
+
+extern "C" int gcnpt_layer_fwd(void* stream, const void* h, int h_dtype, const void* w_fwd, const float* bias,
+                               const int32_t* row_ptr, const int32_t* col_idx, const int32_t* ell, const int32_t* deg_ell,
+                               int B, int T, int Din, int H, void* out, int out_dtype, int compute_dtype, float drop_p,
+                               uint64_t seed, void* s_frag, const uint64_t* seed_dev) {
+    return layer_fwd_impl(stream, h, h_dtype, w_fwd, bias, row_ptr, col_idx, ell, deg_ell, B, T, Din, H, out, out_dtype, compute_dtype, drop_p, seed,
+                          s_frag, seed_dev, nullptr, 0);
+}
+
+static int layer_bwd_data_impl(void* stream, const void* dY, const void* Y, int g_dtype, const void* w_bwd,
+                               const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
+                               const int32_t* ellT, int B, int T, int Din, int H, void* dh, int dh_dtype,
+                               int compute_dtype, float scale, void* z_frag, float* zero_dW, float* zero_db,
+                               const void* relu_src, float next_scale, int src_is_dz, void* ws, size_t ws_bytes) {
     GCNPT_REQUIRE(dY && (Y || src_is_dz) && w_bwd && ell && rowT_ptr && colT_idx && ellT, "layer_bwd_data: null pointer");
     GCNPT_REQUIRE(!relu_src || dh, "layer_bwd_data: relu_src without dh");
     GCNPT_REQUIRE(dh || z_frag, "layer_bwd_data: nothing to produce (dh and z_frag both NULL)");
@@ -707,6 +736,23 @@ extern "C" int gcnpt_layer_bwd_data(void* stream, const void* dY, const void* Y,
     p.vec_out = dh ? vec_bytes(Din, esize(dh_dtype), dh, relu_src) : 0;
     p.scale = scale; p.drop_p = 0.0f;
     p.relu_src = relu_src; p.next_scale = next_scale;
+    if (compute_dtype == GCNPT_BF16 && dh && ws && !rowstream_enabled() && rowsplit_wanted(p.N)) {
+        // big batches: gather + matrix launch (rowsplit_kernels.hip).  A top layer that starts from dY first writes its dZ rows (and their
+        // fragment image) into the workspace, behind the aggregated rows, so that the gather loads one row per neighbour
+        const size_t agg_part = rowsplit_agg_bytes(p.N, H);
+        if (!src_is_dz && H <= 960 && ws_bytes >= agg_part + (size_t)p.N * H * esize(g_dtype)) {
+            void* dz = static_cast<char*>(ws) + agg_part;
+            const int rc = launch_dz_rows((hipStream_t)stream, dY, Y, g_dtype, ell, p.N, H, scale, dz, z_frag, 1);
+            if (rc != GCNPT_OK) return rc;
+            dY = dz; src_is_dz = 1; z_frag = nullptr;               // (also what the row-tile kernel continues from, should the split not apply)
+            p.src = dY; p.frag_out = nullptr; p.vec_in = vec_elems(H, esize(g_dtype), dY, nullptr);
+        }
+        if (src_is_dz) {
+            const int rc = rowsplit_layer((hipStream_t)stream, true, dY, g_dtype, w_bwd, nullptr, rowT_ptr, colT_idx, ellT, ell, p.N, T, H, Din, dh,
+                                          dh_dtype, 0.0f, 0, nullptr, z_frag, zero_dW, H * Din, zero_db, H, relu_src, next_scale, ws, agg_part);
+            if (rc != 0) return rc < 0 ? rc : GCNPT_OK;
+        }
+    }
     if (src_is_dz && compute_dtype == GCNPT_BF16 && dh) {
         const int rc = rowstream_try_bwd((hipStream_t)stream, dY, g_dtype, w_bwd, ell, rowT_ptr, colT_idx, ellT, p.N, T, Din, H, dh, dh_dtype, zero_dW,
                                          zero_db, relu_src, next_scale, p.vec_in, p.vec_out);
@@ -718,17 +764,49 @@ extern "C" int gcnpt_layer_bwd_data(void* stream, const void* dY, const void* Y,
     return dispatch_rowtile<true>((hipStream_t)stream, p, g_dtype, dh_dtype, compute_dtype);
 }
 
+extern "C" int gcnpt_layer_bwd_data(void* stream, const void* dY, const void* Y, int g_dtype, const void* w_bwd,
+                                    const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
+                                    const int32_t* ellT, int B, int T, int Din, int H, void* dh, int dh_dtype,
+                                    int compute_dtype, float scale, void* z_frag, float* zero_dW, float* zero_db,
+                                    const void* relu_src, float next_scale, int src_is_dz) {
+    return layer_bwd_data_impl(stream, dY, Y, g_dtype, w_bwd, ell, rowT_ptr, colT_idx, ellT, B, T, Din, H, dh, dh_dtype, compute_dtype, scale, z_frag,
+                               zero_dW, zero_db, relu_src, next_scale, src_is_dz, nullptr, 0);
+}
+
+extern "C" int gcnpt_layer_bwd_data_ws(void* stream, const void* dY, const void* Y, int g_dtype, const void* w_bwd,
+                                       const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
+                                       const int32_t* ellT, int B, int T, int Din, int H, void* dh, int dh_dtype,
+                                       int compute_dtype, float scale, void* z_frag, float* zero_dW, float* zero_db,
+                                       const void* relu_src, float next_scale, int src_is_dz, void* workspace, size_t workspace_bytes) {
+    return layer_bwd_data_impl(stream, dY, Y, g_dtype, w_bwd, ell, rowT_ptr, colT_idx, ellT, B, T, Din, H, dh, dh_dtype, compute_dtype, scale, z_frag,
+                               zero_dW, zero_db, relu_src, next_scale, src_is_dz, workspace, workspace_bytes);
+}
+
 // ---- the whole layer loop / its autograd in one host call: the launches above, back to back (no kernel of their own) ----
 extern "C" int gcnpt_layer_bwd_weight_multi(void* stream, int n_layers, const void* const* z_frag, const void* const* s_frag,
                                             int B, int T, const int* Din, const int* H, float* const* dW, float* const* db,
                                             int compute_dtype);
 constexpr int LAYERS_MAX = 8;
 
-extern "C" int gcnpt_layers_fwd(void* stream, int n_layers, const void* x, int x_dtype, const void* const* w_fwd,
-                                const float* const* bias, const int32_t* row_ptr, const int32_t* col_idx, const int32_t* ell,
-                                const int32_t* deg_ell, int B, int T, const int* Din, const int* H, void* const* out,
-                                const int* out_dtype, int compute_dtype, const float* drop_p, const uint64_t* seed,
-                                void* const* s_frag, const uint64_t* seed_dev) {
+// Workspace of the big-batch path (rowsplit_kernels.hip): [aggregated rows: rows x widest layer side, bf16][dZ of the top layer]
+static size_t ws_agg_part(int n_layers, long long rows, const int* Din, const int* H) {
+    int kmax = 0;
+    for (int l = 0; l < n_layers; ++l) kmax = std::max(kmax, std::max(Din[l], H[l]));
+    return rowsplit_agg_bytes(rows, kmax);
+}
+
+extern "C" size_t gcnpt_layers_workspace_bytes(int n_layers, int B, int T, const int* Din, const int* H, int top_dtype) {
+    if (n_layers < 1 || n_layers > LAYERS_MAX || !Din || !H || B <= 0 || T < 0 || !dtype_ok(top_dtype)) return 0;
+    const long long rows = rows_of(B, T);
+    if (!rowsplit_wanted(rows)) return 0;
+    return ws_agg_part(n_layers, rows, Din, H) + (size_t)((rows * H[n_layers - 1] * (long long)esize(top_dtype) + 255) / 256 * 256);
+}
+
+extern "C" int gcnpt_layers_fwd_ws(void* stream, int n_layers, const void* x, int x_dtype, const void* const* w_fwd,
+                                   const float* const* bias, const int32_t* row_ptr, const int32_t* col_idx, const int32_t* ell,
+                                   const int32_t* deg_ell, int B, int T, const int* Din, const int* H, void* const* out,
+                                   const int* out_dtype, int compute_dtype, const float* drop_p, const uint64_t* seed,
+                                   void* const* s_frag, const uint64_t* seed_dev, void* workspace, size_t workspace_bytes) {
     GCNPT_REQUIRE(n_layers >= 1 && n_layers <= LAYERS_MAX, "layers_fwd: 1..%d layers per call", LAYERS_MAX);
     GCNPT_REQUIRE(x && w_fwd && bias && Din && H && out && out_dtype && drop_p && seed, "layers_fwd: null pointer");
     for (int l = 1; l < n_layers; ++l)
@@ -736,8 +814,9 @@ extern "C" int gcnpt_layers_fwd(void* stream, int n_layers, const void* x, int x
     const void* h = x;
     int h_dtype = x_dtype;
     for (int l = 0; l < n_layers; ++l) {
-        const int rc = gcnpt_layer_fwd(stream, h, h_dtype, w_fwd[l], bias[l], row_ptr, col_idx, ell, deg_ell, B, T, Din[l], H[l], out[l],
-                                       out_dtype[l], compute_dtype, drop_p[l], seed[l], s_frag ? s_frag[l] : nullptr, seed_dev);
+        const int rc = layer_fwd_impl(stream, h, h_dtype, w_fwd[l], bias[l], row_ptr, col_idx, ell, deg_ell, B, T, Din[l], H[l], out[l],
+                                      out_dtype[l], compute_dtype, drop_p[l], seed[l], s_frag ? s_frag[l] : nullptr, seed_dev, workspace,
+                                      workspace_bytes);
         if (rc != GCNPT_OK) return rc;
         h = out[l];
         h_dtype = out_dtype[l];
@@ -745,11 +824,20 @@ extern "C" int gcnpt_layers_fwd(void* stream, int n_layers, const void* x, int x
     return GCNPT_OK;
 }
 
+extern "C" int gcnpt_layers_fwd(void* stream, int n_layers, const void* x, int x_dtype, const void* const* w_fwd,
+                                const float* const* bias, const int32_t* row_ptr, const int32_t* col_idx, const int32_t* ell,
+                                const int32_t* deg_ell, int B, int T, const int* Din, const int* H, void* const* out,
+                                const int* out_dtype, int compute_dtype, const float* drop_p, const uint64_t* seed,
+                                void* const* s_frag, const uint64_t* seed_dev) {
+    return gcnpt_layers_fwd_ws(stream, n_layers, x, x_dtype, w_fwd, bias, row_ptr, col_idx, ell, deg_ell, B, T, Din, H, out, out_dtype, compute_dtype,
+                               drop_p, seed, s_frag, seed_dev, nullptr, 0);
+}
+
 static int layers_bwd_impl(void* stream, int n_layers, const void* gy, const void* const* Y, const int* y_dtype,
                            const void* const* w_bwd, const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
                            const int32_t* ellT, int B, int T, const int* Din, const int* H, void* const* dh,
                            const int* dh_dtype, int compute_dtype, const float* scale, void* const* z_frag,
-                           const void* const* s_frag, float* const* dW, float* const* db, bool gy_is_dz) {
+                           const void* const* s_frag, float* const* dW, float* const* db, bool gy_is_dz, void* ws, size_t ws_bytes) {
     GCNPT_REQUIRE(n_layers >= 1 && n_layers <= LAYERS_MAX, "layers_bwd: 1..%d layers per call", LAYERS_MAX);
     GCNPT_REQUIRE(gy && Y && y_dtype && w_bwd && Din && H && dh && dh_dtype && scale, "layers_bwd: null pointer");
     GCNPT_REQUIRE(!z_frag || (s_frag && dW && db), "layers_bwd: weight gradients need z_frag, s_frag, dW and db");
@@ -773,9 +861,9 @@ static int layers_bwd_impl(void* stream, int n_layers, const void* gy, const voi
     }
     for (int l = n_layers - 1; l >= 0; --l) {
         if (l == top && top_is_dz) {
-            const int rc = gcnpt_layer_bwd_data(stream, g, Y[l], y_dtype[l], w_bwd[l], ell, rowT_ptr, colT_idx, ellT, B, T, Din[l], H[l], dh[l],
-                                                dh_dtype[l], compute_dtype, scale[l], nullptr, z_frag ? dW[l] : nullptr, z_frag ? db[l] : nullptr,
-                                                Y[l - 1], scale[l - 1], 1);
+            const int rc = layer_bwd_data_impl(stream, g, Y[l], y_dtype[l], w_bwd[l], ell, rowT_ptr, colT_idx, ellT, B, T, Din[l], H[l], dh[l],
+                                               dh_dtype[l], compute_dtype, scale[l], nullptr, z_frag ? dW[l] : nullptr, z_frag ? db[l] : nullptr,
+                                               Y[l - 1], scale[l - 1], 1, ws, ws_bytes);
             if (rc != GCNPT_OK) return rc;
             g = dh[l];
             continue;
@@ -784,10 +872,10 @@ static int layers_bwd_impl(void* stream, int n_layers, const void* gy, const voi
             // every layer but the bottom one hands the layer below its dZ ready-made (dh[l] then holds dZ of layer l-1), and every
             // layer but the top one receives it: one load per neighbour in the gather instead of three
             const bool hand_down = l > 0, handed = l < n_layers - 1 || gy_is_dz;
-            const int rc = gcnpt_layer_bwd_data(stream, g, Y[l], y_dtype[l], w_bwd[l], ell, rowT_ptr, colT_idx, ellT, B, T, Din[l], H[l],
-                                                dh[l], dh_dtype[l], compute_dtype, scale[l], z_frag ? z_frag[l] : nullptr,
-                                                z_frag ? dW[l] : nullptr, z_frag ? db[l] : nullptr, hand_down ? Y[l - 1] : nullptr,
-                                                hand_down ? scale[l - 1] : 1.0f, handed ? 1 : 0);
+            const int rc = layer_bwd_data_impl(stream, g, Y[l], y_dtype[l], w_bwd[l], ell, rowT_ptr, colT_idx, ellT, B, T, Din[l], H[l],
+                                               dh[l], dh_dtype[l], compute_dtype, scale[l], z_frag ? z_frag[l] : nullptr,
+                                               z_frag ? dW[l] : nullptr, z_frag ? db[l] : nullptr, hand_down ? Y[l - 1] : nullptr,
+                                               hand_down ? scale[l - 1] : 1.0f, handed ? 1 : 0, ws, ws_bytes);
             if (rc != GCNPT_OK) return rc;
         }
         g = dh[l];
@@ -802,7 +890,7 @@ extern "C" int gcnpt_layers_bwd(void* stream, int n_layers, const void* gy, cons
                                 const int* dh_dtype, int compute_dtype, const float* scale, void* const* z_frag,
                                 const void* const* s_frag, float* const* dW, float* const* db) {
     return layers_bwd_impl(stream, n_layers, gy, Y, y_dtype, w_bwd, ell, rowT_ptr, colT_idx, ellT, B, T, Din, H, dh, dh_dtype, compute_dtype, scale,
-                           z_frag, s_frag, dW, db, false);
+                           z_frag, s_frag, dW, db, false, nullptr, 0);
 }
 
 // the same sweep when the caller already holds dZ of the TOP layer (gcnpt_pool3_bwd_dz leaves it): the top layer then gathers one
@@ -813,5 +901,16 @@ extern "C" int gcnpt_layers_bwd_dz(void* stream, int n_layers, const void* dz_to
                                    const int* dh_dtype, int compute_dtype, const float* scale, void* const* z_frag,
                                    const void* const* s_frag, float* const* dW, float* const* db) {
     return layers_bwd_impl(stream, n_layers, dz_top, Y, y_dtype, w_bwd, ell, rowT_ptr, colT_idx, ellT, B, T, Din, H, dh, dh_dtype, compute_dtype,
-                           scale, z_frag, s_frag, dW, db, true);
+                           scale, z_frag, s_frag, dW, db, true, nullptr, 0);
+}
+
+// both sweeps with the big-batch workspace (gcnpt_layers_workspace_bytes; NULL / too small: exactly the calls above)
+extern "C" int gcnpt_layers_bwd_ws(void* stream, int n_layers, const void* gy, const void* const* Y, const int* y_dtype,
+                                   const void* const* w_bwd, const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
+                                   const int32_t* ellT, int B, int T, const int* Din, const int* H, void* const* dh,
+                                   const int* dh_dtype, int compute_dtype, const float* scale, void* const* z_frag,
+                                   const void* const* s_frag, float* const* dW, float* const* db, int gy_is_dz, void* workspace,
+                                   size_t workspace_bytes) {
+    return layers_bwd_impl(stream, n_layers, gy, Y, y_dtype, w_bwd, ell, rowT_ptr, colT_idx, ellT, B, T, Din, H, dh, dh_dtype, compute_dtype, scale,
+                           z_frag, s_frag, dW, db, gy_is_dz != 0, workspace, workspace_bytes);
 }

@@ -132,6 +132,13 @@ def gcn_layer(h, weight, bias, trees, drop_p=0.0, seed=0, compute_dtype=torch.fl
     return _GCNLayerFn.apply(h, weight, bias, trees, float(drop_p), int(seed), compute, out_dtype, bool(no_adj), seed_dev)
 
 
+def _layers_workspace(lib, L, B, T, dims, top_dtype, dev):
+    """Scratch for the big-batch layer path (include/gcnpt.h, gcnpt_layers_workspace_bytes); None when that path does not apply."""
+    ints = lambda v: (ctypes.c_int * L)(*v)  # noqa: E731
+    n = lib.gcnpt_layers_workspace_bytes(L, B, T, ints([k for _, k in dims]), ints([h for h, _ in dims]), _lib.dtype_code(top_dtype))
+    return torch.empty((n,), dtype=torch.uint8, device=dev) if n else None
+
+
 class _GCNLayersFn(torch.autograd.Function):
     """The reference's layer loop (model/gcn.py:266-393) as ONE autograd op over the per-layer kernels: one launch packs
     every layer's weights, one launch per layer and direction does the layer, one launch at the end of the backward sweep
@@ -170,12 +177,15 @@ class _GCNLayersFn(torch.autograd.Function):
         g_ell = trees.empty_ell() if cfg["no_adj"] else trees.ell
         outs = [torch.empty(lead + (H,), dtype=cfg["out_dtype"] if l == L - 1 else cfg["mid_dtype"], device=dev) for l, (H, _) in enumerate(dims)]
         s_frag = [torch.empty((lib.gcnpt_frag_bytes(rows, K, compute),), **u8) if need_w else None for _, K in dims]
-        # every layer's launch from ONE native call (gcnpt_layers_fwd): no interpreter time between the launches
-        _lib.check(lib.gcnpt_layers_fwd(
+        # every layer's launch from ONE native call (gcnpt_layers_fwd_ws): no interpreter time between the launches.  Big batches get a
+        # scratch workspace and run every layer as gather + matrix launch (csrc/rowsplit_kernels.hip); ws None: the row-tile kernels
+        ws = _layers_workspace(lib, L, B, T, dims, outs[-1].dtype, dev)
+        _lib.check(lib.gcnpt_layers_fwd_ws(
             st, L, _lib.ptr(x), _lib.dtype_code(x.dtype), _lib.ptr_array(wf), _lib.ptr_array(b32), _lib.ptr(trees.row_ptr),
             _lib.ptr(trees.col_idx), _lib.ptr(g_ell), _lib.ptr(trees.ell), B, T, ints([k for _, k in dims]), ints([h for h, _ in dims]),
             _lib.ptr_array(outs), ints([_lib.dtype_code(o.dtype) for o in outs]), compute, (ctypes.c_float * L)(*cfg["drop_p"]),
-            (ctypes.c_uint64 * L)(*cfg["seed"]), _lib.ptr_array(s_frag), _lib.ptr(cfg.get("seed_dev"))))
+            (ctypes.c_uint64 * L)(*cfg["seed"]), _lib.ptr_array(s_frag), _lib.ptr(cfg.get("seed_dev")), _lib.ptr(ws),
+            ws.numel() if ws is not None else 0))
         ctx.trees, ctx.cfg, ctx.dims, ctx.shape, ctx.need_w = trees, cfg, dims, (B, T, Din, L), need_w
         ctx.rows, ctx.lead = rows, lead
         ctx.x_dtype = x.dtype
@@ -227,13 +237,15 @@ class _GCNLayersFn(torch.autograd.Function):
             dWs = [torch.empty((H, K), dtype=torch.float32, device=dev) for H, K in dims]       # cleared by bwd_data, filled at the end
             dbs = [torch.empty((H,), dtype=torch.float32, device=dev) for H, _ in dims]
         ints = lambda v: (ctypes.c_int * L)(*v)  # noqa: E731
-        # the backward sweep and all weight gradients from ONE native call (gcnpt_layers_bwd; _dz: its first tensor already is dZ)
-        _lib.check((lib.gcnpt_layers_bwd if pool is None else lib.gcnpt_layers_bwd_dz)(
+        # the backward sweep and all weight gradients from ONE native call (gcnpt_layers_bwd_ws; gy_is_dz: its first tensor already is dZ)
+        ws = _layers_workspace(lib, L, B, T, dims, outs[-1].dtype, dev)
+        _lib.check(lib.gcnpt_layers_bwd_ws(
             st, L, _lib.ptr(g), _lib.ptr_array(list(outs)), ints([_lib.dtype_code(o.dtype) for o in outs]), _lib.ptr_array(list(wb)),
             _lib.ptr(trees.ell), _lib.ptr(trees.rowT_ptr), _lib.ptr(trees.colT_idx), _lib.ptr(g_ellT), B, T, ints([k for _, k in dims]),
             ints([h for h, _ in dims]), _lib.ptr_array(dhs), ints([_lib.dtype_code(t) for t in in_dtypes]), compute,
             (ctypes.c_float * L)(*scales), _lib.ptr_array(z_frag) if want_w else None, _lib.ptr_array(list(s_frag)) if want_w else None,
-            _lib.ptr_array(dWs) if want_w else None, _lib.ptr_array(dbs) if want_w else None))
+            _lib.ptr_array(dWs) if want_w else None, _lib.ptr_array(dbs) if want_w else None, 0 if pool is None else 1, _lib.ptr(ws),
+            ws.numel() if ws is not None else 0))
         g = dhs[0]
         grads = [None] * (2 * L)
         if want_w:

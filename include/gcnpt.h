@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define GCNPT_ABI_VERSION 4
+#define GCNPT_ABI_VERSION 5
 
 /* element types of activation / gradient buffers and of the MFMA operands */
 #define GCNPT_F32 0
@@ -276,6 +276,34 @@ int gcnpt_layers_bwd_dz(void* stream, int n_layers, const void* dz_top, const vo
                         const int32_t* ellT, int B, int T, const int* Din, const int* H, void* const* dh, const int* dh_dtype,
                         int compute_dtype, const float* scale, void* const* z_frag, const void* const* s_frag, float* const* dW,
                         float* const* db);
+
+/* EXPERIMENTAL, opt-in with the environment variable GCNPT_ROWSPLIT=1 (measured no faster than the default kernels).
+ * Big batches (>= 16 384 token rows, bf16 compute): with a workspace the layer loop runs every layer as TWO launches -- a gather
+ * that writes the rows aggregating at least one neighbour (plus the weight gradient's fragment image) and a matrix launch that shares
+ * each weight fragment among 8-10 row tiles -- instead of one row-tile launch that pulls the whole weight matrix through its CU per
+ * 32 rows (csrc/rowsplit_kernels.hip; same values bit for bit).  gcnpt_layers_workspace_bytes: bytes that path needs for this shape
+ * (0: it does not apply or is not switched on, pass NULL); top_dtype = dtype of the top layer's output Y.  The workspace [dev] is scratch: nothing in it
+ * outlives a call, one buffer serves forward and backward.  workspace NULL or smaller than asked for: exactly gcnpt_layers_fwd /
+ * gcnpt_layers_bwd (gy_is_dz = 0) / gcnpt_layers_bwd_dz (gy_is_dz = 1).  reference: model/gcn.py:266-271, 390-393 and their autograd.
+ * gcnpt_layer_fwd_ws / gcnpt_layer_bwd_data_ws: gcnpt_layer_fwd / gcnpt_layer_bwd_data with the same workspace (ask for the size with n_layers = 1). */
+size_t gcnpt_layers_workspace_bytes(int n_layers, int B, int T, const int* Din, const int* H, int top_dtype);
+int gcnpt_layer_fwd_ws(void* stream, const void* h, int h_dtype, const void* w_fwd, const float* bias, const int32_t* row_ptr,
+                       const int32_t* col_idx, const int32_t* ell, const int32_t* deg_ell, int B, int T, int Din, int H, void* out,
+                       int out_dtype, int compute_dtype, float drop_p, uint64_t seed, void* s_frag, const uint64_t* seed_dev,
+                       void* workspace, size_t workspace_bytes);
+int gcnpt_layer_bwd_data_ws(void* stream, const void* dY, const void* Y, int g_dtype, const void* w_bwd, const int32_t* ell,
+                            const int32_t* rowT_ptr, const int32_t* colT_idx, const int32_t* ellT, int B, int T, int Din, int H,
+                            void* dh, int dh_dtype, int compute_dtype, float scale, void* z_frag, float* zero_dW, float* zero_db,
+                            const void* relu_src, float next_scale, int src_is_dz, void* workspace, size_t workspace_bytes);
+int gcnpt_layers_fwd_ws(void* stream, int n_layers, const void* x, int x_dtype, const void* const* w_fwd, const float* const* bias,
+                        const int32_t* row_ptr, const int32_t* col_idx, const int32_t* ell, const int32_t* deg_ell, int B, int T,
+                        const int* Din, const int* H, void* const* out, const int* out_dtype, int compute_dtype, const float* drop_p,
+                        const uint64_t* seed, void* const* s_frag, const uint64_t* seed_dev, void* workspace, size_t workspace_bytes);
+int gcnpt_layers_bwd_ws(void* stream, int n_layers, const void* gy, const void* const* Y, const int* y_dtype,
+                        const void* const* w_bwd, const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
+                        const int32_t* ellT, int B, int T, const int* Din, const int* H, void* const* dh, const int* dh_dtype,
+                        int compute_dtype, const float* scale, void* const* z_frag, const void* const* s_frag, float* const* dW,
+                        float* const* db, int gy_is_dz, void* workspace, size_t workspace_bytes);
 
 /* ---- N2: adj_type == 'diagonal_deprel', model/gcn.py:272-294 (+ 390-393) -------------------------------------------
  * No weight matrix: out[r] = dropout(relu((sum_{c: 0<adj[r,c]<42} E[deprel[c]]*h[c] + sum_{c: 42<adj[r,c]<84}

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(handle, n), "libgcnpt.so does not export %s" % n
     assert sorted(_lib.SIGNATURES) == names                      # the ctypes binding covers the header, nothing else
-    assert _lib.lib().gcnpt_abi_version() == _lib.ABI_VERSION == 4
+    assert _lib.lib().gcnpt_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_argument_validation_needs_no_gpu():
@@ -57,6 +57,17 @@ def test_argument_validation_needs_no_gpu():
     assert b"dh[1] must exist" in L.gcnpt_last_error()
     assert L.gcnpt_layers_bwd(None, 2, p, ptrs, two(0, 0), ptrs, p, p, p, p, 1, 1, two(8, 8), two(8, 8), ptrs, two(0, 0), 0, f2, ptrs, None, None, None) == _lib.E_INVALID
     assert b"weight gradients need" in L.gcnpt_last_error()
+    # the big-batch workspace: none below 16 384 token rows, [rows x widest side, bf16] + [rows x H_top] above
+    # (the two-launch layer form is opt-in: no workspace is asked for without GCNPT_ROWSPLIT=1)
+    os.environ.pop("GCNPT_ROWSPLIT", None)
+    assert L.gcnpt_layers_workspace_bytes(2, 128, 300, two(600, 300), two(300, 300), _lib.BF16) == 0
+    os.environ["GCNPT_ROWSPLIT"] = "1"
+    try:
+        assert L.gcnpt_layers_workspace_bytes(2, 50, 100, two(360, 200), two(200, 200), _lib.BF16) == 0
+        assert L.gcnpt_layers_workspace_bytes(2, 128, 300, two(600, 300), two(300, 300), _lib.BF16) == 38400 * 600 * 2 + 38400 * 300 * 2
+        assert L.gcnpt_layers_workspace_bytes(9, 128, 300, two(600, 300), two(300, 300), _lib.BF16) == 0
+    finally:
+        os.environ.pop("GCNPT_ROWSPLIT", None)
     assert L.gcnpt_compact_trees(None, p, p, None, None, None, p, None, p, p, 1, 4, 12, 0, 12, p, p, None, None, None, p, None, p, p, p, p) == _lib.E_INVALID
     assert L.gcnpt_compact_trees(None, p, p, None, None, None, p, None, p, p, 1, 4, 12, 4, 12, p, p, p, None, None, p, None, p, p, p, p) == _lib.E_INVALID
     assert b"labels wanted" in L.gcnpt_last_error()

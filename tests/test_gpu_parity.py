@@ -1499,7 +1499,8 @@ def test_cgcn_full_size_layer_stack_vs_oracle(api, dev):
     B, T, K = 50, 100, 1
     opt = dict(vocab_size=500, emb_dim=300, pos_dim=30, ner_dim=30, hidden_dim=200, num_layers=2, input_dropout=0.0, gcn_dropout=0.0,
                word_dropout=0.0, prune_k=K, pooling="max", mlp_layers=2, rnn=True, rnn_hidden=200, rnn_layers=1, rnn_dropout=0.0,
-               dataset="tacred", num_class=42, topn=10 ** 9, cuda=True, conv_l2=0.0, pooling_l2=0.003, adj_type="regular")
+               dataset="tacred", num_class=42, topn=10 ** 9, cuda=True, conv_l2=0.0, pooling_l2=0.003, adj_type="regular",
+               gcn_pool_handover=False)        # (the hooks below need h itself: with the hand-over the GCN submodule returns the pooled vectors)
     torch.manual_seed(5)
     model = gcn.GCNClassifier(opt).to(dev).train()
     tb = synthetic.random_tree_batch(61, B, T, "tacred")

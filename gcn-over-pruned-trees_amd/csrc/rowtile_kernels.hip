@@ -157,6 +157,12 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
                 if (p.knob & 1) { wreg[ks][j] = wfrag[lane]; continue; }          // experiment: no weight traffic
 #endif
                 wreg[ks][j] = wfrag[((size_t)tl * ksteps + kk) * 64 + lane];
+#ifdef GCNPT_STAMPS
+                if (p.knob & 16) {      // experiment (VERDICT item 2b by proxy): twice the weight bytes through the CU, as an fp32 source would need
+                    const uint4 extra = wfrag[((size_t)(n_tiles - 1 - tl) * ksteps + (ksteps - 1 - kk)) * 64 + lane];
+                    asm volatile("" ::"v"(extra.x), "v"(extra.y), "v"(extra.z), "v"(extra.w));
+                }
+#endif
             }
     };
     // (The MFMAs run with swapped operands, weights as A, so a lane ends up with 4 CONSECUTIVE output columns of one row:

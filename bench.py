@@ -79,6 +79,8 @@ def parse():
     ap.add_argument("--no-kernel-breakdown", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements on rank 0 (with_prune, with_cached_trees, the fp32 "
                                                                 "strict-parity block): quick runs and tests")
+    ap.add_argument("--separate-pack", action="store_true", help="A/B: keep the weight pack a launch of its own in the with_prune / "
+                    "with_cached_trees steps instead of a side job of the tree launch")
     ap.add_argument("--no-pooled-only", action="store_true", help="skip the secondary pooled-only-rows measurement (profiling runs: its launches "
                                                                   "would mix into the per-kernel statistics of the headline step)")
     return ap.parse_args()
@@ -170,19 +172,21 @@ class Stack(object):
         return f[o[0]:o[1]], f[o[1]:o[2]], f[o[2]:o[3]], f[o[3]:]
 
     # ---- individual C-ABI calls (each only enqueues on the current stream) ----
-    def prune(self):
+    def prune(self, pack=False):
+        """pack: the same launch also packs the weights (gcnpt_prune_to_csr_pack: side job on the CUs the tree build leaves idle)."""
         tr, P, st = self.trees, self._lib.ptr, self._lib.stream()
-        self._lib.check(self.L.gcnpt_prune_to_csr(st, P(self.head), P(self.subj), P(self.obj), P(self.deprel), P(self.masks), None,
-                                                  self.B, self.T, self.args.prune_k, tr.cap, P(tr.row_ptr), P(tr.col_idx), None,
-                                                  P(tr.rowT_ptr), P(tr.colT_idx), P(tr.ell), P(tr.ellT), P(tr.pool_mask), P(tr.status)))
+        a = (st, P(self.head), P(self.subj), P(self.obj), P(self.deprel), P(self.masks), None,
+             self.B, self.T, self.args.prune_k, tr.cap, P(tr.row_ptr), P(tr.col_idx), None,
+             P(tr.rowT_ptr), P(tr.colT_idx), P(tr.ell), P(tr.ellT), P(tr.pool_mask), P(tr.status))
+        self._lib.check(self.L.gcnpt_prune_to_csr_pack(*(a + self._native_args(0)[0])) if pack else self.L.gcnpt_prune_to_csr(*a))
 
-    def gather(self):
+    def gather(self, pack=False):
         """The batch's PrunedTrees from the cached dataset (gcnpt_gather_trees) into the same buffers prune() fills."""
         tr, src, P = self.trees, self.cache.trees, self._lib.ptr
-        self._lib.check(self.L.gcnpt_gather_trees(
-            self._lib.stream(), P(src.row_ptr), P(src.col_idx), None, P(src.rowT_ptr), P(src.colT_idx), P(src.ell), P(src.ellT),
-            P(src.pool_mask), P(src.status), P(self.cache.lens), src.B, src.T, src.cap, P(self.cache_idx), self.B, self.T, tr.cap,
-            P(tr.row_ptr), P(tr.col_idx), None, P(tr.rowT_ptr), P(tr.colT_idx), P(tr.ell), P(tr.ellT), P(tr.pool_mask), P(tr.status)))
+        a = (self._lib.stream(), P(src.row_ptr), P(src.col_idx), None, P(src.rowT_ptr), P(src.colT_idx), P(src.ell), P(src.ellT),
+             P(src.pool_mask), P(src.status), P(self.cache.lens), src.B, src.T, src.cap, P(self.cache_idx), self.B, self.T, tr.cap,
+             P(tr.row_ptr), P(tr.col_idx), None, P(tr.rowT_ptr), P(tr.colT_idx), P(tr.ell), P(tr.ellT), P(tr.pool_mask), P(tr.status))
+        self._lib.check(self.L.gcnpt_gather_trees_pack(*(a + self._native_args(0)[0])) if pack else self.L.gcnpt_gather_trees(*a))
 
     def pack(self, l):
         P = self._lib.ptr
@@ -267,16 +271,17 @@ class Stack(object):
         The argument lists are built once: the host has ~50 us per step for six launches and must not spend them marshalling."""
         pack, fwd, bwd = self._native_args(k)
         st = self._lib.stream()
+        merged = bool(with_prune) and not self.args.separate_pack and not self.args.fused2       # the tree launch carries the weight pack
         if with_prune == "cached":
-            self.gather()
+            self.gather(pack=merged)
         elif with_prune:
-            self.prune()
+            self.prune(pack=merged)
         L = self.L
         if self.args.fused2:                    # opt-in A/B: the step with the two-layer forward launch (eager launches from Python)
             for _, call in self.calls(k):
                 call()
             return
-        rc = L.gcnpt_pack_weights_multi(st, *pack) or L.gcnpt_layers_fwd_ws(st, *fwd) or L.gcnpt_layers_bwd_ws(st, *bwd)
+        rc = (0 if merged else L.gcnpt_pack_weights_multi(st, *pack)) or L.gcnpt_layers_fwd_ws(st, *fwd) or L.gcnpt_layers_bwd_ws(st, *bwd)
         if rc:
             self._lib.check(rc)
 
@@ -362,11 +367,12 @@ class Stack(object):
         side stream (fork and join are inside the step, so they become parallel branches of the captured graph).
         """
         if self.args.streams == 1 or self.fused:
+            merged = bool(with_prune) and not self.args.separate_pack and not self.fused and not self.args.fused2
             if with_prune == "cached":
-                self.gather()
+                self.gather(pack=merged)
             elif with_prune:
-                self.prune()
-            for _, call in self.calls(k):
+                self.prune(pack=merged)
+            for _, call in self.calls(k)[1 if merged else 0:]:
                 call()
             return
         main = torch.cuda.current_stream()
@@ -764,9 +770,11 @@ def main():
         }
         if not args.no_secondary:
             result["with_prune"] = {"value": args.batch * args.steps / wall_p, "unit": "sentences/s", "ms_per_step": wall_p / args.steps * 1e3,
-                                    "note": "rank 0, pruned-tree adjacency build (gcnpt_prune_to_csr) inside every step"}
+                                    "note": "rank 0, pruned-tree adjacency build inside every step; the tree launch carries the weight pack as a "
+                                            "side job (gcnpt_prune_to_csr_pack: one launch boundary less)"}
             result["with_cached_trees"] = {"value": args.batch * args.steps / wall_c, "unit": "sentences/s", "ms_per_step": wall_c / args.steps * 1e3,
-                                           "note": "rank 0, dataset pruned once; every step assembles its batch's adjacency with gcnpt_gather_trees"}
+                                           "note": "rank 0, dataset pruned once; every step assembles its batch's adjacency with gcnpt_gather_trees_pack (the weight "
+                                                   "pack rides in the same launch)"}
             if args.dtype == "bf16":
                 # the reference's own arithmetic: fp32 activations, exact fp32 MFMA (the strict-parity mode of the tests), same step
                 import copy

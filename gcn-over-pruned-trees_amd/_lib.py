@@ -19,6 +19,7 @@ SIGNATURES = {
     "gcnpt_abi_version": (_i, []),
     "gcnpt_last_error": (ctypes.c_char_p, []),
     "gcnpt_prune_to_csr": (_i, [_p] * 7 + [_i] * 4 + [_p] * 9),
+    "gcnpt_prune_to_csr_pack": (_i, [_p] * 7 + [_i] * 4 + [_p] * 9 + [_i, _p, _p, _p, _i, _p, _p]),
     "gcnpt_adj_to_csr": (_i, [_p, _p, _i, _i, _i] + [_p] * 9),
     "gcnpt_csr_to_adj": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "gcnpt_packed_bytes": (_sz, [_i, _i, _i]),
@@ -50,6 +51,7 @@ SIGNATURES = {
     "gcnpt_diag_layer_fwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p, _f, _u64, _p]),
     "gcnpt_diag_layer_bwd": (_i, [_p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _f]),
     "gcnpt_gather_trees": (_i, [_p] * 11 + [_i, _i, _i, _p, _i, _i, _i] + [_p] * 9),
+    "gcnpt_gather_trees_pack": (_i, [_p] * 11 + [_i, _i, _i, _p, _i, _i, _i] + [_p] * 9 + [_i, _p, _p, _p, _i, _p, _p]),
     "gcnpt_compact_trees": (_i, [_p] * 10 + [_i] * 5 + [_p] * 11),
     "gcnpt_bilinear_packed_bytes": (_sz, [_i, _i, _i]),
     "gcnpt_bilinear_supported": (_i, [_i, _i, _i]),

@@ -12,6 +12,7 @@
 //   dist[i] = edges from i up to its first ancestor-or-self in P (infinite if none);  keep = dist <= K;
 //   edges = {(head[i]-1 -> i) : keep[i], i != lca, head[i] > 0}.
 #include "gcnpt_common.h"
+#include "pack_common.h"
 
 namespace gcnpt {
 
@@ -367,9 +368,13 @@ __global__ __launch_bounds__(PRUNE_THREADS) void prune_to_csr_kernel(
     int B, int T, int prune_k, int cap, int32_t* __restrict__ row_ptr, int32_t* __restrict__ col_idx,
     int32_t* __restrict__ label, int32_t* __restrict__ rowT_ptr, int32_t* __restrict__ colT_idx,
     int32_t* __restrict__ ell, int32_t* __restrict__ ellT, uint8_t* __restrict__ pool_mask,
-    int32_t* __restrict__ status, unsigned long long* stamps) {
+    int32_t* __restrict__ status, unsigned long long* stamps, const PackParams pk, int pk_dtype) {
     extern __shared__ int smem[];  // carved in prune_sentence()
     __shared__ int s_err;
+    if ((int)blockIdx.x >= B) {    // side job of gcnpt_prune_to_csr_pack: the launch leaves most CUs idle, these workgroups pack the weights
+        pack_side_job(pk, pk_dtype, B);
+        return;
+    }
 
     __shared__ int s_status, s_nrows;
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -502,8 +507,13 @@ struct TreeArrays {
 };
 __global__ __launch_bounds__(GATHER_THREADS) void gather_trees_kernel(const TreeArrays src, const int32_t* __restrict__ src_len,
                                                                      int S, int Ts, int cap_s, const int64_t* __restrict__ idx,
-                                                                     int B, int T, int cap, const TreeArrays dst) {
+                                                                     int B, int T, int cap, const TreeArrays dst, const PackParams pk,
+                                                                     int pk_dtype) {
     __shared__ int s_max[GATHER_THREADS / WAVE];
+    if ((int)blockIdx.x >= B) {    // side job of gcnpt_gather_trees_pack
+        pack_side_job(pk, pk_dtype, B);
+        return;
+    }
     const int b = blockIdx.x, t = threadIdx.x;
     const int64_t s64 = idx[b];
     const bool known = s64 >= 0 && s64 < S;
@@ -650,11 +660,12 @@ __global__ __launch_bounds__(COMPACT_THREADS) void compact_trees_kernel(const Tr
 
 using namespace gcnpt;
 
-extern "C" int gcnpt_prune_to_csr(void* stream, const int64_t* head, const int64_t* subj_pos, const int64_t* obj_pos,
-                                  const int64_t* deprel, const uint8_t* pad_mask, const int32_t* len, int B, int T,
-                                  int prune_k, int cap, int32_t* row_ptr, int32_t* col_idx, int32_t* label,
-                                  int32_t* rowT_ptr, int32_t* colT_idx, int32_t* ell, int32_t* ellT, uint8_t* pool_mask,
-                                  int32_t* status) {
+// pack_blocks > 0: that many extra workgroups of the launch pack the weights described by pk (side job)
+static int prune_impl(void* stream, const int64_t* head, const int64_t* subj_pos, const int64_t* obj_pos,
+                      const int64_t* deprel, const uint8_t* pad_mask, const int32_t* len, int B, int T,
+                      int prune_k, int cap, int32_t* row_ptr, int32_t* col_idx, int32_t* label,
+                      int32_t* rowT_ptr, int32_t* colT_idx, int32_t* ell, int32_t* ellT, uint8_t* pool_mask,
+                      int32_t* status, const PackParams& pk, int pk_dtype, int pack_blocks) {
     GCNPT_REQUIRE(head && subj_pos && obj_pos && deprel && (pad_mask || len), "prune_to_csr: null input pointer");
     GCNPT_REQUIRE(row_ptr && col_idx && ell && status, "prune_to_csr: null output pointer");
     GCNPT_REQUIRE((rowT_ptr == nullptr) == (ellT == nullptr), "prune_to_csr: rowT_ptr, colT_idx and ellT go together");
@@ -670,11 +681,38 @@ extern "C" int gcnpt_prune_to_csr(void* stream, const int64_t* head, const int64
     // sentences beyond ~2300 tokens need more than the default 64 KB of LDS (7 words per token); minus the kernel's few static words
     if (lds > 64 * 1024) GCNPT_LDS_ATTR_ONCE(prune_to_csr_kernel, 160 * 1024 - 256);
     if ((long long)B * T > PRUNE_SCAN_MAX) GCNPT_HIP_CHECK(hipMemsetAsync(status + B, 0, sizeof(int32_t), s));   // big batches: atomicMax per sentence
-    hipLaunchKernelGGL(prune_to_csr_kernel, dim3(B), dim3(PRUNE_THREADS), lds, s, head, subj_pos, obj_pos, deprel,
+    hipLaunchKernelGGL(prune_to_csr_kernel, dim3(B + pack_blocks), dim3(PRUNE_THREADS), lds, s, head, subj_pos, obj_pos, deprel,
                        pad_mask, len, B, T, prune_k, cap, row_ptr, col_idx, label, rowT_ptr, colT_idx, ell, ellT, pool_mask, status,
-                       static_cast<unsigned long long*>(g_debug_stamps));
+                       static_cast<unsigned long long*>(g_debug_stamps), pk, pk_dtype);
     GCNPT_HIP_CHECK(hipGetLastError());
     return GCNPT_OK;
+}
+
+extern "C" int gcnpt_prune_to_csr(void* stream, const int64_t* head, const int64_t* subj_pos, const int64_t* obj_pos,
+                                  const int64_t* deprel, const uint8_t* pad_mask, const int32_t* len, int B, int T,
+                                  int prune_k, int cap, int32_t* row_ptr, int32_t* col_idx, int32_t* label,
+                                  int32_t* rowT_ptr, int32_t* colT_idx, int32_t* ell, int32_t* ellT, uint8_t* pool_mask,
+                                  int32_t* status) {
+    return prune_impl(stream, head, subj_pos, obj_pos, deprel, pad_mask, len, B, T, prune_k, cap, row_ptr, col_idx, label, rowT_ptr, colT_idx,
+                      ell, ellT, pool_mask, status, PackParams{}, GCNPT_F32, 0);
+}
+
+// workgroups a side-job pack adds to a launch of `threads` per workgroup: enough for one fragment per thread, at most 192
+static int pack_side_blocks(const PackParams& pk, int threads) {
+    return (int)std::min<long long>(192, (pk.first[pk.n_layers] + threads - 1) / threads);
+}
+
+extern "C" int gcnpt_prune_to_csr_pack(void* stream, const int64_t* head, const int64_t* subj_pos, const int64_t* obj_pos,
+                                       const int64_t* deprel, const uint8_t* pad_mask, const int32_t* len, int B, int T,
+                                       int prune_k, int cap, int32_t* row_ptr, int32_t* col_idx, int32_t* label,
+                                       int32_t* rowT_ptr, int32_t* colT_idx, int32_t* ell, int32_t* ellT, uint8_t* pool_mask,
+                                       int32_t* status, int n_layers, const float* const* W, const int* H, const int* Din, int dtype,
+                                       void* const* w_fwd, void* const* w_bwd) {
+    PackParams pk;
+    const int rc = fill_pack_params(pk, n_layers, W, H, Din, dtype, w_fwd, w_bwd);
+    if (rc != GCNPT_OK) return rc;
+    return prune_impl(stream, head, subj_pos, obj_pos, deprel, pad_mask, len, B, T, prune_k, cap, row_ptr, col_idx, label, rowT_ptr, colT_idx,
+                      ell, ellT, pool_mask, status, pk, dtype, pack_side_blocks(pk, PRUNE_THREADS));
 }
 
 extern "C" int gcnpt_adj_to_csr(void* stream, const float* adj, int B, int T, int cap, int32_t* row_ptr,
@@ -707,12 +745,12 @@ extern "C" int gcnpt_csr_to_adj(void* stream, const int32_t* row_ptr, const int3
     return GCNPT_OK;
 }
 
-extern "C" int gcnpt_gather_trees(void* stream, const int32_t* src_row_ptr, const int32_t* src_col_idx, const int32_t* src_label,
-                                  const int32_t* src_rowT_ptr, const int32_t* src_colT_idx, const int32_t* src_ell,
-                                  const int32_t* src_ellT, const uint8_t* src_pool_mask, const int32_t* src_status,
-                                  const int32_t* src_len, int S, int Ts, int cap_s, const int64_t* idx, int B, int T, int cap,
-                                  int32_t* row_ptr, int32_t* col_idx, int32_t* label, int32_t* rowT_ptr, int32_t* colT_idx,
-                                  int32_t* ell, int32_t* ellT, uint8_t* pool_mask, int32_t* status) {
+static int gather_impl(void* stream, const int32_t* src_row_ptr, const int32_t* src_col_idx, const int32_t* src_label,
+                       const int32_t* src_rowT_ptr, const int32_t* src_colT_idx, const int32_t* src_ell,
+                       const int32_t* src_ellT, const uint8_t* src_pool_mask, const int32_t* src_status,
+                       const int32_t* src_len, int S, int Ts, int cap_s, const int64_t* idx, int B, int T, int cap,
+                       int32_t* row_ptr, int32_t* col_idx, int32_t* label, int32_t* rowT_ptr, int32_t* colT_idx,
+                       int32_t* ell, int32_t* ellT, uint8_t* pool_mask, int32_t* status, const PackParams& pk, int pk_dtype, int pack_blocks) {
     GCNPT_REQUIRE(src_row_ptr && src_col_idx && src_ell && src_status && src_len && idx, "gather_trees: null cache pointer");
     GCNPT_REQUIRE(row_ptr && col_idx && ell && status, "gather_trees: null output pointer");
     GCNPT_REQUIRE(S > 0 && Ts > 0 && cap_s > 0 && B > 0 && T > 0 && cap > 0, "gather_trees: sizes must be positive");
@@ -727,10 +765,37 @@ extern "C" int gcnpt_gather_trees(void* stream, const int32_t* src_row_ptr, cons
                          const_cast<int32_t*>(src_ell), const_cast<int32_t*>(src_ellT), const_cast<uint8_t*>(src_pool_mask),
                          const_cast<int32_t*>(src_status)};
     const TreeArrays dst{row_ptr, col_idx, label, rowT_ptr, colT_idx, ell, ellT, pool_mask, status};
-    hipLaunchKernelGGL(gather_trees_kernel, dim3(B), dim3(GATHER_THREADS), 0, (hipStream_t)stream, src, src_len, S, Ts, cap_s, idx, B, T,
-                       cap, dst);
+    hipLaunchKernelGGL(gather_trees_kernel, dim3(B + pack_blocks), dim3(GATHER_THREADS), 0, (hipStream_t)stream, src, src_len, S, Ts, cap_s, idx,
+                       B, T, cap, dst, pk, pk_dtype);
     GCNPT_HIP_CHECK(hipGetLastError());
     return GCNPT_OK;
+}
+
+extern "C" int gcnpt_gather_trees(void* stream, const int32_t* src_row_ptr, const int32_t* src_col_idx, const int32_t* src_label,
+                                  const int32_t* src_rowT_ptr, const int32_t* src_colT_idx, const int32_t* src_ell,
+                                  const int32_t* src_ellT, const uint8_t* src_pool_mask, const int32_t* src_status,
+                                  const int32_t* src_len, int S, int Ts, int cap_s, const int64_t* idx, int B, int T, int cap,
+                                  int32_t* row_ptr, int32_t* col_idx, int32_t* label, int32_t* rowT_ptr, int32_t* colT_idx,
+                                  int32_t* ell, int32_t* ellT, uint8_t* pool_mask, int32_t* status) {
+    return gather_impl(stream, src_row_ptr, src_col_idx, src_label, src_rowT_ptr, src_colT_idx, src_ell, src_ellT, src_pool_mask, src_status,
+                       src_len, S, Ts, cap_s, idx, B, T, cap, row_ptr, col_idx, label, rowT_ptr, colT_idx, ell, ellT, pool_mask, status,
+                       PackParams{}, GCNPT_F32, 0);
+}
+
+extern "C" int gcnpt_gather_trees_pack(void* stream, const int32_t* src_row_ptr, const int32_t* src_col_idx, const int32_t* src_label,
+                                       const int32_t* src_rowT_ptr, const int32_t* src_colT_idx, const int32_t* src_ell,
+                                       const int32_t* src_ellT, const uint8_t* src_pool_mask, const int32_t* src_status,
+                                       const int32_t* src_len, int S, int Ts, int cap_s, const int64_t* idx, int B, int T, int cap,
+                                       int32_t* row_ptr, int32_t* col_idx, int32_t* label, int32_t* rowT_ptr, int32_t* colT_idx,
+                                       int32_t* ell, int32_t* ellT, uint8_t* pool_mask, int32_t* status, int n_layers,
+                                       const float* const* W, const int* H, const int* Din, int dtype, void* const* w_fwd,
+                                       void* const* w_bwd) {
+    PackParams pk;
+    const int rc = fill_pack_params(pk, n_layers, W, H, Din, dtype, w_fwd, w_bwd);
+    if (rc != GCNPT_OK) return rc;
+    return gather_impl(stream, src_row_ptr, src_col_idx, src_label, src_rowT_ptr, src_colT_idx, src_ell, src_ellT, src_pool_mask, src_status,
+                       src_len, S, Ts, cap_s, idx, B, T, cap, row_ptr, col_idx, label, rowT_ptr, colT_idx, ell, ellT, pool_mask, status,
+                       pk, dtype, pack_side_blocks(pk, GATHER_THREADS));
 }
 
 extern "C" int gcnpt_compact_trees(void* stream, const int32_t* src_row_ptr, const int32_t* src_col_idx, const int32_t* src_label,

@@ -1,71 +1,14 @@
 // Weight-side kernels (gfx950): nn.Linear weights -> MFMA fragment order, and the weight/bias gradient
 // dW += dZ^T ((A+I) h), db += 2 sum dZ of reference model/gcn.py:270-271 (autograd).
 #include "layer_common.h"
+#include "pack_common.h"
 
 namespace gcnpt {
 
 
-// ---------------------------------------------------------------------------------------------------
-// nn.Linear weight [H,Din] fp32 -> MFMA B-operand fragments
-//   fragment (tile, kstep, lane) = 16 bytes:
-//     bf16: 8 values  B[k = 32 kstep + 8 (lane>>4) + j][n = 16 tile + (lane&15)],  j = 0..7
-//     f32 : 4 values  B[k = 16 kstep + 4 (lane>>4) + s][n = 16 tile + (lane&15)],  s = 0..3
-//   forward image : B[k][n] = W[n][k]  (n over H,   k over Din)
-//   backward image: B[k][n] = W[k][n]  (n over Din, k over H)
-// ---------------------------------------------------------------------------------------------------
-constexpr int PACK_MAX_LAYERS = 8;
-struct PackParams {
-    const float* W[PACK_MAX_LAYERS];
-    uint4* wf[PACK_MAX_LAYERS];
-    uint4* wb[PACK_MAX_LAYERS];
-    int H[PACK_MAX_LAYERS], Din[PACK_MAX_LAYERS];
-    long long first[PACK_MAX_LAYERS + 1];      // fragment index range of each layer in the launch
-    int n_layers;
-};
-
-// one launch packs every layer of the stack (weights change once per optimizer step)
 template <typename CT>
 __global__ void pack_weights_kernel(const PackParams p) {
-    constexpr int KSTEP = sizeof(CT) == 2 ? 32 : 16;
-    constexpr int PER = sizeof(CT) == 2 ? 8 : 4;
-    for (long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x; gid < p.first[p.n_layers];
-         gid += (long long)gridDim.x * blockDim.x) {
-        int l = 0;
-#pragma unroll
-        for (int i = 1; i < PACK_MAX_LAYERS; ++i) l += (i < p.n_layers && gid >= p.first[i]) ? 1 : 0;
-        const float* W = p.W[l];
-        const int H = p.H[l], Din = p.Din[l];
-        const int ksf = round_up(Din, KSTEP) / KSTEP, ntf = ceil_div(H, 16);
-        const int ksb = round_up(H, KSTEP) / KSTEP;
-        const long long nf = p.wf[l] ? (long long)ntf * ksf * 64 : 0;
-        const long long id = gid - p.first[l];
-        const bool bwd = id >= nf;
-        const long long f = bwd ? id - nf : id;
-        const int ks_n = bwd ? ksb : ksf;
-        const int lane = (int)(f & 63);
-        const int ks = (int)((f >> 6) % ks_n), tl = (int)((f >> 6) / ks_n);
-        const int n = tl * 16 + (lane & 15);
-        const int kb = ks * KSTEP + (lane >> 4) * PER;
-        float v[PER];
-#pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            const int k = kb + j;
-            // unconditional clamped load + select (a conditional load would serialise the 8 of them)
-            const int rr = bwd ? k : n, cc = bwd ? n : k;
-            const float x = W[(size_t)min(rr, H - 1) * Din + min(cc, Din - 1)];
-            v[j] = (rr < H && cc < Din) ? x : 0.0f;
-        }
-        uint4 u;
-        if constexpr (sizeof(CT) == 2) {
-            u.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-            u.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-            u.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
-            u.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
-        } else {
-            u.x = __float_as_uint(v[0]); u.y = __float_as_uint(v[1]); u.z = __float_as_uint(v[2]); u.w = __float_as_uint(v[3]);
-        }
-        (bwd ? p.wb[l] : p.wf[l])[f] = u;
-    }
+    pack_fragments<CT>(p, (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -262,12 +205,13 @@ extern "C" size_t gcnpt_packed_bytes(int n_out, int k_in, int dtype) {
     return (size_t)ceil_div(n_out, 16) * ks * 64 * 16;
 }
 
-extern "C" int gcnpt_pack_weights_multi(void* stream, int n_layers, const float* const* W, const int* H, const int* Din,
-                                        int dtype, void* const* w_fwd, void* const* w_bwd) {
+namespace gcnpt {
+int fill_pack_params(PackParams& p, int n_layers, const float* const* W, const int* H, const int* Din, int dtype, void* const* w_fwd,
+                     void* const* w_bwd) {
     GCNPT_REQUIRE(n_layers >= 1 && n_layers <= PACK_MAX_LAYERS, "pack_weights: 1..%d layers per call", PACK_MAX_LAYERS);
     GCNPT_REQUIRE(W && H && Din && w_fwd && w_bwd, "pack_weights: null pointer");
     GCNPT_REQUIRE(dtype == GCNPT_F32 || dtype == GCNPT_BF16, "pack_weights: dtype %d", dtype);
-    PackParams p{};
+    p = PackParams{};
     p.n_layers = n_layers;
     p.first[0] = 0;
     for (int l = 0; l < n_layers; ++l) {
@@ -279,6 +223,15 @@ extern "C" int gcnpt_pack_weights_multi(void* stream, int n_layers, const float*
                              (w_bwd[l] ? gcnpt_packed_bytes(Din[l], H[l], dtype) : 0) / 16;
         p.first[l + 1] = p.first[l] + (long long)frags;
     }
+    return GCNPT_OK;
+}
+}  // namespace gcnpt
+
+extern "C" int gcnpt_pack_weights_multi(void* stream, int n_layers, const float* const* W, const int* H, const int* Din,
+                                        int dtype, void* const* w_fwd, void* const* w_bwd) {
+    PackParams p;
+    const int rc = fill_pack_params(p, n_layers, W, H, Din, dtype, w_fwd, w_bwd);
+    if (rc != GCNPT_OK) return rc;
     const int grid = (int)((p.first[n_layers] + 255) / 256);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == GCNPT_BF16) hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, p);

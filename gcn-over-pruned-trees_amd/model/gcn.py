@@ -132,6 +132,35 @@ def gcn_layer(h, weight, bias, trees, drop_p=0.0, seed=0, compute_dtype=torch.fl
     return _GCNLayerFn.apply(h, weight, bias, trees, float(drop_p), int(seed), compute, out_dtype, bool(no_adj), seed_dev)
 
 
+class WeightPack(object):
+    """The layer weights' MFMA-order images (gcnpt_pack_weights_multi) as a request that another launch can carry as a side job:
+    `prune_to_csr(..., pack=wp)` / `TreeCache.batch(..., pack=wp)` build the trees and fill wp.wf / wp.wb in ONE launch
+    (include/gcnpt.h, gcnpt_prune_to_csr_pack); the layer op then takes the images from the request when they still belong to the
+    current weights (same storage, same version counters), and packs as usual otherwise."""
+
+    def __init__(self, Ws, compute, dev):
+        lib = _lib.lib()
+        self.key = WeightPack.key_of(Ws, compute, dev)
+        self.compute = compute
+        self.dims = [tuple(w.shape) for w in Ws]
+        self.w32 = [w.detach().to(torch.float32).contiguous() for w in Ws]
+        u8 = dict(dtype=torch.uint8, device=dev)
+        self.wf = [torch.empty((lib.gcnpt_packed_bytes(h, k, compute),), **u8) for h, k in self.dims]
+        self.wb = [torch.empty((lib.gcnpt_packed_bytes(k, h, compute),), **u8) for h, k in self.dims]
+        self.launched = False                      # set by the launch that carried the request
+
+    @staticmethod
+    def key_of(Ws, compute, dev):
+        return (compute, str(dev)) + tuple((w.data_ptr(), w._version, tuple(w.shape)) for w in Ws)
+
+    def c_args(self):
+        """The trailing arguments of gcnpt_pack_weights_multi / gcnpt_*_pack."""
+        L = len(self.dims)
+        ints = lambda v: (ctypes.c_int * L)(*v)  # noqa: E731
+        return (L, _lib.ptr_array(self.w32), ints([h for h, _ in self.dims]), ints([k for _, k in self.dims]), self.compute,
+                _lib.ptr_array(self.wf), _lib.ptr_array(self.wb))
+
+
 def _layers_workspace(lib, L, B, T, dims, top_dtype, dev):
     """Scratch for the big-batch layer path (include/gcnpt.h, gcnpt_layers_workspace_bytes); None when that path does not apply."""
     ints = lambda v: (ctypes.c_int * L)(*v)  # noqa: E731
@@ -156,21 +185,25 @@ class _GCNLayersFn(torch.autograd.Function):
                 raise RuntimeError("GCN layer %d: weight %s does not fit an input of width %d" % (l, (h, k), Din if l == 0 else dims[l - 1][0]))
         lib, st, dev, compute = _lib.lib(), _lib.stream(), x.device, cfg["compute"]
         x = x.contiguous()
-        w32 = [w.detach().to(torch.float32).contiguous() for w in Ws]
         b32 = [b.detach().to(torch.float32).contiguous() for b in bs]
         u8 = dict(dtype=torch.uint8, device=dev)
         ints = lambda v: (ctypes.c_int * L)(*v)  # noqa: E731
         # the fragment-order images only change when an optimizer step (or a load_state_dict) rewrites a weight in place, which bumps
-        # the tensor's version counter: a module passes its cache and eval() / gradient-accumulation forwards skip the pack launch
+        # the tensor's version counter: a module passes its cache and eval() / gradient-accumulation forwards skip the pack launch;
+        # a training step that builds its trees in the same forward gets them from that launch's side job (WeightPack)
         cache = None if torch.cuda.is_current_stream_capturing() else cfg.get("wcache")     # (a captured step must contain its pack)
-        key = (compute, str(dev)) + tuple((w.data_ptr(), w._version, tuple(w.shape)) for w in Ws)
-        if cache is not None and cache.get("key") == key:
+        key = WeightPack.key_of(Ws, compute, dev)
+        pre = cfg.get("prepacked")
+        if pre is not None and pre.key == key and pre.launched:
+            wf, wb = pre.wf, pre.wb
+            if cache is not None:
+                cache.update(key=key, wf=wf, wb=wb)
+        elif cache is not None and cache.get("key") == key:
             wf, wb = cache["wf"], cache["wb"]
         else:
-            wf = [torch.empty((lib.gcnpt_packed_bytes(h, k, compute),), **u8) for h, k in dims]
-            wb = [torch.empty((lib.gcnpt_packed_bytes(k, h, compute),), **u8) for h, k in dims]
-            _lib.check(lib.gcnpt_pack_weights_multi(st, L, _lib.ptr_array(w32), ints([h for h, _ in dims]), ints([k for _, k in dims]),
-                                                    compute, _lib.ptr_array(wf), _lib.ptr_array(wb)))
+            pk = WeightPack(Ws, compute, dev)
+            _lib.check(lib.gcnpt_pack_weights_multi(st, *pk.c_args()))
+            wf, wb = pk.wf, pk.wb
             if cache is not None:
                 cache.update(key=key, wf=wf, wb=wb)
         need_w = any(p.requires_grad for p in params)
@@ -256,7 +289,7 @@ class _GCNLayersFn(torch.autograd.Function):
 
 
 def gcn_layers(x, weights, biases, trees, drop_p=None, seeds=None, compute_dtype=torch.float32, out_dtype=torch.float32, no_adj=False,
-               seed_dev=None, wcache=None, pool=None):
+               seed_dev=None, wcache=None, pool=None, prepacked=None):
     """
     The reference's whole layer loop (model/gcn.py:266-393) over the per-layer kernels.  x [B,T,Din] float32/bfloat16 CUDA;
     weights / biases: lists of the nn.Linear parameters (any widths that chain); drop_p[l]: dropout applied to the output of
@@ -273,7 +306,7 @@ def gcn_layers(x, weights, biases, trees, drop_p=None, seeds=None, compute_dtype
         x, out_dtype = (x.float() if x.dtype != torch.float32 else x), torch.float32
     cfg = dict(drop_p=[float(p) for p in (drop_p or [0.0] * L)], seed=[int(s) for s in (seeds or [0] * L)], compute=compute,
                mid_dtype=torch.float32 if compute == _lib.F32 else torch.bfloat16, out_dtype=out_dtype, no_adj=bool(no_adj),
-               seed_dev=seed_dev, wcache=wcache, pool=None)
+               seed_dev=seed_dev, wcache=wcache, pool=None, prepacked=prepacked)
     if pool is not None:
         # pool = (subj_pos, obj_pos, 'max' | 'avg' | 'sum'): the op returns float32 [B, 3H] = pool3(h_L, trees.pool_mask, subj_pos, obj_pos)
         # instead of h_L (padded layout only)
@@ -485,10 +518,13 @@ class GCNRelationModel(nn.Module):
             words, masks, pos, ner, deprel, head, subj_pos, obj_pos = inputs
         else:
             words, masks, pos, deprel, head, subj_pos, obj_pos = inputs
+        pack = None
         if trees is None:
-            # lengths, head_to_tree, tree_to_adj and the upload (gcn.py:96-112) in one launch, no host round trip
+            # lengths, head_to_tree, tree_to_adj and the upload (gcn.py:96-112) in one launch, no host round trip; in a training step the
+            # same launch packs the layer weights on the CUs the tree build leaves idle (one launch boundary less)
+            pack = self.gcn.weight_pack(head.shape[0], head.shape[1]) if self.opt.get('gcn_pack_with_trees', True) else None
             trees = prune_to_csr(head, subj_pos, obj_pos, deprel, self.opt['prune_k'], masks=masks,
-                                 want_label=self.adj_type != 'regular')
+                                 want_label=self.adj_type != 'regular', pack=pack)
             if self.opt.get('gcn_check_trees', True):
                 trees.check(expect_maxlen=head.shape[1])
             if self.opt.get('gcn_pooled_only', False):
@@ -511,10 +547,14 @@ class GCNRelationModel(nn.Module):
             # any other (gcn.py:116-119), so the pooled vectors are the full batch's
             subj_pos, obj_pos = trees.take(subj_pos, fill=150), trees.take(obj_pos, fill=150)      # 150: the loader's pad value (loader.py:120-121)
         self.gcn._pool_req = (subj_pos, obj_pos, self.opt['pooling']) if handover else None
+        if pack is not None:
+            self.gcn.use_weight_pack(pack)
         try:
             h, pool_mask = self.gcn(trees, inputs)
         finally:
             self.gcn._pool_req = None
+            if pack is not None:
+                self.gcn.use_weight_pack(None)
         if isinstance(h, _Pooled):
             pooled = h.value
             return self.out_mlp(pooled), pooled[:, :self.opt['hidden_dim']]
@@ -600,6 +640,32 @@ class GCN(nn.Module):
         out, _ = self.rnn(packed, (h0, h0.clone()))
         out, _ = nn.utils.rnn.pad_packed_sequence(out, batch_first=True)
         return out
+
+    def weight_pack(self, B=None, T=None):
+        """A WeightPack for the launch that builds this step's trees (`prune_to_csr(..., pack=)`, `TreeCache.batch(..., pack=)`), or None
+        when the next forward would not use one: only the `regular` per-layer kernels pack this way, and only when the cached images do
+        not already belong to the current weights (eval(), gradient accumulation).  Hand the request back with `use_weight_pack`."""
+        if self.adj_type != 'regular':
+            return None
+        dev = self.W[0].weight.device
+        if dev.type != 'cuda':
+            return None
+        Ws = [lin.weight for lin in self.W]
+        compute = _lib.dtype_code(self.compute_dtype)
+        if B is not None and self._stack_path(B, T, Ws[0].shape[1]):
+            return None
+        if not torch.cuda.is_current_stream_capturing() and self._wcache.get("key") == WeightPack.key_of(Ws, compute, dev):
+            return None
+        return WeightPack(Ws, compute, dev)
+
+    def use_weight_pack(self, pack):
+        """The next forward takes the weight images from `pack` (a WeightPack a tree launch has filled); None clears it."""
+        self._prepacked = pack
+
+    def _stack_path(self, B, T, Din):
+        # the sentence-resident kernels win from ~256 sentences per batch on (profiles/r02_stack_vs_layers.json): default there
+        return bool(self.compute_dtype == torch.bfloat16 and self.opt.get('gcn_fused', B >= 256)
+                    and gcn_stack_supported(T, Din, self.mem_dim, self.layers))
 
     def _dropout_plan(self):
         """(p per layer, seed per layer, device seed word or None) for this forward -- gcn.py:393: every layer but the last."""
@@ -735,7 +801,8 @@ class GCN(nn.Module):
             ps, seeds, seed_dev = self._dropout_plan()
             Ws, bs = [lin.weight for lin in self.W], [lin.bias for lin in self.W]
             xp = packed.pack_rows(gcn_inputs if gcn_inputs.dtype in (torch.float32, torch.bfloat16) else gcn_inputs.float())
-            hp = gcn_layers(xp, Ws, bs, packed, ps, seeds, self.compute_dtype, torch.float32, no_adj, seed_dev, self._wcache)
+            hp = gcn_layers(xp, Ws, bs, packed, ps, seeds, self.compute_dtype, torch.float32, no_adj, seed_dev, self._wcache,
+                            prepacked=getattr(self, "_prepacked", None))
             return packed.unpack_rows(hp), packed.padded.pool_mask
         trees = adj if isinstance(adj, PrunedTrees) else adj_to_csr(adj, want_label=False)   # gcn.py:260-262
         no_adj = bool(self.opt.get('no_adj', False))                                           # gcn.py:264-265
@@ -743,17 +810,16 @@ class GCN(nn.Module):
         B, T, Din = x.shape
         ps, seeds, seed_dev = self._dropout_plan()
         Ws, bs = [lin.weight for lin in self.W], [lin.bias for lin in self.W]
-        # the sentence-resident kernels win from ~256 sentences per batch on (profiles/r02_stack_vs_layers.json): default there
-        if (self.compute_dtype == torch.bfloat16 and self.opt.get('gcn_fused', B >= 256)
-                and gcn_stack_supported(T, Din, self.mem_dim, self.layers)):
+        if self._stack_path(B, T, Din):
             # whole stack in one launch per direction (sentence-resident kernels)
             return gcn_stack(x, Ws, bs, trees, ps, seeds, torch.float32, no_adj, seed_dev), trees.pool_mask
+        pre = getattr(self, "_prepacked", None)
         req = getattr(self, "_pool_req", None)
         if req is not None:
             # GCNRelationModel asked for the pooled vectors directly (it would pool h next, gcn.py:116-121): stack + pooling as one op
-            return _Pooled(gcn_layers(x, Ws, bs, trees, ps, seeds, self.compute_dtype, torch.float32, no_adj, seed_dev, self._wcache, pool=req)), \
-                trees.pool_mask
-        x = gcn_layers(x, Ws, bs, trees, ps, seeds, self.compute_dtype, torch.float32, no_adj, seed_dev, self._wcache)
+            return _Pooled(gcn_layers(x, Ws, bs, trees, ps, seeds, self.compute_dtype, torch.float32, no_adj, seed_dev, self._wcache, pool=req,
+                                      prepacked=pre)), trees.pool_mask
+        x = gcn_layers(x, Ws, bs, trees, ps, seeds, self.compute_dtype, torch.float32, no_adj, seed_dev, self._wcache, prepacked=pre)
         return x, trees.pool_mask
 
 

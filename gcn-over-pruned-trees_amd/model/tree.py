@@ -319,13 +319,14 @@ def _i64(t, name):
     return t.contiguous()
 
 
-def prune_to_csr(head, subj_pos, obj_pos, deprel, prune_k, masks=None, lens=None, want_label=True):
+def prune_to_csr(head, subj_pos, obj_pos, deprel, prune_k, masks=None, lens=None, want_label=True, pack=None):
     """
     Batch version of `tree_to_adj(maxlen, head_to_tree(head[i], words[i], l[i], prune, subj_pos[i],
     obj_pos[i], deprel[i]), directed=False, self_loop=True)` for every sentence i (model/gcn.py:105-106),
     on the device.  head/subj_pos/obj_pos/deprel: int64 [B,T] CUDA tensors straight from the loader;
     masks: bool [B,T] (True = pad, model/gcn.py:96) or lens: int32 [B].
     Asynchronous; call `.check()` on the result to surface per-sentence errors.
+    pack: a model.gcn.WeightPack -- the same launch then also packs the layer weights (gcnpt_prune_to_csr_pack).
     """
     _lib.require_gpu(head)
     head, subj_pos, obj_pos, deprel = (_i64(t, n) for t, n in ((head, "head"), (subj_pos, "subj_pos"),
@@ -342,11 +343,15 @@ def prune_to_csr(head, subj_pos, obj_pos, deprel, prune_k, masks=None, lens=None
     cap = 3 * T
     bufs = _alloc(B, T, cap, head.device, want_label, True)
     row_ptr, col_idx, label, rowT_ptr, colT_idx, ell, ellT, pool_mask, status = bufs
-    _lib.check(_lib.lib().gcnpt_prune_to_csr(
-        _lib.stream(), _lib.ptr(head), _lib.ptr(subj_pos), _lib.ptr(obj_pos), _lib.ptr(deprel),
-        _lib.ptr(masks) if masks is not None else None, _lib.ptr(lens) if masks is None else None,
-        B, T, int(prune_k), cap, _lib.ptr(row_ptr), _lib.ptr(col_idx), _lib.ptr(label), _lib.ptr(rowT_ptr),
-        _lib.ptr(colT_idx), _lib.ptr(ell), _lib.ptr(ellT), _lib.ptr(pool_mask), _lib.ptr(status)))
+    args = (_lib.stream(), _lib.ptr(head), _lib.ptr(subj_pos), _lib.ptr(obj_pos), _lib.ptr(deprel),
+            _lib.ptr(masks) if masks is not None else None, _lib.ptr(lens) if masks is None else None,
+            B, T, int(prune_k), cap, _lib.ptr(row_ptr), _lib.ptr(col_idx), _lib.ptr(label), _lib.ptr(rowT_ptr),
+            _lib.ptr(colT_idx), _lib.ptr(ell), _lib.ptr(ellT), _lib.ptr(pool_mask), _lib.ptr(status))
+    if pack is None:
+        _lib.check(_lib.lib().gcnpt_prune_to_csr(*args))
+    else:
+        _lib.check(_lib.lib().gcnpt_prune_to_csr_pack(*(args + pack.c_args())))
+        pack.launched = True
     return PrunedTrees(B, T, cap, *bufs)
 
 
@@ -392,25 +397,26 @@ class TreeCache(object):
         # compact form: entity tokens are kept even when they are outside the tree (one-node trees), see PrunedTrees.compact
         return cls(trees, lens, prune_k, trees.compact(also_keep=(subj_pos == 0) | (obj_pos == 0)) if compact else None)
 
-    def batch(self, idx, T, want_label=None, compact=False, Tc=None):
+    def batch(self, idx, T, want_label=None, compact=False, Tc=None, pack=None):
         """idx: int64 [B] sentence numbers (CUDA tensor; repeats allowed); T: the width the batch tensors are padded to
         (the reference pads to the longest sentence of the batch, gcn.py:97).  compact=True: a CompactTrees of width Tc
-        (default: the widest tree of the dataset) whose token positions refer to the [B,T] batch."""
+        (default: the widest tree of the dataset) whose token positions refer to the [B,T] batch.
+        pack: a model.gcn.WeightPack (GCN.weight_pack()) -- the gather launch then also packs the layer weights."""
         idx = _lib.require_gpu(idx).to(torch.int64).contiguous()
         if compact:
             if self.compact is None:
                 raise ValueError("the cache was built without compact=True")
             width = int(Tc) if Tc is not None else self.compact.Tc
-            ct = self._gather(self.compact.trees, self.compact.kept, idx, width, want_label)
+            ct = self._gather(self.compact.trees, self.compact.kept, idx, width, want_label, pack)
             n = min(width, self.compact.Tc)
             tok = torch.full((idx.numel(), width), -1, dtype=torch.int64, device=idx.device)
             tok[:, :n] = self.compact.tok.index_select(0, idx.clamp(0, len(self) - 1))[:, :n]
             tok = torch.where((ct.status[:-1] == 0).unsqueeze(1), tok, torch.full_like(tok, -1))
             return CompactTrees(ct, tok, self.compact.kept.index_select(0, idx.clamp(0, len(self) - 1)), int(T))
-        return self._gather(self.trees, self.lens, idx, int(T), want_label)
+        return self._gather(self.trees, self.lens, idx, int(T), want_label, pack)
 
     @staticmethod
-    def _gather(src, lens, idx, T, want_label):
+    def _gather(src, lens, idx, T, want_label, pack=None):
         B = int(idx.numel())
         want_label = (src.label is not None) if want_label is None else want_label
         if want_label and src.label is None:
@@ -419,10 +425,14 @@ class TreeCache(object):
         bufs = _alloc(B, T, cap, src.device, want_label, True)
         row_ptr, col_idx, label, rowT_ptr, colT_idx, ell, ellT, pool_mask, status = bufs
         P = _lib.ptr
-        _lib.check(_lib.lib().gcnpt_gather_trees(
-            _lib.stream(), P(src.row_ptr), P(src.col_idx), P(src.label), P(src.rowT_ptr), P(src.colT_idx), P(src.ell), P(src.ellT),
-            P(src.pool_mask), P(src.status), P(lens), src.B, src.T, src.cap, P(idx), B, T, cap,
-            P(row_ptr), P(col_idx), P(label), P(rowT_ptr), P(colT_idx), P(ell), P(ellT), P(pool_mask), P(status)))
+        args = (_lib.stream(), P(src.row_ptr), P(src.col_idx), P(src.label), P(src.rowT_ptr), P(src.colT_idx), P(src.ell), P(src.ellT),
+                P(src.pool_mask), P(src.status), P(lens), src.B, src.T, src.cap, P(idx), B, T, cap,
+                P(row_ptr), P(col_idx), P(label), P(rowT_ptr), P(colT_idx), P(ell), P(ellT), P(pool_mask), P(status))
+        if pack is None:
+            _lib.check(_lib.lib().gcnpt_gather_trees(*args))
+        else:
+            _lib.check(_lib.lib().gcnpt_gather_trees_pack(*(args + pack.c_args())))
+            pack.launched = True
         return PrunedTrees(B, T, cap, *bufs)
 
 

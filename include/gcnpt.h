@@ -254,6 +254,24 @@ int gcnpt_pack_trees(void* stream, const int32_t* src_row_ptr, const int32_t* sr
 int gcnpt_pack_rows(void* stream, const void* src, int dtype, const int32_t* cu_seqlens, int B, int T, int W, void* dst);
 int gcnpt_unpack_rows(void* stream, const void* src, int dtype, const int32_t* cu_seqlens, int B, int T, int W, void* dst);
 
+/* ---- the weight pack as a side job of the tree launch ---------------------------------------------------------------------
+ * A training step needs the weights re-packed (gcnpt_pack_weights_multi) after every optimizer step and a batch's trees built
+ * (gcnpt_prune_to_csr) or assembled (gcnpt_gather_trees); both launches leave most of the 256 CUs idle and neither depends on the
+ * other.  These forms do both in ONE launch: extra workgroups pack while the others build the trees (same results bit for bit; the
+ * trailing arguments are gcnpt_pack_weights_multi's).  Saves one launch boundary (~4 us) per step. */
+int gcnpt_prune_to_csr_pack(void* stream, const int64_t* head, const int64_t* subj_pos, const int64_t* obj_pos, const int64_t* deprel,
+                            const uint8_t* pad_mask, const int32_t* len, int B, int T, int prune_k, int cap, int32_t* row_ptr,
+                            int32_t* col_idx, int32_t* label, int32_t* rowT_ptr, int32_t* colT_idx, int32_t* ell, int32_t* ellT,
+                            uint8_t* pool_mask, int32_t* status, int n_layers, const float* const* W, const int* H, const int* Din,
+                            int dtype, void* const* w_fwd, void* const* w_bwd);
+int gcnpt_gather_trees_pack(void* stream, const int32_t* src_row_ptr, const int32_t* src_col_idx, const int32_t* src_label,
+                            const int32_t* src_rowT_ptr, const int32_t* src_colT_idx, const int32_t* src_ell, const int32_t* src_ellT,
+                            const uint8_t* src_pool_mask, const int32_t* src_status, const int32_t* src_len, int S, int Ts, int cap_s,
+                            const int64_t* idx, int B, int T, int cap, int32_t* row_ptr, int32_t* col_idx, int32_t* label,
+                            int32_t* rowT_ptr, int32_t* colT_idx, int32_t* ell, int32_t* ellT, uint8_t* pool_mask, int32_t* status,
+                            int n_layers, const float* const* W, const int* H, const int* Din, int dtype, void* const* w_fwd,
+                            void* const* w_bwd);
+
 /* ---- N1: the consumer right after the path, model/gcn.py:116-121 + pool() 473-483 ---------------------------------
  * One pass over h [B*T,H] (h_dtype) produces out [B, 3H] float32 = [pool(h, pool_mask) | pool(h, subj_pos != 0) |
  * pool(h, obj_pos != 0)], the row the output MLP reads.  type: 0 = max (masked tokens count as -1e12; ties go to the

@@ -1645,3 +1645,99 @@ def test_pool_handover_classifier_same_update(api, dev, variant):
     assert set(ga) == set(gb) and len(ga) > 4
     for n in ga:
         assert max_rel(gb[n].cpu().numpy(), ga[n].cpu().numpy()) <= tol, n
+
+
+# ---------------------------------------------------------------------------------------------------
+# the weight pack as a side job of the tree launch (gcnpt_prune_to_csr_pack / gcnpt_gather_trees_pack)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("compute", [torch.float32, torch.bfloat16])
+def test_tree_launch_carries_the_weight_pack(api, dev, compute):
+    """One launch = trees + packed weights: every tree array and both weight images are bit-identical to the two separate launches,
+    for the pruner and for the cached-dataset gather; a request made for older weights is not used."""
+    from gcn_over_pruned_trees_amd import _lib
+    from gcn_over_pruned_trees_amd.utils import synthetic
+    gcn, tree = api
+    B, T, K = 9, 57, 1
+    tb = synthetic.random_tree_batch(41, B, T, "tacred")
+    head, subj, obj, deprel, masks = (_t(tb[k], dev) for k in ("head", "subj_pos", "obj_pos", "deprel", "masks"))
+    Wn, bn = synthetic.layer_params(6, [72, 40, 56])
+    Ws = [_t(w, dev).requires_grad_() for w in Wn]
+    code = _lib.dtype_code(compute)
+    ref_pack = gcn.WeightPack(Ws, code, dev)
+    _lib.check(_lib.lib().gcnpt_pack_weights_multi(_lib.stream(), *ref_pack.c_args()))
+    ref_trees = tree.prune_to_csr(head, subj, obj, deprel, K, masks=masks)
+    pk = gcn.WeightPack(Ws, code, dev)
+    trees = tree.prune_to_csr(head, subj, obj, deprel, K, masks=masks, pack=pk)
+    assert pk.launched
+    names = ("row_ptr", "col_idx", "label", "rowT_ptr", "colT_idx", "ell", "ellT", "pool_mask", "status")
+    nnz = int(ref_trees.nnz().sum())
+
+    def same_trees(a, b):
+        for n in names:
+            u, v = getattr(a, n), getattr(b, n)
+            if n in ("col_idx", "label", "colT_idx"):               # only the first nnz[b] slots of a sentence's segment are defined
+                for s in range(B):
+                    k = int(a.row_ptr[s * (T + 1) + T]) - s * a.cap
+                    assert torch.equal(u[s * a.cap:s * a.cap + k], v[s * a.cap:s * a.cap + k]), n
+            else:
+                assert torch.equal(u, v), n
+    same_trees(trees, ref_trees)
+    assert nnz > 0
+    for l in range(2):
+        assert torch.equal(pk.wf[l], ref_pack.wf[l]) and torch.equal(pk.wb[l], ref_pack.wb[l])
+    # the cached-dataset gather carries it too
+    cache = tree.TreeCache.build(head, subj, obj, deprel, K, masks=masks)
+    idx = torch.tensor([3, 0, 8, 8, 5], device=dev)
+    pk2 = gcn.WeightPack(Ws, code, dev)
+    got = cache.batch(idx, T, pack=pk2)
+    want = cache.batch(idx, T)
+    assert pk2.launched and torch.equal(got.ell, want.ell) and torch.equal(got.row_ptr, want.row_ptr) and torch.equal(got.status, want.status)
+    for l in range(2):
+        assert torch.equal(pk2.wf[l], ref_pack.wf[l]) and torch.equal(pk2.wb[l], ref_pack.wb[l])
+    # the layer op takes the images from a request that belongs to the current weights ... (no pack launch of its own: same output)
+    x = _t(synthetic.normal(7, (B, T, 72)), dev)
+    bs = [_t(b, dev) for b in bn]
+    y_ref = gcn.gcn_layers(x, Ws, bs, trees, compute_dtype=compute)
+    y_pre = gcn.gcn_layers(x, Ws, bs, trees, compute_dtype=compute, prepacked=pk)
+    assert torch.equal(y_ref, y_pre)
+    # ... and ignores one made before an in-place update (the version counter moved on)
+    with torch.no_grad():
+        Ws[0].mul_(1.5)
+    y_new = gcn.gcn_layers(x, Ws, bs, trees, compute_dtype=compute, prepacked=pk)
+    y_chk = gcn.gcn_layers(x, Ws, bs, trees, compute_dtype=compute)
+    assert torch.equal(y_new, y_chk) and not torch.equal(y_new, y_ref)
+
+
+def test_classifier_packs_with_the_tree_launch(api, dev):
+    """GCNClassifier builds trees and weight images in one launch by default: same logits and gradients as with
+    opt['gcn_pack_with_trees']=False, in eval() (cached images) and across an optimizer step in train()."""
+    import json
+    gcn, _ = api
+    g = load_golden("e2e_gcn.npz")
+    opt = json.loads(str(g["opt"]))
+    opt["cuda"] = True
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd:")}
+    inputs = tuple(_t(g[k], dev) for k in ("words", "masks", "pos", "ner", "deprel", "head", "subj_pos", "obj_pos"))
+    outs = []
+    for merged in (False, True):
+        model = gcn.GCNClassifier(dict(opt, gcn_pack_with_trees=merged))
+        model.load_state_dict(sd, strict=True)
+        model.to(dev).eval()
+        with torch.no_grad():
+            le, _ = model(inputs)
+            le2, _ = model(inputs)                                   # second forward: images from the module's cache
+        assert max_rel(le.cpu().numpy(), g["logits"]) <= 1e-4 and torch.equal(le, le2)
+        model.train()
+        sgd = torch.optim.SGD(model.parameters(), lr=0.1)
+        steps = []
+        for it in range(3):
+            torch.manual_seed(50 + it)
+            sgd.zero_grad()
+            logits, pooled = model(inputs)
+            (logits.logsumexp(1).mean() + 0.003 * (pooled ** 2).sum(1).mean()).backward()
+            sgd.step()                                               # in-place update: the next forward must re-pack
+            steps.append(logits.detach().clone())
+        outs.append(steps)
+    for a, b in zip(*outs):
+        assert max_rel(b.cpu().numpy(), a.cpu().numpy()) <= 1e-4
+    assert not torch.equal(outs[1][0], outs[1][2])                   # the updates did reach the packed images

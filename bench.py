@@ -229,6 +229,22 @@ class Stack(object):
                                                        P(tr.colT_idx), P(tr.ellT), self.B, self.T, Din, H, P(dst), self.act, self.compute, sc,
                                                        P(self.zf[l]), P(dW), P(db), P(relu), nsc, is_dz, P(self.ws), self.ws_n))
 
+    def bwd_data_wgrad(self, k=0):
+        """Layer 0's backward-data launch carrying layer 1's weight gradient on the CUs without a row tile (what gcnpt_layers_bwd does
+        for batches of up to 192 row tiles; bigger ones: two launches)."""
+        P, tr = self._lib.ptr, self.trees
+        H, Din = self.W[0].shape
+        H1, Din1 = self.W[1].shape
+        dW, db = self._dw_db(0, k)
+        dW1, db1 = self._dw_db(1, k)
+        self._lib.check(self.L.gcnpt_layer_bwd_data_wgrad(
+            self._lib.stream(), P(self.dh1), P(self.h1), self.act, P(self.wb[0]), P(tr.ell), P(tr.rowT_ptr), P(tr.colT_idx), P(tr.ellT), self.B,
+            self.T, Din, H, P(self.dx), self.act, self.compute, self.scale, P(self.zf[0]), P(dW), P(db), None, 1.0, 1,
+            P(self.zf[1]), P(self.sf[1]), Din1, H1, P(dW1), P(db1)))
+
+    def carries_wgrad(self):
+        return self.rows <= 192 * 32 and self.ws is None and not self.args.split_weight_grad
+
     def bwd_weight(self, l, k=0):
         P = self._lib.ptr
         H, Din = self.W[l].shape
@@ -357,6 +373,10 @@ class Stack(object):
         if self.two_layer_launches():
             return [("pack", self.pack_all), ("fwd", self.fwd_all), ("bwd_data1", lambda: self.bwd_data(1, k)),
                     ("bwd_data0", lambda: self.bwd_data(0, k)), ("bwd_weight", lambda: self.bwd_weight_all(k))]
+        if self.carries_wgrad():
+            return [("pack", self.pack_all), ("fwd0", lambda: self.fwd(0)), ("fwd1", lambda: self.fwd(1)),
+                    ("bwd_data1", lambda: self.bwd_data(1, k)), ("bwd_data0+wgrad1", lambda: self.bwd_data_wgrad(k)),
+                    ("bwd_weight0", lambda: self.bwd_weight(0, k))]
         return [("pack", self.pack_all), ("fwd0", lambda: self.fwd(0)), ("fwd1", lambda: self.fwd(1)),
                 ("bwd_data1", lambda: self.bwd_data(1, k)), ("bwd_data0", lambda: self.bwd_data(0, k)),
                 ("bwd_weight", lambda: self.bwd_weight_all(k))]
@@ -404,6 +424,8 @@ class Stack(object):
                 self.zf[l].numel() + 4 * (H * Din + H)
             out["bwd_weight%d" % l] = self.zf[l].numel() + self.sf[l].numel() + 4 * (H * Din + H)
             out["bwd_weight"] = out.get("bwd_weight", 0) + out["bwd_weight%d" % l]
+            if l == 1:
+                out["bwd_data0+wgrad1"] = out["bwd_data0"] + out["bwd_weight1"]
             out["pack"] = out.get("pack", 0) + 4 * H * Din + self.wf[l].numel() + self.wb[l].numel()
         out["fwd"] = sum(out["fwd%d" % l] for l in range(len(self.W)))
         out["bwd_data"] = sum(out["bwd_data%d" % l] for l in range(len(self.W)))
@@ -433,6 +455,8 @@ class Stack(object):
             per["bwd_weight%d" % l] = e * N * Din + 4 * Din * H + 4 * H
         L = len(self.W)
         per["bwd_weight"] = sum(per["bwd_weight%d" % l] for l in range(L))
+        if L > 1:
+            per["bwd_data0+wgrad1"] = per["bwd_data0"] + per["bwd_weight1"]
         per["fwd"] = per["stack_fwd"] = sum(per["fwd%d" % l] for l in range(L))
         per["bwd_data"] = per["stack_bwd"] = sum(per["bwd_data%d" % l] for l in range(L))
         per["stack_bwd_weight"] = per["bwd_weight"]

@@ -16,6 +16,7 @@
 //       whole rows in 16-byte stores.
 // The dense [B,T,T] bmm of the reference (gcn.py:269) never exists: aggregation is a gather.
 #include "layer_common.h"
+#include "wgrad_common.h"
 
 namespace gcnpt {
 
@@ -58,9 +59,10 @@ struct RowTileParams {
 
 // DZIN (bwd only): `src` already holds dZ (the layer above wrote it, see relu_src), so the row loader is the forward's plain
 // gather -- one load per neighbour instead of three (dY, Y, degree).
+// (a device function: the launch of its own below, and the backward launch that also carries a weight gradient, share it; block_id /
+// n_blocks: this workgroup's tile number and the number of tiles, which that launch does not read off blockIdx / gridDim)
 template <typename CT, typename IT, typename OT, bool BWD, int VEC, int NTW, int KSMAX, bool DZIN = false>
-__global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTileParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+__device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int block_id, const int n_blocks, unsigned char* smem_raw) {
     static_assert(BWD || !DZIN, "DZIN is a backward mode");
     constexpr bool MASKED = BWD && !DZIN;                       // the loader computes dZ = dY * 1[Y>0] * scale / (deg+1) itself
     constexpr int KSTEP = sizeof(CT) == 2 ? 32 : 16;            // K consumed per fragment
@@ -92,8 +94,8 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
     // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one), each with its own L2, and a row's neighbours
     // sit in its own sentence, i.e. in the adjacent tiles: XCD x takes a CONTIGUOUS run of tiles, so that the neighbour rows a tile
     // gathers are rows the same L2 serves to the tiles next to it (speed only; any placement gives the same values)
-    const int xg = blockIdx.x & 7, xq = gridDim.x >> 3, xr = gridDim.x & 7;
-    const int tile_id = xg * xq + min(xg, xr) + (blockIdx.x >> 3);
+    const int xg = block_id & 7, xq = n_blocks >> 3, xr = n_blocks & 7;
+    const int tile_id = xg * xq + min(xg, xr) + (block_id >> 3);
     const int r0 = tile_id * ROWS;
     const IT* src = static_cast<const IT*>(p.src);
     const IT* yref = static_cast<const IT*>(p.yref);
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
         const int w_tiles = ceil_div(p.K, 16);
         if constexpr (sizeof(CT) == 2) {
             const int i = lane & 15, g = lane >> 4, q4 = i >> 2, pp = i & 3;
-            const size_t nks = gridDim.x;
+            const size_t nks = n_blocks;
             for (int t = wave; t < w_tiles; t += RT_WAVES) {
                 const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                     (__attribute__((address_space(3))) s16x4_t*)(X + (size_t)(8 * g + q4) * stride + 16 * t + 4 * pp));
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
             }
         } else {
             const int i = lane & 15, g = lane >> 4;
-            const size_t nks = (size_t)gridDim.x * 2;
+            const size_t nks = (size_t)n_blocks * 2;
             for (int tk = wave; tk < w_tiles * 2; tk += RT_WAVES) {
                 const int t = tk >> 1, kk = tk & 1;
                 uint4 u;
@@ -393,9 +395,9 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
         if (p.frag_out) __syncthreads();                         // every wave has read its share of Z: the region becomes O
     }
     if (p.zero_a)
-        for (int i = blockIdx.x * RT_THREADS + tid; i < p.zero_a_n; i += gridDim.x * RT_THREADS) p.zero_a[i] = 0.0f;
+        for (int i = block_id * RT_THREADS + tid; i < p.zero_a_n; i += n_blocks * RT_THREADS) p.zero_a[i] = 0.0f;
     if (p.zero_b)
-        for (int i = blockIdx.x * RT_THREADS + tid; i < p.zero_b_n; i += gridDim.x * RT_THREADS) p.zero_b[i] = 0.0f;
+        for (int i = block_id * RT_THREADS + tid; i < p.zero_b_n; i += n_blocks * RT_THREADS) p.zero_b[i] = 0.0f;
     GCNPT_STAMP(p.stamps, 7);
     if (!p.out) return;
 
@@ -578,6 +580,26 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
     GCNPT_STAMP(p.stamps, 10);
 }
 
+
+template <typename CT, typename IT, typename OT, bool BWD, int VEC, int NTW, int KSMAX, bool DZIN = false>
+__global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTileParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    rowtile_body<CT, IT, OT, BWD, VEC, NTW, KSMAX, DZIN>(p, (int)blockIdx.x, (int)gridDim.x, smem_raw);
+}
+
+// The backward-data launch of layer l with the WEIGHT GRADIENT OF LAYER l+1 as a side job: that gradient only needs the fragment images
+// the launches before this one have left (dZ_{l+1}, S_{l+1}), and a batch of <= ~6 k rows leaves a third of the CUs without a row tile.
+// Workgroups [0, n_tiles) are row tiles, workgroups [wg_first, gridDim.x) (wg_first = n_tiles rounded up to 8, so that the weight
+// gradient's block -> XCD map holds) contract one slice of one output block each.  The last launch of the sweep is then the bottom
+// layer's weight gradient alone: 7.3 us instead of 13.0 us for both layers (profiles/r02_bench_c2_variants.json).
+template <typename CT, typename IT, typename OT, int VEC, int NTW, int KSMAX>
+__global__ __launch_bounds__(RT_THREADS, 2) void rowtile_wgrad_kernel(const RowTileParams p, const WeightGradParams wg, const int n_tiles,
+                                                                      const int wg_first) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    if ((int)blockIdx.x < n_tiles) rowtile_body<CT, IT, OT, true, VEC, NTW, KSMAX, true>(p, (int)blockIdx.x, n_tiles, smem_raw);
+    else if ((int)blockIdx.x >= wg_first) weight_grad_body<CT, RT_WAVES, WG_NT, WG_KB>(wg, (int)blockIdx.x - wg_first, smem_raw);
+}
+
 }  // namespace gcnpt
 
 // =====================================================================================================
@@ -601,6 +623,11 @@ static int vec_bytes(int width, size_t es, const void* a, const void* b) {
     return 0;
 }
 
+// A weight gradient the next backward-data launch should carry (layers_bwd_impl sets it around that one call; thread-local because it
+// is only an argument that skips four levels of dispatch templates, not state: it never outlives the call that set it)
+struct SideWgrad { const WeightGradParams* wg = nullptr; int blocks = 0; bool carried = false; };
+static thread_local SideWgrad t_side;
+
 template <typename CT, typename IT, typename OT, bool BWD, int VEC, int NTW, int KSMAX, bool DZIN = false>
 static int launch_rowtile_cfg(hipStream_t s, const RowTileParams& p) {
     const int stride = lds_stride_dw(p.Kpad * (int)sizeof(CT) / 4) * 4 / (int)sizeof(CT);
@@ -610,9 +637,23 @@ static int launch_rowtile_cfg(hipStream_t s, const RowTileParams& p) {
     const size_t lds = s_bytes + (BWD ? std::max(s_bytes, o_bytes) : o_bytes) +
                        (size_t)ROWS * 13 * sizeof(int) + (size_t)RT_THREADS * sizeof(float);
     if (lds > 160 * 1024) return fail(GCNPT_E_UNSUPPORTED, "layer: K=%d needs %zu B of LDS per workgroup", p.K, lds);
+    const int n_tiles = ceil_div(p.N, ROWS);
+    // the uniform-precision instantiations can carry the layer above's weight gradient on the CUs that have no row tile
+    if constexpr (BWD && DZIN && std::is_same<IT, OT>::value && sizeof(CT) == sizeof(IT)) {
+        if (t_side.wg && t_side.blocks > 0) {
+            auto kern = rowtile_wgrad_kernel<CT, IT, OT, VEC, NTW, KSMAX>;
+            GCNPT_LDS_ATTR_ONCE(kern, 160 * 1024);
+            const int wg_first = round_up(n_tiles, 8);
+            hipLaunchKernelGGL(kern, dim3(wg_first + t_side.blocks), dim3(RT_THREADS), std::max(lds, weight_grad_lds(RT_WAVES)), s, p, *t_side.wg,
+                               n_tiles, wg_first);
+            GCNPT_HIP_CHECK(hipGetLastError());
+            t_side.carried = true;
+            return GCNPT_OK;
+        }
+    }
     auto kern = rowtile_kernel<CT, IT, OT, BWD, VEC, NTW, KSMAX, DZIN>;
     GCNPT_LDS_ATTR_ONCE(kern, 160 * 1024);
-    hipLaunchKernelGGL(kern, dim3(ceil_div(p.N, ROWS)), dim3(RT_THREADS), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(RT_THREADS), lds, s, p);
     GCNPT_HIP_CHECK(hipGetLastError());
     return GCNPT_OK;
 }
@@ -788,6 +829,41 @@ extern "C" int gcnpt_layer_bwd_data_ws(void* stream, const void* dY, const void*
                                zero_dW, zero_db, relu_src, next_scale, src_is_dz, workspace, workspace_bytes);
 }
 
+// Offers the weight gradient of the layer ABOVE (its two fragment images, left by earlier launches) to the next backward-data launch of
+// this thread: taken by the row-tile launch of a small batch (<= 192 row tiles), see rowtile_wgrad_kernel.  p_out must outlive that call.
+static void offer_side_wgrad(WeightGradParams& p_out, const void* z_frag_up, const void* s_frag_up, int B, int T, int Din_up, int H_up,
+                             float* dW_up, float* db_up, int compute_dtype) {
+    t_side = SideWgrad{};
+    const int n_tiles = ceil_div((int)rows_of(B, T), ROWS);
+    if (!z_frag_up || !s_frag_up || !dW_up || !db_up || n_tiles > 192 || rowstream_enabled()) return;
+    const int nks = n_tiles * (compute_dtype == GCNPT_BF16 ? 1 : 2);
+    const int blocks_l = ceil_div(ceil_div(H_up, 16), WG_MT) * ceil_div(ceil_div(Din_up, 16), WG_NT);
+    t_side.blocks = plan_weight_grad(p_out, z_frag_up, s_frag_up, nks, Din_up, H_up, dW_up, db_up, blocks_l, RT_WAVES, std::max(64, 256 - n_tiles),
+                                     WG_NT);
+    t_side.wg = &p_out;
+}
+
+extern "C" int gcnpt_layer_bwd_weight(void* stream, const void* z_frag, const void* s_frag, int B, int T, int Din, int H,
+                                      float* dW, float* db, int compute_dtype);
+
+extern "C" int gcnpt_layer_bwd_data_wgrad(void* stream, const void* dY, const void* Y, int g_dtype, const void* w_bwd,
+                                          const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
+                                          const int32_t* ellT, int B, int T, int Din, int H, void* dh, int dh_dtype,
+                                          int compute_dtype, float scale, void* z_frag, float* zero_dW, float* zero_db,
+                                          const void* relu_src, float next_scale, int src_is_dz, const void* up_z_frag,
+                                          const void* up_s_frag, int up_Din, int up_H, float* up_dW, float* up_db) {
+    GCNPT_REQUIRE(up_z_frag && up_s_frag && up_dW && up_db && up_Din > 0 && up_H > 0, "layer_bwd_data_wgrad: the layer above's weight gradient needs "
+                  "its two fragment images, dW and db");
+    WeightGradParams side_p;
+    offer_side_wgrad(side_p, up_z_frag, up_s_frag, B, T, up_Din, up_H, up_dW, up_db, compute_dtype);
+    const int rc = layer_bwd_data_impl(stream, dY, Y, g_dtype, w_bwd, ell, rowT_ptr, colT_idx, ellT, B, T, Din, H, dh, dh_dtype, compute_dtype, scale,
+                                       z_frag, zero_dW, zero_db, relu_src, next_scale, src_is_dz, nullptr, 0);
+    const bool carried = t_side.carried;
+    t_side = SideWgrad{};
+    if (rc != GCNPT_OK) return rc;
+    return carried ? GCNPT_OK : gcnpt_layer_bwd_weight(stream, up_z_frag, up_s_frag, B, T, up_Din, up_H, up_dW, up_db, compute_dtype);
+}
+
 // ---- the whole layer loop / its autograd in one host call: the launches above, back to back (no kernel of their own) ----
 extern "C" int gcnpt_layer_bwd_weight_multi(void* stream, int n_layers, const void* const* z_frag, const void* const* s_frag,
                                             int B, int T, const int* Din, const int* H, float* const* dW, float* const* db,
@@ -865,6 +941,19 @@ static int layers_bwd_impl(void* stream, int n_layers, const void* gy, const voi
         g = dh[0];
         top_is_dz = true;
     }
+    // Small batches: the weight gradient of layer l+1 rides in the backward-data launch of layer l (rowtile_wgrad_kernel); what is
+    // left for the launch at the end of the sweep is the bottom layer (and any layer whose launch could not carry one)
+    bool wg_done[LAYERS_MAX] = {};
+    WeightGradParams side_p;
+    auto offer_side = [&](int l) {                      // called before the backward-data launch of layer l: carry layer l+1's gradient?
+        t_side = SideWgrad{};
+        if (!z_frag || l + 1 >= n_layers) return;
+        offer_side_wgrad(side_p, z_frag[l + 1], s_frag[l + 1], B, T, Din[l + 1], H[l + 1], dW[l + 1], db[l + 1], compute_dtype);
+    };
+    auto close_side = [&](int l) {
+        if (t_side.carried) wg_done[l + 1] = true;
+        t_side = SideWgrad{};
+    };
     for (int l = n_layers - 1; l >= 0; --l) {
         if (l == top && top_is_dz) {
             const int rc = layer_bwd_data_impl(stream, g, Y[l], y_dtype[l], w_bwd[l], ell, rowT_ptr, colT_idx, ellT, B, T, Din[l], H[l], dh[l],
@@ -878,16 +967,30 @@ static int layers_bwd_impl(void* stream, int n_layers, const void* gy, const voi
             // every layer but the bottom one hands the layer below its dZ ready-made (dh[l] then holds dZ of layer l-1), and every
             // layer but the top one receives it: one load per neighbour in the gather instead of three
             const bool hand_down = l > 0, handed = l < n_layers - 1 || gy_is_dz;
+            offer_side(l);
             const int rc = layer_bwd_data_impl(stream, g, Y[l], y_dtype[l], w_bwd[l], ell, rowT_ptr, colT_idx, ellT, B, T, Din[l], H[l],
                                                dh[l], dh_dtype[l], compute_dtype, scale[l], z_frag ? z_frag[l] : nullptr,
                                                z_frag ? dW[l] : nullptr, z_frag ? db[l] : nullptr, hand_down ? Y[l - 1] : nullptr,
                                                hand_down ? scale[l - 1] : 1.0f, handed ? 1 : 0, ws, ws_bytes);
+            close_side(l);
             if (rc != GCNPT_OK) return rc;
         }
         g = dh[l];
     }
     if (!z_frag) return GCNPT_OK;
-    return gcnpt_layer_bwd_weight_multi(stream, n_layers, z_frag, s_frag, B, T, Din, H, dW, db, compute_dtype);
+    // the weight gradients no launch has carried, in one launch
+    const void* zf_r[LAYERS_MAX];
+    const void* sf_r[LAYERS_MAX];
+    float* dW_r[LAYERS_MAX];
+    float* db_r[LAYERS_MAX];
+    int Din_r[LAYERS_MAX], H_r[LAYERS_MAX], n_r = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        if (wg_done[l]) continue;
+        zf_r[n_r] = z_frag[l]; sf_r[n_r] = s_frag[l]; dW_r[n_r] = dW[l]; db_r[n_r] = db[l]; Din_r[n_r] = Din[l]; H_r[n_r] = H[l];
+        ++n_r;
+    }
+    if (n_r == 0) return GCNPT_OK;
+    return gcnpt_layer_bwd_weight_multi(stream, n_r, zf_r, sf_r, B, T, Din_r, H_r, dW_r, db_r, compute_dtype);
 }
 
 extern "C" int gcnpt_layers_bwd(void* stream, int n_layers, const void* gy, const void* const* Y, const int* y_dtype,

@@ -295,6 +295,17 @@ int gcnpt_layers_bwd_dz(void* stream, int n_layers, const void* dz_top, const vo
                         int compute_dtype, const float* scale, void* const* z_frag, const void* const* s_frag, float* const* dW,
                         float* const* db);
 
+/* gcnpt_layer_bwd_data for layer l that ALSO computes the weight gradient of the layer above it (up_*: that layer's two fragment images,
+ * widths and accumulators, exactly gcnpt_layer_bwd_weight's arguments): for batches of up to 192 row tiles (6 144 token rows) the
+ * gradient rides in the same launch, on the CUs that have no row tile (one launch boundary less on the step's critical path: the
+ * last launch of a backward sweep is then the bottom layer's weight gradient alone); otherwise it is launched right after.
+ * gcnpt_layers_bwd / _bwd_dz / _bwd_ws do this for every layer but the top one. */
+int gcnpt_layer_bwd_data_wgrad(void* stream, const void* dY, const void* Y, int g_dtype, const void* w_bwd, const int32_t* ell,
+                               const int32_t* rowT_ptr, const int32_t* colT_idx, const int32_t* ellT, int B, int T, int Din, int H,
+                               void* dh, int dh_dtype, int compute_dtype, float scale, void* z_frag, float* zero_dW, float* zero_db,
+                               const void* relu_src, float next_scale, int src_is_dz, const void* up_z_frag, const void* up_s_frag,
+                               int up_Din, int up_H, float* up_dW, float* up_db);
+
 /* EXPERIMENTAL, opt-in with the environment variable GCNPT_ROWSPLIT=1 (measured no faster than the default kernels).
  * Big batches (>= 16 384 token rows, bf16 compute): with a workspace the layer loop runs every layer as TWO launches -- a gather
  * that writes the rows aggregating at least one neighbour (plus the weight gradient's fragment image) and a matrix launch that shares

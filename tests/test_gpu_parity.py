@@ -1741,3 +1741,35 @@ def test_classifier_packs_with_the_tree_launch(api, dev):
     for a, b in zip(*outs):
         assert max_rel(b.cpu().numpy(), a.cpu().numpy()) <= 1e-4
     assert not torch.equal(outs[1][0], outs[1][2])                   # the updates did reach the packed images
+
+
+# ---------------------------------------------------------------------------------------------------
+# the backward-data launch of layer l carries the weight gradient of layer l+1 (rowtile_wgrad_kernel)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("compute", [torch.float32, torch.bfloat16])
+def test_three_layer_sweep_carries_weight_gradients_vs_oracle(api, dev, compute):
+    """Three layers: the weight gradients of layers 2 and 1 ride in the backward-data launches of layers 1 and 0, the last launch is
+    layer 0's alone.  Every gradient against the oracle (model/gcn.py:266-271, 390-393 and their autograd)."""
+    from gcn_over_pruned_trees_amd.utils import synthetic
+    from oracle import gcn_ref, prune_ref
+    gcn, tree = api
+    B, T, K, dims = 11, 43, 1, [56, 40, 72, 48]
+    tb = synthetic.random_tree_batch(33, B, T, "tacred")
+    adj = prune_ref.batch_adj(tb["head"], tb["subj_pos"], tb["obj_pos"], tb["deprel"], tb["lens"], K)["adj"]
+    Wn, bn = synthetic.layer_params(8, dims)
+    xn, gyn = synthetic.normal(9, (B, T, dims[0])), synthetic.normal(10, (B, T, dims[-1]))
+    trees = _prune(tree, tb, K, dev)
+    x = _t(xn, dev).requires_grad_()
+    Ws = [_t(w, dev).requires_grad_() for w in Wn]
+    bs = [_t(b, dev).requires_grad_() for b in bn]
+    h = gcn.gcn_layers(x, Ws, bs, trees, compute_dtype=compute)
+    h.backward(_t(gyn, dev))
+    href, _ = gcn_ref.gcn_forward(adj, xn, Wn, bn)
+    dx, dWs, dbs = gcn_ref.gcn_backward(adj, xn, Wn, bn, gyn)
+    # fp32: the stated tolerances; bf16 storage: normwise (a ReLU decided the other way by a rounded pre-activation moves single entries)
+    err, f_tol, g_tol = (max_rel, FWD_RTOL, GRAD_RTOL) if compute == torch.float32 else (fro_rel, BF16_FRO, BF16_FRO)
+    assert err(h.detach().cpu().numpy(), href) <= f_tol
+    assert err(x.grad.cpu().numpy(), dx) <= g_tol
+    for l in range(3):
+        assert err(Ws[l].grad.cpu().numpy(), dWs[l]) <= g_tol, l
+        assert err(bs[l].grad.cpu().numpy(), dbs[l]) <= g_tol, l

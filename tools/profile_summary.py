@@ -22,7 +22,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 
 def short(name):
-    m = re.search(r"(rowtile_kernel<[^>]*>|weight_grad_kernel<[^>]*>|pack_weights_kernel<[^>]*>|prune_to_csr_kernel|fused_fwd_kernel<[^>]*>|rowprep_kernel<[^>]*>|rowgemm_kernel<[^>]*>|dz_rows_kernel<[^>]*>)", name)
+    m = re.search(r"(rowtile_wgrad_kernel<[^>]*>|rowtile_kernel<[^>]*>|weight_grad_kernel<[^>]*>|pack_weights_kernel<[^>]*>|prune_to_csr_kernel|fused_fwd_kernel<[^>]*>|rowprep_kernel<[^>]*>|rowgemm_kernel<[^>]*>|dz_rows_kernel<[^>]*>)", name)
     return (m.group(1) if m else name[:50]).replace("unsigned short", "bf16")
 
 
@@ -33,7 +33,9 @@ def bench_names(rows):
     for r in rows:
         n = short(r["Kernel_Name"])
         k = None
-        if n.startswith("rowtile"):
+        if n.startswith("rowtile_wgrad"):
+            k = "bwd_data0+wgrad1"                             # layer 0's backward-data launch carries layer 1's weight gradient
+        elif n.startswith("rowtile"):
             args = [a.strip() for a in n[n.index("<") + 1:n.rindex(">")].split(",")]
             bwd, dzin = args[3] == "true", args[-1] == "true"
             if not bwd:
@@ -42,7 +44,7 @@ def bench_names(rows):
             else:
                 k = "bwd_data0" if dzin else "bwd_data1"          # the top layer derives dZ itself, the layer below receives it
         elif n.startswith("weight_grad"):
-            k = "bwd_weight"                                   # one launch per step serves both layers
+            k = "bwd_weight0"                                  # the last launch of the sweep: the bottom layer's weight gradient
         elif n.startswith("pack"):
             k = "pack"
         elif n.startswith("prune"):
@@ -96,7 +98,7 @@ traffic = {k: int(2 * cs.get("FETCH_SIZE", 0) * 1024 + cs.get("WRITE_SIZE", 0) *
 # bench.py quotes these bytes only for the workload they were recorded on (tools/profile_round.sh profiles the default bench command)
 sha = os.popen("git -C %s rev-parse --short HEAD 2>/dev/null" % ROOT).read().strip() or "?"
 meta = dict(batch=50, seq=100, din=360, hidden=200, prune_k=1, dtype="bf16", lengths="full",
-            kernels=["pack", "fwd0", "fwd1", "bwd_data1", "bwd_data0", "bwd_weight"], git_sha="%s (%s)" % (sha, tag))
+            kernels=["pack", "fwd0", "fwd1", "bwd_data1", "bwd_data0+wgrad1", "bwd_weight0"], git_sha="%s (%s)" % (sha, tag))
 json.dump(dict(meta=meta, traffic=traffic), open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(traffic))
 for k in sorted(merged):

@@ -835,7 +835,8 @@ static void offer_side_wgrad(WeightGradParams& p_out, const void* z_frag_up, con
                              float* dW_up, float* db_up, int compute_dtype) {
     t_side = SideWgrad{};
     const int n_tiles = ceil_div((int)rows_of(B, T), ROWS);
-    if (!z_frag_up || !s_frag_up || !dW_up || !db_up || n_tiles > 192 || rowstream_enabled()) return;
+    static const int max_tiles = [] { const char* e = getenv("GCNPT_SIDE_TILES"); return e ? atoi(e) : 192; }();     // (experiments)
+    if (!z_frag_up || !s_frag_up || !dW_up || !db_up || n_tiles > max_tiles || rowstream_enabled()) return;
     const int nks = n_tiles * (compute_dtype == GCNPT_BF16 ? 1 : 2);
     const int blocks_l = ceil_div(ceil_div(H_up, 16), WG_MT) * ceil_div(ceil_div(Din_up, 16), WG_NT);
     t_side.blocks = plan_weight_grad(p_out, z_frag_up, s_frag_up, nks, Din_up, H_up, dW_up, db_up, blocks_l, RT_WAVES, std::max(64, 256 - n_tiles),

@@ -89,6 +89,11 @@ int plan_weight_grad(WeightGradParams& p, const void* z_frag, const void* s_frag
     // (big batches, wg_budget 768: 4-wave workgroups, three per CU, so that every CU's L1 path streams fragments -- with one slice a
     // 128 x 300-token batch ran on 135 workgroups for 121 us)
     int want = std::max(1, std::min(ceil_div(p.nks, waves), wg_budget / std::max(blocks_in_launch, mb * nb)));
+    // GCNPT_DETERMINISTIC=1: one slice, i.e. every element of dW / db is summed by exactly ONE workgroup in a fixed order and meets
+    // its zero-initialised accumulator in a single atomic add: run-to-run bit-identical gradients, as the reference's CPU / single-GPU
+    // path gives, at the price of the split contraction's parallelism
+    const char* det = getenv("GCNPT_DETERMINISTIC");
+    if (det && det[0] == '1') want = 1;
     int slices = want >= 8 ? want / 8 * 8 : (want >= 4 ? 4 : (want >= 2 ? 2 : 1));
     p.ks_per_wg = ceil_div(p.nks, slices);
     p.mb = mb; p.nb = nb; p.slices = slices;

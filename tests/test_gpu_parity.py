@@ -1773,3 +1773,30 @@ def test_three_layer_sweep_carries_weight_gradients_vs_oracle(api, dev, compute)
     for l in range(3):
         assert err(Ws[l].grad.cpu().numpy(), dWs[l]) <= g_tol, l
         assert err(bs[l].grad.cpu().numpy(), dbs[l]) <= g_tol, l
+
+
+def test_deterministic_weight_gradients(api, dev, monkeypatch):
+    """GCNPT_DETERMINISTIC=1: the weight gradient's contraction is not split across workgroups, so dW / db are bitwise reproducible from
+    run to run (and still the oracle's numbers); without it the float atomics may reorder the last bits."""
+    from gcn_over_pruned_trees_amd.utils import synthetic
+    from oracle import gcn_ref, prune_ref
+    gcn, tree = api
+    B, T, K, dims = 50, 100, 1, [360, 200, 200]
+    tb = synthetic.random_tree_batch(17, B, T, "tacred")
+    adj = prune_ref.batch_adj(tb["head"], tb["subj_pos"], tb["obj_pos"], tb["deprel"], tb["lens"], K)["adj"]
+    Wn, bn = synthetic.layer_params(18, dims)
+    xn, gyn = synthetic.normal(19, (B, T, dims[0])), synthetic.normal(20, (B, T, dims[-1]))
+    trees = _prune(tree, tb, K, dev)
+    monkeypatch.setenv("GCNPT_DETERMINISTIC", "1")
+    runs = []
+    for _ in range(3):
+        x = _t(xn, dev).requires_grad_()
+        Ws = [_t(w, dev).requires_grad_() for w in Wn]
+        bs = [_t(b, dev).requires_grad_() for b in bn]
+        gcn.gcn_layers(x, Ws, bs, trees, compute_dtype=torch.float32).backward(_t(gyn, dev))
+        runs.append([w.grad.clone() for w in Ws] + [b.grad.clone() for b in bs])
+    for r in runs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(runs[0], r))
+    _, dWs, dbs = gcn_ref.gcn_backward(adj, xn, Wn, bn, gyn)
+    for l in range(2):
+        assert max_rel(runs[0][l].cpu().numpy(), dWs[l]) <= GRAD_RTOL and max_rel(runs[0][2 + l].cpu().numpy(), dbs[l]) <= GRAD_RTOL

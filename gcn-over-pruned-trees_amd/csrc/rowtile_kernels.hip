@@ -18,6 +18,28 @@
 #include "layer_common.h"
 #include "wgrad_common.h"
 
+// the kernel's big outputs (rows, fragment images): plain stores, or -DGCNPT_NT_STORES=1 non-temporal ones (experiment: does leaving
+// less dirty data in the L2s shorten the launch boundary?  see DESIGN.md section 5)
+#if defined(GCNPT_NT_STORES) && GCNPT_NT_STORES
+template <typename V> __device__ __forceinline__ void gcnpt_out_store(V* p, const V& v) {
+    if constexpr (sizeof(V) == 16) {
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(p));
+    } else {
+        typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+        __builtin_nontemporal_store(__builtin_bit_cast(u32x2, v), reinterpret_cast<u32x2*>(p));
+    }
+}
+#define GCNPT_NT(ptr, val) gcnpt_out_store(ptr, val)
+#else
+#define GCNPT_NT_STORES 0
+#define GCNPT_NT(ptr, val) (*(ptr) = (val))
+#endif
+#define GCNPT_PLAIN(ptr, val) (*(ptr) = (val))
+// level 1: everything; 2: rows + the forward's S image (the dZ image is read by the very next launches); 3: rows only; 4: images only
+#define GCNPT_ROW_STORE(ptr, val) do { if (GCNPT_NT_STORES >= 1 && GCNPT_NT_STORES <= 3) GCNPT_NT(ptr, val); else GCNPT_PLAIN(ptr, val); } while (0)
+#define GCNPT_FRAG_STORE(bwd, ptr, val) do { if (GCNPT_NT_STORES == 1 || GCNPT_NT_STORES == 4 || (GCNPT_NT_STORES == 2 && !(bwd))) GCNPT_NT(ptr, val); else GCNPT_PLAIN(ptr, val); } while (0)
+
 namespace gcnpt {
 
 constexpr int ROWS = 32;             // token rows per workgroup (two 16-row MFMA tiles)
@@ -375,7 +397,7 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
                 u.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
                 u.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
                 u.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
-                F[((size_t)t * nks + tile_id) * 64 + lane] = u;
+                GCNPT_FRAG_STORE(BWD, &F[((size_t)t * nks + tile_id) * 64 + lane], u);
             }
         } else {
             const int i = lane & 15, g = lane >> 4;
@@ -387,7 +409,7 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
                 u.y = __float_as_uint(X[(size_t)(16 * kk + 4 * g + 1) * stride + 16 * t + i]);
                 u.z = __float_as_uint(X[(size_t)(16 * kk + 4 * g + 2) * stride + 16 * t + i]);
                 u.w = __float_as_uint(X[(size_t)(16 * kk + 4 * g + 3) * stride + 16 * t + i]);
-                F[((size_t)t * nks + 2 * tile_id + kk) * 64 + lane] = u;
+                GCNPT_FRAG_STORE(BWD, &F[((size_t)t * nks + 2 * tile_id + kk) * 64 + lane], u);
             }
         }
     }
@@ -546,13 +568,13 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
 #pragma unroll
                             for (int q = 0; q < NW; ++q) ow[q] = hw[q] > 0.0f ? ow[q] * f : 0.0f;
                         }
-                        *reinterpret_cast<V*>(out + (size_t)r * p.NOUT + c_lo + pc * PER) = o;
+                        GCNPT_ROW_STORE(reinterpret_cast<V*>(out + (size_t)r * p.NOUT + c_lo + pc * PER), o);
                     }
                 }
             } else if (r < p.N) {
                 for (int pc = tid & 15; pc < pieces; pc += 16)
-                    *reinterpret_cast<V*>(out + (size_t)r * p.NOUT + c_lo + pc * PER) =
-                        *reinterpret_cast<const V*>(O + (size_t)row * ostride + pc * PER);
+                    GCNPT_ROW_STORE(reinterpret_cast<V*>(out + (size_t)r * p.NOUT + c_lo + pc * PER),
+                                    *reinterpret_cast<const V*>(O + (size_t)row * ostride + pc * PER));
             }
         };
         constexpr int PER16 = 16 / (int)sizeof(OT), PER8 = 8 / (int)sizeof(OT);

@@ -801,8 +801,8 @@ class GCN(nn.Module):
             ps, seeds, seed_dev = self._dropout_plan()
             Ws, bs = [lin.weight for lin in self.W], [lin.bias for lin in self.W]
             xp = packed.pack_rows(gcn_inputs if gcn_inputs.dtype in (torch.float32, torch.bfloat16) else gcn_inputs.float())
-            hp = gcn_layers(xp, Ws, bs, packed, ps, seeds, self.compute_dtype, torch.float32, no_adj, seed_dev, self._wcache,
-                            prepacked=getattr(self, "_prepacked", None))
+            pre, self._prepacked = getattr(self, "_prepacked", None), None
+            hp = gcn_layers(xp, Ws, bs, packed, ps, seeds, self.compute_dtype, torch.float32, no_adj, seed_dev, self._wcache, prepacked=pre)
             return packed.unpack_rows(hp), packed.padded.pool_mask
         trees = adj if isinstance(adj, PrunedTrees) else adj_to_csr(adj, want_label=False)   # gcn.py:260-262
         no_adj = bool(self.opt.get('no_adj', False))                                           # gcn.py:264-265
@@ -813,7 +813,7 @@ class GCN(nn.Module):
         if self._stack_path(B, T, Din):
             # whole stack in one launch per direction (sentence-resident kernels)
             return gcn_stack(x, Ws, bs, trees, ps, seeds, torch.float32, no_adj, seed_dev), trees.pool_mask
-        pre = getattr(self, "_prepacked", None)
+        pre, self._prepacked = getattr(self, "_prepacked", None), None      # a request serves ONE forward
         req = getattr(self, "_pool_req", None)
         if req is not None:
             # GCNRelationModel asked for the pooled vectors directly (it would pool h next, gcn.py:116-121): stack + pooling as one op

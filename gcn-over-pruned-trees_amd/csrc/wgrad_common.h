@@ -64,8 +64,10 @@ __device__ __forceinline__ void weight_grad_body(const WeightGradParams& p, cons
     // XCD group: its rows cross the fabric once and every other read hits that XCD's L2.  (Speed only.)
     const int xg = id & 7, rest = id >> 3;
     int slice, blk;
-    if ((p.slices & 7) == 0) { const int sp = p.slices >> 3; slice = xg + 8 * (rest % sp); blk = rest / sp; }
-    else                     { const int gp = 8 / p.slices;  slice = xg % p.slices;       blk = rest * gp + xg / p.slices; }
+    // Which slices an XCD takes follows the row-tile kernels: XCD x wrote the x-th eighth of the row tiles (contiguous runs, see
+    // rowtile_kernels.hip), i.e. of the k-steps, and those lines are still in ITS L2 when the images are read back.
+    if ((p.slices & 7) == 0) { const int sp = p.slices >> 3; slice = xg * sp + rest % sp; blk = rest / sp; }
+    else                     { const int gp = 8 / p.slices;  slice = xg / gp;             blk = rest * gp + xg % gp; }
     if (blk >= p.mb * p.nb) return;
     const int bm = blk % p.mb, bn = blk / p.mb;
     const int m0 = bm * WG_MT, n0 = bn * NT;

@@ -613,7 +613,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTilePar
 // the launches before this one have left (dZ_{l+1}, S_{l+1}), and a batch of <= ~6 k rows leaves a third of the CUs without a row tile.
 // Workgroups [0, n_tiles) are row tiles, workgroups [wg_first, gridDim.x) (wg_first = n_tiles rounded up to 8, so that the weight
 // gradient's block -> XCD map holds) contract one slice of one output block each.  The last launch of the sweep is then the bottom
-// layer's weight gradient alone: 7.3 us instead of 13.0 us for both layers (profiles/r02_bench_c2_variants.json).
+// layer's weight gradient alone: 7.5 us instead of 13.0 us for both layers (profiles/r02_bench.json).
 template <typename CT, typename IT, typename OT, int VEC, int NTW, int KSMAX>
 __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_wgrad_kernel(const RowTileParams p, const WeightGradParams wg, const int n_tiles,
                                                                       const int wg_first) {

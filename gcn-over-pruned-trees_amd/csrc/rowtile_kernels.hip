@@ -45,7 +45,7 @@ namespace gcnpt {
 constexpr int ROWS = 32;             // token rows per workgroup (two 16-row MFMA tiles)
 constexpr int RT_THREADS = 512;      // 8 waves; wave w owns output tiles w, w+8, ...
 constexpr int RT_WAVES = RT_THREADS / WAVE;
-static_assert(RT_THREADS == 16 * ROWS, "the row store loop gives every row 16 threads");
+static_assert(RT_THREADS == 16 * ROWS, "the row store loop gives every row 16 threads (two rounds in the 4-wave form)");
 constexpr int NB_INLINE = 7;         // neighbours per row that the ELL head carries (include/gcnpt.h)
 #ifndef GCNPT_W_EARLY_NUM
 #define GCNPT_W_EARLY_NUM 1          // quarters of a wave's weight fragments requested before the adjacency is known (0..4 measured: 1 is best)
@@ -83,8 +83,11 @@ struct RowTileParams {
 // gather -- one load per neighbour instead of three (dY, Y, degree).
 // (a device function: the launch of its own below, and the backward launch that also carries a weight gradient, share it; block_id /
 // n_blocks: this workgroup's tile number and the number of tiles, which that launch does not read off blockIdx / gridDim)
-template <typename CT, typename IT, typename OT, bool BWD, int VEC, int NTW, int KSMAX, bool DZIN = false>
+// NWV: waves per workgroup.  8 for the headline batches (one workgroup per CU, the shortest chain); 4 for big batches, where two
+// workgroups share a CU (same registers per wave, half the waves each) and one's memory waits overlap the other's arithmetic.
+template <typename CT, typename IT, typename OT, bool BWD, int VEC, int NTW, int KSMAX, bool DZIN = false, int NWV = 8>
 __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int block_id, const int n_blocks, unsigned char* smem_raw) {
+    constexpr int RTT = NWV * WAVE, RTW = NWV;                  // threads and waves of this workgroup
     static_assert(BWD || !DZIN, "DZIN is a backward mode");
     constexpr bool MASKED = BWD && !DZIN;                       // the loader computes dZ = dY * 1[Y>0] * scale / (deg+1) itself
     constexpr int KSTEP = sizeof(CT) == 2 ? 32 : 16;            // K consumed per fragment
@@ -92,7 +95,7 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
     constexpr int ITEMS = WIDE ? 2 : 3;                         // 8-element chunks a thread gathers per batch
     constexpr int NBU = WIDE ? 2 : 4;                           // neighbour rows fetched together
     const int stride = lds_stride_dw(p.Kpad * (int)sizeof(CT) / 4) * 4 / (int)sizeof(CT);     // S row stride, CT elements
-    const int ncols_pass = RT_WAVES * NTW * 16;
+    const int ncols_pass = RTW * NTW * 16;
     const int ostride = out_stride_dw(min(round_up(p.NOUT, 16), ncols_pass) * (int)sizeof(OT) / 4) * 4 / (int)sizeof(OT);
     const size_t s_bytes = (size_t)ROWS * stride * sizeof(CT);
     CT* S = reinterpret_cast<CT*>(smem_raw);
@@ -109,7 +112,7 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
     int* glist = meta + 10 * ROWS;            // [ROWS] tile rows that aggregate at least one entry, compacted
     int* rsb = meta + 11 * ROWS;              // [ROWS] first row of the row's sentence (b * T)
     int* gcount = meta + 12 * ROWS;           // [1] the number of entries of glist
-    float* sbias = reinterpret_cast<float*>(meta + 13 * ROWS);   // [RT_THREADS] fwd: the bias of this pass's columns
+    float* sbias = reinterpret_cast<float*>(meta + 13 * ROWS);   // [max(RTT, columns of a pass)] fwd: the bias of this pass's columns
 
     // `wave` through readfirstlane: the compiler then knows it is uniform and does every wave-dependent address in SALU
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -139,6 +142,8 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
     const int sb_v = p.T ? (int)er / p.T * p.T : 0;   // the one division by T, done while the loads are on their way (T = 0: packed rows, columns are absolute)
     float bias_v = 0.0f;                           // fwd: one bias element per thread, parked in LDS with the heads (registers are
     if constexpr (!BWD) bias_v = p.bias[min(tid, p.NOUT - 1)];      // too scarce to carry 4 per tile through the whole kernel)
+    float bias_w = 0.0f;                           // (4 waves x 5 tiles: 320 columns per pass, a second element for the first 64 threads)
+    if constexpr (!BWD && RTW * NTW * 16 > RTT) bias_w = p.bias[min(RTT + tid, p.NOUT - 1)];
 
     // own rows of the first batch (everyone)
     const int nchunk = p.Kpad / 8;
@@ -155,7 +160,7 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
     auto issue_self = [&](int batch) {
 #pragma unroll
         for (int u = 0; u < ITEMS; ++u) {
-            const int it = (batch * ITEMS + u) * RT_THREADS + tid;
+            const int it = (batch * ITEMS + u) * RTT + tid;
             const int row = div_chunk(it), k0 = (it - row * nchunk) * 8;
             const size_t r = (size_t)min(r0 + row, p.N - 1);
             ld8(src, r, min(k0, kmax8), self[u]);
@@ -175,7 +180,7 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
                 if (ks < ks_lo || ks >= ks_hi) continue;                    // compile-time after unrolling
-                const int tl = min(pass * RT_WAVES * NTW + j * RT_WAVES + wave, n_tiles - 1);
+                const int tl = min(pass * RTW * NTW + j * RTW + wave, n_tiles - 1);
                 const int kk = min(kc0 + ks, ksteps - 1);
 #ifdef GCNPT_STAMPS
                 if (p.knob & 1) { wreg[ks][j] = wfrag[lane]; continue; }          // experiment: no weight traffic
@@ -202,7 +207,10 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
         reinterpret_cast<int4*>(rell)[erow * 2 + ehalf] = make_int4(e0, ell_v.y, ell_v.z, ell_v.w);
         const float dn = (float)(deg_v + 1);
         rsb[erow] = sb_v;
-        if constexpr (!BWD) sbias[tid] = bias_v;
+        if constexpr (!BWD) {
+            sbias[tid] = bias_v;
+            if constexpr (RTW * NTW * 16 > RTT) { if (tid < RTW * NTW * 16 - RTT) sbias[RTT + tid] = bias_w; }
+        }
         rinv[erow] = (BWD ? p.scale : 1.0f) / dn;       // both lanes of a row write it: a use under `first` only would let
         rden[erow] = dn;                                // hipcc sink the degree load into that branch, behind a full wait
         const bool agg = first && e0 > 0 && p.out != nullptr;
@@ -333,11 +341,11 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
     GCNPT_STAMP(p.stamps, 3);
 
     // (2b)
-    const int n_batches = ceil_div(n_items, ITEMS * RT_THREADS);
+    const int n_batches = ceil_div(n_items, ITEMS * RTT);
     auto copy_batch = [&](int batch) {
 #pragma unroll
         for (int u = 0; u < ITEMS; ++u) {
-            const int it = (batch * ITEMS + u) * RT_THREADS + tid;
+            const int it = (batch * ITEMS + u) * RTT + tid;
             if (it >= n_items) continue;
             const int row = div_chunk(it), k0 = (it - row * nchunk) * 8;
             const bool live = r0 + row < p.N && k0 < p.K;
@@ -365,7 +373,7 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
     GCNPT_STAMP(p.stamps, 4);
     // (2a) -- only the waves that own an item: the sums cost a wave ~120 VALU instructions whether its lanes are live or not
     if (wave * WAVE < n_g) g_finish(tid, g0);
-    for (int base = RT_THREADS; base < n_g; base += RT_THREADS) {      // tiles with more than 512 / (K/8) aggregating rows
+    for (int base = RTT; base < n_g; base += RTT) {      // tiles with more than 512 / (K/8) aggregating rows
         GItem g;
         g_issue(base + tid, g);
         g_finish(base + tid, g);
@@ -387,7 +395,7 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
         if constexpr (sizeof(CT) == 2) {
             const int i = lane & 15, g = lane >> 4, q4 = i >> 2, pp = i & 3;
             const size_t nks = n_blocks;
-            for (int t = wave; t < w_tiles; t += RT_WAVES) {
+            for (int t = wave; t < w_tiles; t += RTW) {
                 const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                     (__attribute__((address_space(3))) s16x4_t*)(X + (size_t)(8 * g + q4) * stride + 16 * t + 4 * pp));
                 const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -402,7 +410,7 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
         } else {
             const int i = lane & 15, g = lane >> 4;
             const size_t nks = (size_t)n_blocks * 2;
-            for (int tk = wave; tk < w_tiles * 2; tk += RT_WAVES) {
+            for (int tk = wave; tk < w_tiles * 2; tk += RTW) {
                 const int t = tk >> 1, kk = tk & 1;
                 uint4 u;
                 u.x = __float_as_uint(X[(size_t)(16 * kk + 4 * g + 0) * stride + 16 * t + i]);
@@ -417,22 +425,22 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
         if (p.frag_out) __syncthreads();                         // every wave has read its share of Z: the region becomes O
     }
     if (p.zero_a)
-        for (int i = block_id * RT_THREADS + tid; i < p.zero_a_n; i += n_blocks * RT_THREADS) p.zero_a[i] = 0.0f;
+        for (int i = block_id * RTT + tid; i < p.zero_a_n; i += n_blocks * RTT) p.zero_a[i] = 0.0f;
     if (p.zero_b)
-        for (int i = block_id * RT_THREADS + tid; i < p.zero_b_n; i += n_blocks * RT_THREADS) p.zero_b[i] = 0.0f;
+        for (int i = block_id * RTT + tid; i < p.zero_b_n; i += n_blocks * RTT) p.zero_b[i] = 0.0f;
     GCNPT_STAMP(p.stamps, 7);
     if (!p.out) return;
 
     // (3) + (4)
     OT* out = static_cast<OT*>(p.out);
     const int arow = lane & 15, kgrp = lane >> 4;
-    const int n_pass = ceil_div(n_tiles, RT_WAVES * NTW);
+    const int n_pass = ceil_div(n_tiles, RTW * NTW);
 
     for (int pass = 0; pass < n_pass; ++pass) {
         f32x4_t acc[2][NTW];
 #pragma unroll
         for (int j = 0; j < NTW; ++j) { acc[0][j] = (f32x4_t){0, 0, 0, 0}; acc[1][j] = (f32x4_t){0, 0, 0, 0}; }
-        const int tile0 = pass * RT_WAVES * NTW + wave;
+        const int tile0 = pass * RTW * NTW + wave;
 
         for (int kc0 = 0; kc0 < ksteps; kc0 += KSMAX) {
             if (pass > 0 || kc0 > 0) load_w(pass, kc0, 0, KSMAX);
@@ -475,7 +483,7 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
         if (pass > 0) {
             __syncthreads();                                             // previous pass's rows have left O
             if constexpr (!BWD) {                                        // (NOUT > 512 only) this pass's bias
-                sbias[tid] = p.bias[min(pass * ncols_pass + tid, p.NOUT - 1)];
+                for (int c = tid; c < ncols_pass; c += RTT) sbias[c] = p.bias[min(pass * ncols_pass + c, p.NOUT - 1)];
                 __syncthreads();
             }
         }
@@ -484,7 +492,7 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
         for (int mt = 0; mt < 2; ++mt) { den[mt] = rden[mt * 16 + (lane & 15)]; inv[mt] = rinv[mt * 16 + (lane & 15)]; }
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
-            const int tl = tile0 + j * RT_WAVES;
+            const int tl = tile0 + j * RTW;
             if (tl >= n_tiles) continue;
             const int col0 = tl * 16 + (lane >> 4) * 4;
             const int lcol0 = col0 - pass * ncols_pass;
@@ -537,7 +545,9 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
             constexpr int PER = (int)sizeof(V) / (int)sizeof(OT);
             constexpr int NW = (int)sizeof(V) / 4;
             const int pieces = width / PER;                                  // 16 threads per row: no division, 256 contiguous bytes each round
-            const int row = tid >> 4, r = r0 + row;
+#pragma unroll
+            for (int rh = 0; rh < ROWS; rh += RTT / 16) {                    // (one round with 8 waves, two with 4)
+            const int row = rh + (tid >> 4), r = r0 + row;
             if (BWD && relu) {
                 // hand-over to the layer below: its dZ instead of dh (gcn.py:390-393 differentiated where the rows are at hand);
                 // the input rows are fetched in one batch, then masked and scaled while the tile leaves LDS
@@ -576,6 +586,7 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
                     GCNPT_ROW_STORE(reinterpret_cast<V*>(out + (size_t)r * p.NOUT + c_lo + pc * PER),
                                     *reinterpret_cast<const V*>(O + (size_t)row * ostride + pc * PER));
             }
+            }
         };
         constexpr int PER16 = 16 / (int)sizeof(OT), PER8 = 8 / (int)sizeof(OT);
         if (p.vec_out == 16 && (width % PER16) == 0 && (c_lo % PER16) == 0) {
@@ -583,7 +594,7 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
         } else if (p.vec_out >= 8 && (width % PER8) == 0 && (c_lo % PER8) == 0) {
             store_rows(uint2{});
         } else {
-            for (int it = tid; it < ROWS * width; it += RT_THREADS) {
+            for (int it = tid; it < ROWS * width; it += RTT) {
                 const int row = it / width, c = it - row * width;
                 const int r = r0 + row;
                 if (r >= p.N) continue;
@@ -603,10 +614,10 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
 }
 
 
-template <typename CT, typename IT, typename OT, bool BWD, int VEC, int NTW, int KSMAX, bool DZIN = false>
-__global__ __launch_bounds__(RT_THREADS, 2) void rowtile_kernel(const RowTileParams p) {
+template <typename CT, typename IT, typename OT, bool BWD, int VEC, int NTW, int KSMAX, bool DZIN = false, int NWV = 8>
+__global__ __launch_bounds__(NWV * WAVE, 2) void rowtile_kernel(const RowTileParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    rowtile_body<CT, IT, OT, BWD, VEC, NTW, KSMAX, DZIN>(p, (int)blockIdx.x, (int)gridDim.x, smem_raw);
+    rowtile_body<CT, IT, OT, BWD, VEC, NTW, KSMAX, DZIN, NWV>(p, (int)blockIdx.x, (int)gridDim.x, smem_raw);
 }
 
 // The backward-data launch of layer l with the WEIGHT GRADIENT OF LAYER l+1 as a side job: that gradient only needs the fragment images
@@ -650,18 +661,18 @@ static int vec_bytes(int width, size_t es, const void* a, const void* b) {
 struct SideWgrad { const WeightGradParams* wg = nullptr; int blocks = 0; bool carried = false; };
 static thread_local SideWgrad t_side;
 
-template <typename CT, typename IT, typename OT, bool BWD, int VEC, int NTW, int KSMAX, bool DZIN = false>
+template <typename CT, typename IT, typename OT, bool BWD, int VEC, int NTW, int KSMAX, bool DZIN = false, int NWV = 8>
 static int launch_rowtile_cfg(hipStream_t s, const RowTileParams& p) {
     const int stride = lds_stride_dw(p.Kpad * (int)sizeof(CT) / 4) * 4 / (int)sizeof(CT);
-    const int ncols_pass = RT_WAVES * NTW * 16;
+    const int ncols_pass = NWV * NTW * 16;
     const int ostride = out_stride_dw(std::min(round_up(p.NOUT, 16), ncols_pass) * (int)sizeof(OT) / 4) * 4 / (int)sizeof(OT);
     const size_t s_bytes = (size_t)ROWS * stride * sizeof(CT), o_bytes = (size_t)ROWS * ostride * sizeof(OT);
     const size_t lds = s_bytes + (BWD ? std::max(s_bytes, o_bytes) : o_bytes) +
-                       (size_t)ROWS * 13 * sizeof(int) + (size_t)RT_THREADS * sizeof(float);
+                       (size_t)ROWS * 13 * sizeof(int) + (size_t)std::max(NWV * WAVE, ncols_pass) * sizeof(float);
     if (lds > 160 * 1024) return fail(GCNPT_E_UNSUPPORTED, "layer: K=%d needs %zu B of LDS per workgroup", p.K, lds);
     const int n_tiles = ceil_div(p.N, ROWS);
     // the uniform-precision instantiations can carry the layer above's weight gradient on the CUs that have no row tile
-    if constexpr (BWD && DZIN && std::is_same<IT, OT>::value && sizeof(CT) == sizeof(IT)) {
+    if constexpr (NWV == 8 && BWD && DZIN && std::is_same<IT, OT>::value && sizeof(CT) == sizeof(IT)) {
         if (t_side.wg && t_side.blocks > 0) {
             auto kern = rowtile_wgrad_kernel<CT, IT, OT, VEC, NTW, KSMAX>;
             GCNPT_LDS_ATTR_ONCE(kern, 160 * 1024);
@@ -673,11 +684,25 @@ static int launch_rowtile_cfg(hipStream_t s, const RowTileParams& p) {
             return GCNPT_OK;
         }
     }
-    auto kern = rowtile_kernel<CT, IT, OT, BWD, VEC, NTW, KSMAX, DZIN>;
+    auto kern = rowtile_kernel<CT, IT, OT, BWD, VEC, NTW, KSMAX, DZIN, NWV>;
     GCNPT_LDS_ATTR_ONCE(kern, 160 * 1024);
-    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(RT_THREADS), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(NWV * WAVE), lds, s, p);
     GCNPT_HIP_CHECK(hipGetLastError());
     return GCNPT_OK;
+}
+
+// Big batches (more row tiles than CUs): workgroups of 4 waves, two or three per CU, so that one workgroup's memory waits overlap another's
+// arithmetic (the 8-wave form keeps ~240 registers per wave: one workgroup per CU, nothing to overlap with).  Measured (C2 widths,
+// B = 64 ... 1024; C5 widths): slower below ~256 tiles (B = 80: +20 %), 3 % faster at B = 100, 9-12 % faster from B = 256 on and at the
+// C5 shape; not when the narrower workgroup needs one more column pass than the wide one (360 columns: 23 tiles = 20 + 3).
+// GCNPT_WAVES4=0 / 1 forces the choice (A/B, tests).
+static bool use_four_waves(const RowTileParams& p) {
+    const char* e = getenv("GCNPT_WAVES4");
+    if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+    if (ceil_div(p.N, ROWS) <= 256) return false;
+    const int n_tiles = ceil_div(p.NOUT, 16);
+    const int pass8 = n_tiles <= 24 ? 1 : ceil_div(n_tiles, 32), pass4 = n_tiles <= 16 ? 1 : ceil_div(n_tiles, 20);
+    return pass4 <= pass8;
 }
 
 // output tiles per wave: the smallest of {2,3,4} that covers NOUT in one pass (8 waves x NTW x 16 columns),
@@ -686,6 +711,12 @@ static int launch_rowtile_cfg(hipStream_t s, const RowTileParams& p) {
 template <typename CT, typename IT, typename OT, bool BWD, int VEC, bool DZIN>
 static int launch_rowtile_vec(hipStream_t s, const RowTileParams& p) {
     const int n_tiles = ceil_div(p.NOUT, 16);
+    if (use_four_waves(p)) {                                  // 4 waves cover 8 / 12 / 16 column tiles per pass
+        if (n_tiles <= 4 * 2) return launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 2, 12, DZIN, 4>(s, p);
+        if (n_tiles <= 4 * 3) return launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 3, 7, DZIN, 4>(s, p);
+        if (n_tiles <= 4 * 4) return launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 4, 5, DZIN, 4>(s, p);
+        return launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 5, 4, DZIN, 4>(s, p);      // 300 / 600 columns: one / two passes of 20 tiles
+    }
     if (n_tiles <= RT_WAVES * 2) {
         // 13 k-steps = the C-GCN input width (2 x 200 BiLSTM states): one more resident k-step instead of a second load phase
         if (p.Kpad / (sizeof(CT) == 2 ? 32 : 16) == 13) return launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 2, 13, DZIN>(s, p);

@@ -1800,3 +1800,38 @@ def test_deterministic_weight_gradients(api, dev, monkeypatch):
     _, dWs, dbs = gcn_ref.gcn_backward(adj, xn, Wn, bn, gyn)
     for l in range(2):
         assert max_rel(runs[0][l].cpu().numpy(), dWs[l]) <= GRAD_RTOL and max_rel(runs[0][2 + l].cpu().numpy(), dbs[l]) <= GRAD_RTOL
+
+
+# ---------------------------------------------------------------------------------------------------
+# 4-wave workgroups (big batches: two or three workgroups per CU) against the 8-wave form
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dims", [(72, 100), (200, 180), (360, 250), (600, 300), (300, 600)],
+                         ids=["7_tiles", "12_tiles", "16_tiles", "19_tiles", "38_tiles_two_passes"])
+@pytest.mark.parametrize("compute", [torch.float32, torch.bfloat16])
+def test_four_wave_workgroups_match_eight(api, dev, compute, dims, monkeypatch):
+    """GCNPT_WAVES4=1 forces the big-batch form of the row-tile kernel (4 waves per workgroup; 2 / 3 / 4 / 5 column tiles per wave, one
+    or two passes) on a small batch: same k-step order per output tile, so outputs and the input gradient are bit-identical to the 8-wave
+    form's; the weight gradient (float atomics) to 1e-5."""
+    from gcn_over_pruned_trees_amd.utils import synthetic
+    gcn, tree = api
+    din, hid = dims
+    B, T, K = 7, 53, 2
+    tb = synthetic.random_tree_batch(23, B, T, "tacred")
+    trees = _prune(tree, tb, K, dev)
+    Wn, bn = synthetic.layer_params(24, [din, hid, hid])
+    xn, gyn = synthetic.normal(25, (B, T, din)), synthetic.normal(26, (B, T, hid))
+    res = []
+    for four in ("0", "1"):
+        monkeypatch.setenv("GCNPT_WAVES4", four)
+        x = _t(xn, dev).requires_grad_()
+        Ws = [_t(w, dev).requires_grad_() for w in Wn]
+        bs = [_t(b, dev).requires_grad_() for b in bn]
+        h = gcn.gcn_layers(x, Ws, bs, trees, [0.3, 0.0], [5, 0], compute_dtype=compute)
+        h.backward(_t(gyn, dev))
+        torch.cuda.synchronize()
+        res.append((h.detach(), x.grad, [w.grad for w in Ws], [b.grad for b in bs]))
+    a, b = res
+    assert float(a[0].abs().max()) > 0
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for l in range(2):
+        assert max_rel(b[2][l].cpu().numpy(), a[2][l].cpu().numpy()) <= 1e-5 and max_rel(b[3][l].cpu().numpy(), a[3][l].cpu().numpy()) <= 1e-5

@@ -663,8 +663,9 @@ class GCN(nn.Module):
         self._prepacked = pack
 
     def _stack_path(self, B, T, Din):
-        # the sentence-resident kernels win from ~256 sentences per batch on (profiles/r02_stack_vs_layers.json): default there
-        return bool(self.compute_dtype == torch.bfloat16 and self.opt.get('gcn_fused', B >= 256)
+        # the sentence-resident kernels (one launch per direction) are opt-in: since the row-tile kernel runs big batches with 4-wave
+        # workgroups, one launch per layer is faster at every batch size measured (profiles/r02_stack_vs_layers.json: B = 256 ... 1024)
+        return bool(self.compute_dtype == torch.bfloat16 and self.opt.get('gcn_fused', False)
                     and gcn_stack_supported(T, Din, self.mem_dim, self.layers))
 
     def _dropout_plan(self):

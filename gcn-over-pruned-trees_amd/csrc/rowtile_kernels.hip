@@ -701,7 +701,7 @@ static bool use_four_waves(const RowTileParams& p) {
     if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
     if (ceil_div(p.N, ROWS) <= 256) return false;
     const int n_tiles = ceil_div(p.NOUT, 16);
-    const int pass8 = n_tiles <= 24 ? 1 : ceil_div(n_tiles, 32), pass4 = n_tiles <= 16 ? 1 : ceil_div(n_tiles, 20);
+    const int pass8 = n_tiles <= 24 ? 1 : ceil_div(n_tiles, 32), pass4 = n_tiles <= 24 ? 1 : ceil_div(n_tiles, 20);
     return pass4 <= pass8;
 }
 
@@ -715,6 +715,7 @@ static int launch_rowtile_vec(hipStream_t s, const RowTileParams& p) {
         if (n_tiles <= 4 * 2) return launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 2, 12, DZIN, 4>(s, p);
         if (n_tiles <= 4 * 3) return launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 3, 7, DZIN, 4>(s, p);
         if (n_tiles <= 4 * 4) return launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 4, 5, DZIN, 4>(s, p);
+        if (n_tiles > 20 && n_tiles <= 24) return launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 6, 3, DZIN, 4>(s, p);      // 360 columns in one pass
         return launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 5, 4, DZIN, 4>(s, p);      // 300 / 600 columns: one / two passes of 20 tiles
     }
     if (n_tiles <= RT_WAVES * 2) {

@@ -1805,11 +1805,11 @@ def test_deterministic_weight_gradients(api, dev, monkeypatch):
 # ---------------------------------------------------------------------------------------------------
 # 4-wave workgroups (big batches: two or three workgroups per CU) against the 8-wave form
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("dims", [(72, 100), (200, 180), (360, 250), (600, 300), (300, 600)],
-                         ids=["7_tiles", "12_tiles", "16_tiles", "19_tiles", "38_tiles_two_passes"])
+@pytest.mark.parametrize("dims", [(72, 100), (200, 180), (360, 250), (600, 300), (200, 360), (300, 600)],
+                         ids=["7_tiles", "12_tiles", "16_tiles", "19_tiles", "23_tiles", "38_tiles_two_passes"])
 @pytest.mark.parametrize("compute", [torch.float32, torch.bfloat16])
 def test_four_wave_workgroups_match_eight(api, dev, compute, dims, monkeypatch):
-    """GCNPT_WAVES4=1 forces the big-batch form of the row-tile kernel (4 waves per workgroup; 2 / 3 / 4 / 5 column tiles per wave, one
+    """GCNPT_WAVES4=1 forces the big-batch form of the row-tile kernel (4 waves per workgroup; 2 / 3 / 4 / 5 / 6 column tiles per wave, one
     or two passes) on a small batch: same k-step order per output tile, so outputs and the input gradient are bit-identical to the 8-wave
     form's; the weight gradient (float atomics) to 1e-5."""
     from gcn_over_pruned_trees_amd.utils import synthetic

@@ -125,7 +125,7 @@ static int wg_blocks(int n_layers, const int* Din, const int* H, int nt) {
 
 static int launch_weight_grad(hipStream_t s, const WeightGradMulti& mp, int compute_dtype, int waves, int nt) {
     if (compute_dtype == GCNPT_BF16) {
-        if (nt == 6) return launch_weight_grad_cfg<bf16_t, 4, 6, 2>(s, mp);
+        if (nt == 6) return launch_weight_grad_cfg<bf16_t, 4, 6, 3>(s, mp);
         return waves == 8 ? launch_weight_grad_cfg<bf16_t, 8, WG_NT, WG_KB>(s, mp) : launch_weight_grad_cfg<bf16_t, 4, WG_NT, WG_KB>(s, mp);
     }
     if (nt == 6) return launch_weight_grad_cfg<float, 4, 6, 2>(s, mp);

@@ -27,7 +27,7 @@ def short(name):
 
 
 def bench_names(rows):
-    """Map dispatches to bench.py kernel names by template arguments: rowtile_kernel<CT, IT, OT, BWD, VEC, NTW, KSMAX, DZIN>."""
+    """Map dispatches to bench.py kernel names by template arguments: rowtile_kernel<CT, IT, OT, BWD, VEC, NTW, KSMAX, DZIN, NWV>."""
     seen = collections.Counter()
     out = []
     for r in rows:
@@ -37,7 +37,7 @@ def bench_names(rows):
             k = "bwd_data0+wgrad1"                             # layer 0's backward-data launch carries layer 1's weight gradient
         elif n.startswith("rowtile"):
             args = [a.strip() for a in n[n.index("<") + 1:n.rindex(">")].split(",")]
-            bwd, dzin = args[3] == "true", args[-1] == "true"
+            bwd, dzin = args[3] == "true", len(args) > 7 and args[7] == "true"
             if not bwd:
                 k = "fwd%d" % (seen["fwd"] % 2)
                 seen["fwd"] += 1

@@ -16,11 +16,12 @@ direction, reached through the C-ABI of include/gcnpt.h.  Embeddings, the option
 the output MLP stay ordinary PyTorch-ROCm modules, as in the reference.
 
 New optional `opt` keys (defaults reproduce the reference): `gcn_dtype` = 'fp32' | 'bf16' (MFMA operand /
-activation storage type inside the layer stack), `gcn_fused` (bf16 only, default: batches of >= 256 sentences: run the whole stack with the
-sentence-resident one-launch-per-direction kernels when the shape fits; slower than one launch per layer at B=50), `gcn_check_trees` = True (synchronise once per forward to
+activation storage type inside the layer stack), `gcn_fused` = False (bf16 only; True: run the whole stack with the
+sentence-resident one-launch-per-direction kernels when the shape fits; slower than one launch per layer at every batch size measured), `gcn_check_trees` = True (synchronise once per forward to
 raise on malformed trees the way the reference does; False keeps the step free of host syncs), `gcn_packed` = False (True: the
 layer loop runs on token-packed rows, sum(len) instead of B*T, padding only at the module boundary), `gcn_graph_rng` = False
-(True: dropout seeds that survive hipGraph capture -- with `gcn_check_trees=False` a whole training step of the no-LSTM
+(True: dropout seeds that survive hipGraph capture), `gcn_pool_handover` = True (layer stack + poolings as one op whose backward
+hands the top layer its dZ), `gcn_pack_with_trees` = True (the tree launch also packs the weights in a training step) -- with `gcn_check_trees=False` a whole training step of the no-LSTM
 model can be captured with torch.cuda.graph and replayed, see tests/test_gpu_parity.py::test_training_step_graph_capture).
 """
 import ctypes

@@ -23,8 +23,56 @@ def rel(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
+def fro(a, b):
+    return float(np.sqrt(((a - b) ** 2).sum()) / max(np.sqrt((b ** 2).sum()), 1e-30))
+
+
+def bf16_case(rng, dev):
+    """bf16 storage: the 4-wave and the 8-wave form must agree bit for bit (forward, input gradient), with dropout on, padded and
+    token-packed; and stay within bf16 distance of the fp32 result."""
+    B, T, K, L = int(rng.randint(1, 24)), int(rng.randint(4, 90)), int(rng.randint(0, 3)), int(rng.randint(1, 4))
+    dims = [int(rng.choice([8, 16, 40, 72, 104, 200, 300, 360])) for _ in range(L + 1)]
+    packed = bool(rng.randint(0, 2))
+    tb = synthetic.random_tree_batch(int(rng.randint(1 << 30)), B, T, "tacred")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    trees = tree.prune_to_csr(t(tb["head"]), t(tb["subj_pos"]), t(tb["obj_pos"]), t(tb["deprel"]), K, masks=t(tb["masks"]))
+    Wn, bn = synthetic.layer_params(int(rng.randint(1 << 30)), dims)
+    xn, gyn = synthetic.normal(int(rng.randint(1 << 30)), (B, T, dims[0])), synthetic.normal(int(rng.randint(1 << 30)), (B, T, dims[-1]))
+    x0, g0 = t(xn).to(torch.bfloat16), t(gyn)
+    if packed:
+        keep = ~t(tb["masks"])
+        trees = trees.pack(tb["lens"].tolist())
+        x0, g0 = x0[keep].contiguous(), g0[keep].contiguous()
+    drop = [0.3] * (L - 1) + [0.0]
+    outs = {}
+    for mode in ("0", "1", "fp32"):
+        os.environ["GCNPT_WAVES4"] = "0" if mode == "fp32" else mode
+        x = (x0.float() if mode == "fp32" else x0.clone()).requires_grad_()
+        Ws = [t(w).requires_grad_() for w in Wn]
+        bs = [t(b).requires_grad_() for b in bn]
+        h = gcn.gcn_layers(x, Ws, bs, trees, drop, list(range(11, 11 + L)), torch.float32 if mode == "fp32" else torch.bfloat16, torch.float32)
+        h.backward(g0)
+        outs[mode] = (h.detach().float(), x.grad.float(), [w.grad for w in Ws])
+    a, b, f = outs["0"], outs["1"], outs["fp32"]
+    ok = torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    e = fro(a[0].cpu().numpy(), f[0].cpu().numpy())
+    if not ok or e > 5e-2:
+        print("BF16 MISMATCH B=%d T=%d K=%d dims=%s packed=%s equal=%s fro_vs_fp32=%.2e" % (B, T, K, dims, packed, ok, e))
+        sys.exit(1)
+    return e
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    if os.environ.get("FUZZ_BF16"):
+        dev = torch.device("cuda:0")
+        rng = np.random.RandomState(int(os.environ.get("FUZZ_SEED", "7")))
+        t0, n, worst = time.time(), 0, 0.0
+        while time.time() - t0 < budget:
+            worst = max(worst, bf16_case(rng, dev))
+            n += 1
+        print("bf16 fuzz ok: %d cases in %.0f s, worst Frobenius distance to fp32 %.2e" % (n, time.time() - t0, worst))
+        return
     dev = torch.device("cuda:0")
     rng = np.random.RandomState(int(os.environ.get("FUZZ_SEED", "7")))
     t0, n, worst = time.time(), 0, 0.0

@@ -2,24 +2,30 @@
 """
 bench.py -- BASELINE.json metric: GCN-layer fwd+bwd sentences/sec at batch=50 seq=100 h=200 on N MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]            (N > 1: launched by torch.distributed.run)
+  python bench.py [--gpus N] [--steps K] [--warmup W]            (N > 1: launched by torch.distributed.run, or self-launched)
 
 One "step" = the hot path over one synthetic TACRED-shaped batch of 50 sentences x 100 tokens
 (BASELINE.json configs[1]: 2-layer GCN, no LSTM, Din 360 -> 200 -> 200, prune_k 1, bf16 storage,
 fp32 accumulation, dropout 0.5 between the layers), entirely through the C-ABI of include/gcnpt.h:
-    pack W0+W1 (one launch) -> layer0 fwd -> layer1 fwd -> layer1 bwd-data -> [layer1 bwd-weight || layer0 bwd-data] -> layer0 bwd-weight
+    pack W0+W1 -> layer0 fwd -> layer1 fwd -> layer1 bwd-data (+ dZ0 image) -> layer0 bwd-data with both weight gradients riding
+(five launches from three native calls: gcnpt_pack_weights_multi, gcnpt_layers_fwd, gcnpt_layers_bwd).
 Inputs (x, gy, weights, the loader's integer tensors) are resident in HBM before the timed region.
-`value` is the layer stack alone, as the metric says; `with_prune` repeats the measurement with the
-pruned-tree adjacency build (gcnpt_prune_to_csr) inside every step.
-For N > 1 every rank runs its own 50-sentence shard (weak scaling, no data-path collective) and the
-flat gradient bucket [dW0,db0,dW1,db1] is all-reduced over RCCL once per step, overlapped with the
-next step's compute (BASELINE.json configs[3]).
+`value` is the layer stack alone, as the metric says; `with_prune` / `with_cached_trees` repeat the measurement with the
+pruned-tree adjacency build / its assembly from a pre-pruned dataset inside every step.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant kernel and
-`cpu_baseline` (the CPU oracle -- a numpy port of the reference's dense-bmm layer loop -- on this box's cores).
+For N > 1 every rank runs its own 50-sentence shard (weak scaling, no data-path collective) as SYNCHRONOUS data-parallel SGD
+(BASELINE.json configs[3]; the reference updates every step at batch 50, train.py:209,224-227): the flat gradient bucket
+[dW0,db0,dW1,db1] is all-reduced over RCCL, W -= lr * g runs on the device, and the next step's weight pack reads the updated
+weights -- step i+1 depends on all-reduce i.  (`async_upper_bound` in the line is the free-running ring of round 2, where nothing
+consumes the reduced gradient: NOT synchronous SGD, reported as a labelled secondary only.)
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant kernel, `launch_floor_us` (the
+same launches with empty bodies) and `cpu_baseline` (the CPU oracle on this box's cores).
 """
 import argparse
+import copy
 import ctypes
+import hashlib
 import json
 import os
 import sys
@@ -32,6 +38,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+SGD_LR = 1e-9                  # N > 1: the device-side update between the all-reduce and the next step's pack
 
 
 def parse():
@@ -51,15 +58,9 @@ def parse():
                          "(gcnpt_pack_trees), what a variable-length batch costs without its padding (use with --lengths tacred)")
     ap.add_argument("--drop", type=float, default=0.5)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--fused", action="store_true",
-                    help="sentence-resident stack kernels (all layers in one launch per direction) instead of one launch per layer; "
-                         "measured slower on MI355X at this size (109 vs 76 us/step): 50 workgroups carry every elementwise phase")
-    ap.add_argument("--fused2", action="store_true",
-                    help="both layers' forward in ONE launch (gcnpt_fused2_fwd, halo recompute, no inter-workgroup wait) instead of one launch "
-                         "per layer; same bits; measured slower on MI355X at this size (fwd 32 us against 18 us)")
-    ap.add_argument("--split-weight-grad", action="store_true",
-                    help="one weight-gradient launch per layer (right after that layer's backward-data) instead of one launch "
-                         "for all layers at the end of the backward sweep")
+    ap.add_argument("--no-riders", action="store_true",
+                    help="A/B: weight gradients in one launch of their own at the end of the backward sweep (gcnpt_set_option SIDE_TILES 0) "
+                         "instead of as passengers of the backward-data launches")
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="2 = run the tree build beside the weight pack on a side stream (only matters for with_prune / with_cached_trees); "
                          "measured slower on MI355X (85 -> 88 us with the pruner, 68 -> 82 with cached trees): parallel graph branches cost more than they hide")
@@ -73,12 +74,15 @@ def parse():
                     help="graph: the step's launches replayed as one hipGraph; native: eager launches from three native calls per step "
                          "(gcnpt_pack_weights_multi, gcnpt_layers_fwd, gcnpt_layers_bwd), which keeps the queue fed as long as the host is "
                          "fast enough; auto: both are tried during warm-up and the faster one is timed")
-    ap.add_argument("--exchange", choices=["auto", "overlap", "inline"], default="auto",
-                    help="N > 1: gradient all-reduce overlapped with the following steps on the communication stream, in line with the "
-                         "compute (synchronous call), or whichever a warm-up trial finds faster")
+    ap.add_argument("--exchange", choices=["sync", "async"], default="sync",
+                    help="N > 1.  sync (the headline): all-reduce, device-side SGD update, and the next step's pack waits for both. "
+                         "async: the round-2 ring of buckets whose all-reduce nobody consumes -- an upper bound, not data-parallel SGD")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
+    ap.add_argument("--no-floor", action="store_true", help="skip the launch-floor leg (the step's launches with empty bodies)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements on rank 0 (with_prune, with_cached_trees, the fp32 "
-                                                                "strict-parity block): quick runs and tests")
+                                                                "strict-parity block, pooling): quick runs and tests")
+    ap.add_argument("--no-secondary-shapes", action="store_true",
+                    help="skip the C5-shaped blocks (B=128, T=300, 600->300->300, K=2 on one GPU, padded and packed; its per-GPU shard of 8)")
     ap.add_argument("--separate-pack", action="store_true", help="A/B: keep the weight pack a launch of its own in the with_prune / "
                     "with_cached_trees steps instead of a side job of the tree launch")
     ap.add_argument("--no-pooled-only", action="store_true", help="skip the secondary pooled-only-rows measurement (profiling runs: its launches "
@@ -86,7 +90,19 @@ def parse():
     return ap.parse_args()
 
 
-N_BUCKETS = 4       # gradient buckets in flight for N > 1: the all-reduce of a bucket is long over when its turn comes again
+N_BUCKETS = 4       # async mode only: gradient buckets in flight
+
+
+def source_hash():
+    """Hash of the kernel sources: a PMC traffic recording is only quoted for the code it was made with."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "gcn-over-pruned-trees_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode())
+                h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 class Stack(object):
@@ -108,8 +124,14 @@ class Stack(object):
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
         self.head, self.subj, self.obj, self.deprel, self.masks = (t(tb[k]) for k in ("head", "subj_pos", "obj_pos", "deprel", "masks"))
         Ws, bs = synthetic.layer_params(seed + 1, [Din, H, H])
-        self.W = [t(w) for w in Ws]
-        self.b = [t(b) for b in bs]
+        # parameters as views of ONE flat fp32 tensor laid out like the gradient bucket [W0, b0, W1, b1]: the N > 1 update is one add_
+        self.n_grad = H * Din + H + H * H + H
+        self.wflat = torch.empty((self.n_grad,), dtype=torch.float32, device=dev)
+        o = [0, H * Din, H * Din + H, H * Din + H + H * H, self.n_grad]
+        self.W = [self.wflat[o[0]:o[1]].view(H, Din), self.wflat[o[2]:o[3]].view(H, H)]
+        self.b = [self.wflat[o[1]:o[2]], self.wflat[o[3]:o[4]]]
+        for dst, src in zip(self.W + self.b, list(Ws) + list(bs)):
+            dst.copy_(t(src))
         self.x = t(synthetic.normal(seed + 2, (B, T, Din))).to(act)
         self.gy = t(synthetic.normal(seed + 3, (B, T, H))).to(act)
         self.trees = tree.prune_to_csr(self.head, self.subj, self.obj, self.deprel, args.prune_k, masks=self.masks, want_label=False)
@@ -138,11 +160,10 @@ class Stack(object):
         dims = [(H, Din), (H, H)]
         self.wf = [torch.empty((self.L.gcnpt_packed_bytes(h, d, self.compute),), dtype=torch.uint8, device=dev) for h, d in dims]
         self.wb = [torch.empty((self.L.gcnpt_packed_bytes(d, h, self.compute),), dtype=torch.uint8, device=dev) for h, d in dims]
-        # saved operands in MFMA fragment order: S_l = (A+I)h_l written by fwd, dZ_l written by bwd_data
+        # saved operands in MFMA fragment order: S_l = (A+I)h_l written by fwd, dZ_l written by the backward sweep
         self.sf = [torch.empty((self.L.gcnpt_frag_bytes(R, d, self.compute),), dtype=torch.uint8, device=dev) for h, d in dims]
         self.zf = [torch.empty((self.L.gcnpt_frag_bytes(R, h, self.compute),), dtype=torch.uint8, device=dev) for h, d in dims]
-        # a ring of flat gradient buckets [dW0, db0, dW1, db1] so that the all-reduce of step i overlaps the following steps
-        self.n_grad = H * Din + H + H * H + H
+        # flat gradient buckets [dW0, db0, dW1, db1] (one; a ring of them in the async exchange mode)
         self.buckets = [torch.zeros((self.n_grad,), dtype=torch.float32, device=dev) for _ in range(N_BUCKETS)]
         # loader-side pre-pruning (N4): a "dataset" of 20 batches pruned once; a step then only gathers its batch's rows
         reps = 20
@@ -151,19 +172,11 @@ class Stack(object):
                                           masks=rep(self.masks), want_label=False)
         self.cache_idx = (torch.arange(B, device=dev) + B * (reps // 2)).to(torch.int64)
         self.scale = 1.0 / (1.0 - args.drop) if args.drop > 0 else 1.0
-        # big batches: scratch for the gather + matrix form of a layer (csrc/rowsplit_kernels.hip); 0 bytes below 16 384 rows
-        Bc, Tc = (self.rows, 0) if packed else (B, T)
-        nws = self.L.gcnpt_layers_workspace_bytes(2, Bc, Tc, (ctypes.c_int * 2)(Din, H), (ctypes.c_int * 2)(H, H), self.act)
-        self.ws = torch.empty((nws,), dtype=torch.uint8, device=dev) if nws else None
-        self.ws_n = nws
         self.side = torch.cuda.Stream(device=dev)
-        self.fused = args.fused and args.dtype == "bf16" and not pooled_only and not packed and bool(self.L.gcnpt_stack_supported(T, Din, H, 2, self.compute))
-        if self.fused:       # fragment images with per-sentence k-steps: layer inputs h_l (fwd) and G_l = (A+I)^T dZ_l (bwd)
-            fb = self.L.gcnpt_stack_frag_bytes
-            self.hf = [torch.empty((fb(B, T, d),), dtype=torch.uint8, device=dev) for h, d in dims]
-            self.gf = [torch.empty((fb(B, T, h),), dtype=torch.uint8, device=dev) for h, d in dims]
         if packed:
             self.B, self.T = self.rows, 0                   # what the C-ABI takes for packed rows (include/gcnpt.h, gcnpt_pack_trees)
+        # small batches: the weight gradients ride in the backward-data launches (gcnpt_layer_bwd_data_ex), the sweep is L launches
+        self.riders = (self.rows + 31) // 32 <= self.L.gcnpt_get_option(_lib.OPT_SIDE_TILES)
 
     def grads(self, k):
         H, Din = self.H, self.Din
@@ -171,7 +184,7 @@ class Stack(object):
         o = [0, H * Din, H * Din + H, H * Din + H + H * H]
         return f[o[0]:o[1]], f[o[1]:o[2]], f[o[2]:o[3]], f[o[3]:]
 
-    # ---- individual C-ABI calls (each only enqueues on the current stream) ----
+    # ---- tree launches (each only enqueues on the current stream) ----
     def prune(self, pack=False):
         """pack: the same launch also packs the weights (gcnpt_prune_to_csr_pack: side job on the CUs the tree build leaves idle)."""
         tr, P, st = self.trees, self._lib.ptr, self._lib.stream()
@@ -188,79 +201,6 @@ class Stack(object):
              P(tr.row_ptr), P(tr.col_idx), None, P(tr.rowT_ptr), P(tr.colT_idx), P(tr.ell), P(tr.ellT), P(tr.pool_mask), P(tr.status))
         self._lib.check(self.L.gcnpt_gather_trees_pack(*(a + self._native_args(0)[0])) if pack else self.L.gcnpt_gather_trees(*a))
 
-    def pack(self, l):
-        P = self._lib.ptr
-        H, Din = self.W[l].shape
-        self._lib.check(self.L.gcnpt_pack_weights(self._lib.stream(), P(self.W[l]), H, Din, self.compute, P(self.wf[l]), P(self.wb[l])))
-
-    def pack_all(self):
-        """Both layers' weights -> MFMA fragment order in ONE launch."""
-        n = len(self.W)
-        arr = lambda vals, ty: (ty * n)(*vals)  # noqa: E731
-        vp = ctypes.c_void_p
-        self._lib.check(self.L.gcnpt_pack_weights_multi(
-            self._lib.stream(), n, arr([w.data_ptr() for w in self.W], vp), arr([w.shape[0] for w in self.W], ctypes.c_int),
-            arr([w.shape[1] for w in self.W], ctypes.c_int), self.compute, arr([t.data_ptr() for t in self.wf], vp),
-            arr([t.data_ptr() for t in self.wb], vp)))
-
-    def fwd(self, l):
-        P, tr = self._lib.ptr, self.trees
-        src, dst = (self.x, self.h1) if l == 0 else (self.h1, self.h2)
-        H, Din = self.W[l].shape
-        p = self.args.drop if l == 0 else 0.0
-        self._lib.check(self.L.gcnpt_layer_fwd_ws(self._lib.stream(), P(src), self.act, P(self.wf[l]), P(self.b[l]), P(tr.row_ptr), P(tr.col_idx),
-                                                  P(tr.ell), None, self.B, self.T, Din, H, P(dst), self.act, self.compute, p, 0x5eed, P(self.sf[l]), None,
-                                                  P(self.ws), self.ws_n))
-
-    def _dw_db(self, l, k):
-        g = self.grads(k)
-        return (g[0], g[1]) if l == 0 else (g[2], g[3])
-
-    def bwd_data(self, l, k=0):
-        """dh, the dZ fragment image, and cleared dW/db accumulators for bwd_weight(l, k)."""
-        P, tr = self._lib.ptr, self.trees
-        dy, y, dst = (self.gy, self.h2, self.dh1) if l == 1 else (self.dh1, self.h1, self.dx)
-        H, Din = self.W[l].shape
-        sc = self.scale if l == 0 else 1.0
-        dW, db = self._dw_db(l, k)
-        # the hand-over gcnpt_layers_bwd uses: layer 1 leaves dZ of layer 0 in dh1 (it has h1's rows at hand), layer 0 takes it as is
-        relu, nsc, is_dz = (self.h1, self.scale, 0) if l == 1 else (None, 1.0, 1)
-        self._lib.check(self.L.gcnpt_layer_bwd_data_ws(self._lib.stream(), P(dy), P(y), self.act, P(self.wb[l]), P(tr.ell), P(tr.rowT_ptr),
-                                                       P(tr.colT_idx), P(tr.ellT), self.B, self.T, Din, H, P(dst), self.act, self.compute, sc,
-                                                       P(self.zf[l]), P(dW), P(db), P(relu), nsc, is_dz, P(self.ws), self.ws_n))
-
-    def bwd_data_wgrad(self, k=0):
-        """Layer 0's backward-data launch carrying layer 1's weight gradient on the CUs without a row tile (what gcnpt_layers_bwd does
-        for batches of up to 192 row tiles; bigger ones: two launches)."""
-        P, tr = self._lib.ptr, self.trees
-        H, Din = self.W[0].shape
-        H1, Din1 = self.W[1].shape
-        dW, db = self._dw_db(0, k)
-        dW1, db1 = self._dw_db(1, k)
-        self._lib.check(self.L.gcnpt_layer_bwd_data_wgrad(
-            self._lib.stream(), P(self.dh1), P(self.h1), self.act, P(self.wb[0]), P(tr.ell), P(tr.rowT_ptr), P(tr.colT_idx), P(tr.ellT), self.B,
-            self.T, Din, H, P(self.dx), self.act, self.compute, self.scale, P(self.zf[0]), P(dW), P(db), None, 1.0, 1,
-            P(self.zf[1]), P(self.sf[1]), Din1, H1, P(dW1), P(db1)))
-
-    def carries_wgrad(self):
-        return self.rows <= 192 * 32 and self.ws is None and not self.args.split_weight_grad
-
-    def bwd_weight(self, l, k=0):
-        P = self._lib.ptr
-        H, Din = self.W[l].shape
-        dW, db = self._dw_db(l, k)
-        self._lib.check(self.L.gcnpt_layer_bwd_weight(self._lib.stream(), P(self.zf[l]), P(self.sf[l]), self.B, self.T, Din, H,
-                                                      P(dW), P(db), self.compute))
-
-    def bwd_weight_all(self, k=0):
-        """Both layers' weight gradients in ONE launch (they only need the fragment images the sweep has left behind)."""
-        A, n = self._lib.ptr_array, len(self.W)
-        g = self.grads(k)
-        ints = lambda vals: (ctypes.c_int * n)(*vals)  # noqa: E731
-        self._lib.check(self.L.gcnpt_layer_bwd_weight_multi(
-            self._lib.stream(), n, A(self.zf), A(self.sf), self.B, self.T, ints([w.shape[1] for w in self.W]),
-            ints([w.shape[0] for w in self.W]), A([g[0], g[2]]), A([g[1], g[3]]), self.compute))
-
     # ---- the whole layer loop / backward sweep from one native call each (gcnpt_layers_fwd / gcnpt_layers_bwd) ----
     def _native_args(self, k):
         if not hasattr(self, "_nargs"):
@@ -273,33 +213,56 @@ class Stack(object):
             act = ints([self.act] * n)
             fwd = (n, P(self.x), self.act, A(self.wf), A(self.b), P(tr.row_ptr), P(tr.col_idx), P(tr.ell), None, self.B, self.T, Din, H,
                    A([self.h1, self.h2]), act, self.compute, (ctypes.c_float * n)(self.args.drop, 0.0), (ctypes.c_uint64 * n)(0x5eed, 0),
-                   A(self.sf), None, P(self.ws), self.ws_n)
+                   A(self.sf), None)
             bwd = (n, P(self.gy), A([self.h1, self.h2]), act, A(self.wb), P(tr.ell), P(tr.rowT_ptr), P(tr.colT_idx), P(tr.ellT), self.B, self.T,
                    Din, H, A([self.dx, self.dh1]), act, self.compute, (ctypes.c_float * n)(self.scale, 1.0), A(self.zf), A(self.sf),
-                   A([g[0], g[2]]), A([g[1], g[3]]), 0, P(self.ws), self.ws_n)
+                   A([g[0], g[2]]), A([g[1], g[3]]))
             vp = ctypes.c_void_p
             pack = (n, (vp * n)(*[w.data_ptr() for w in self.W]), H, Din, self.compute, A(self.wf), A(self.wb))
             self._nargs[k] = (pack, fwd, bwd)
         return self._nargs[k]
 
+    def launch_names(self):
+        """The launches of one step, in order (what gcnpt_layers_bwd enqueues follows csrc/rowtile_kernels.hip, layers_bwd_impl)."""
+        if self.riders:
+            return ["pack", "fwd0", "fwd1", "bwd_data1", "bwd_data0+wgrad1+wgrad0"]
+        return ["pack", "fwd0", "fwd1", "bwd_data1", "bwd_data0", "bwd_weight"]
+
     def step_native(self, k=0, with_prune=False):
         """One step as three native calls (pack, all forward layers, backward sweep + weight gradients): eager launches, no graph.
-        The argument lists are built once: the host has ~50 us per step for six launches and must not spend them marshalling."""
+        The argument lists are built once: the host has ~45 us per step for five launches and must not spend them marshalling."""
         pack, fwd, bwd = self._native_args(k)
         st = self._lib.stream()
-        merged = bool(with_prune) and not self.args.separate_pack and not self.args.fused2       # the tree launch carries the weight pack
+        merged = bool(with_prune) and not self.args.separate_pack       # the tree launch carries the weight pack
         if with_prune == "cached":
             self.gather(pack=merged)
         elif with_prune:
             self.prune(pack=merged)
         L = self.L
-        if self.args.fused2:                    # opt-in A/B: the step with the two-layer forward launch (eager launches from Python)
-            for _, call in self.calls(k):
-                call()
-            return
-        rc = (0 if merged else L.gcnpt_pack_weights_multi(st, *pack)) or L.gcnpt_layers_fwd_ws(st, *fwd) or L.gcnpt_layers_bwd_ws(st, *bwd)
+        rc = (0 if merged else L.gcnpt_pack_weights_multi(st, *pack)) or L.gcnpt_layers_fwd(st, *fwd) or L.gcnpt_layers_bwd(st, *bwd)
         if rc:
             self._lib.check(rc)
+
+    def step_prefix(self, n_launches, k=0):
+        """The first n_launches launches of the step, through the same native entry points (measurement: t(k) - t(k-1))."""
+        pack, fwd, bwd = self._native_args(k)
+        st, L, nl = self._lib.stream(), self.L, len(self.W)
+        rc = 0
+        if n_launches >= 1:
+            rc = L.gcnpt_pack_weights_multi(st, *pack)
+        nf = min(n_launches - 1, nl)
+        if rc == 0 and nf >= 1:
+            rc = L.gcnpt_layers_fwd(st, nf, *fwd[1:])
+        nb = n_launches - 1 - nl
+        if rc == 0 and nb >= 1:
+            rc = L.gcnpt_layers_bwd_range(st, *(bwd + (0, 0, nb)))
+        if rc:
+            self._lib.check(rc)
+
+    def last_launch(self):
+        v = [ctypes.c_int(0) for _ in range(4)]
+        self._lib.check(self.L.gcnpt_last_launch(*[ctypes.byref(x) for x in v]))
+        return tuple(x.value for x in v)
 
     def step_with_pooling(self, handover, k=0):
         """The step with its consumer inside (model/gcn.py:116-121): pack, layers forward, the three poolings, their backward, the backward
@@ -313,131 +276,62 @@ class Stack(object):
             self.amax = torch.empty((B, 3, H), dtype=torch.int32, device=self.dev)
             self.dtop = torch.empty_like(self.h2)
         tr = self.trees
-        bwd = (bwd[0], P(self.dtop)) + bwd[2:-3] + (1 if handover else 0,) + bwd[-2:]
-        rc = (L.gcnpt_pack_weights_multi(st, *pack) or L.gcnpt_layers_fwd_ws(st, *fwd)
+        bwd = (bwd[0], P(self.dtop)) + bwd[2:]
+        rc = (L.gcnpt_pack_weights_multi(st, *pack) or L.gcnpt_layers_fwd(st, *fwd)
               or L.gcnpt_pool3_fwd(st, P(self.h2), self.act, P(tr.pool_mask), P(self.subj), P(self.obj), self.B, self.T, self.H, 0, P(self.pooled),
                                    P(self.amax)))
         if rc == 0 and handover:
             rc = (L.gcnpt_pool3_bwd_dz(st, P(self.gpool), P(self.amax), P(tr.pool_mask), P(self.subj), P(self.obj), self.B, self.T, self.H, 0,
-                                       P(self.h2), P(tr.ell), 1.0, P(self.dtop), self.act) or L.gcnpt_layers_bwd_ws(st, *bwd))
+                                       P(self.h2), P(tr.ell), 1.0, P(self.dtop), self.act) or L.gcnpt_layers_bwd_dz(st, *bwd))
         elif rc == 0:
             rc = (L.gcnpt_pool3_bwd(st, P(self.gpool), P(self.amax), P(tr.pool_mask), P(self.subj), P(self.obj), self.B, self.T, self.H, 0,
-                                    P(self.dtop), self.act) or L.gcnpt_layers_bwd_ws(st, *bwd))
+                                    P(self.dtop), self.act) or L.gcnpt_layers_bwd(st, *bwd))
         if rc:
             self._lib.check(rc)
 
-    # ---- sentence-resident stack: every layer in one launch per direction ----
-    def stack_fwd(self, k=0):
-        P, A, tr, L = self._lib.ptr, self._lib.ptr_array, self.trees, 2
-        g = self.grads(k)
-        self._lib.check(self.L.gcnpt_stack_fwd(
-            self._lib.stream(), L, P(self.x), self.act, A(self.wf), A(self.b), P(tr.row_ptr), P(tr.col_idx), P(tr.ell), None,
-            self.B, self.T, self.Din, self.H, A([self.h1, self.h2]), self.act, (ctypes.c_float * L)(self.args.drop, 0.0),
-            (ctypes.c_uint64 * L)(0x5eed, 0), A(self.hf), A([g[0], g[2]]), A([g[1], g[3]]), None))
-
-    def stack_bwd(self, k=0):
-        P, A, tr, L = self._lib.ptr, self._lib.ptr_array, self.trees, 2
-        g = self.grads(k)
-        self._lib.check(self.L.gcnpt_stack_bwd(
-            self._lib.stream(), L, P(self.gy), A([self.h1, self.h2]), self.act, A(self.wb), P(tr.ell), P(tr.rowT_ptr), P(tr.colT_idx),
-            P(tr.ellT), self.B, self.T, self.Din, self.H, P(self.dx), self.act, (ctypes.c_float * L)(self.scale, 1.0), A(self.gf),
-            A([g[1], g[3]])))
-
-    def stack_bwd_weight(self, k=0):
-        A, L = self._lib.ptr_array, 2
-        g = self.grads(k)
-        self._lib.check(self.L.gcnpt_stack_bwd_weight(self._lib.stream(), L, A(self.gf), A(self.hf), self.B, self.T, self.Din, self.H,
-                                                      A([g[0], g[2]])))
-
-    def fwd_all(self):
-        """Both layers' forward in ONE launch (csrc/fused_kernels.hip, opt-in)."""
-        P, A, tr = self._lib.ptr, self._lib.ptr_array, self.trees
-        self._lib.check(self.L.gcnpt_fused2_fwd(
-            self._lib.stream(), P(self.x), A(self.wf), A(self.b), P(tr.row_ptr), P(tr.col_idx), P(tr.ell), None, self.B, self.T, self.Din,
-            (ctypes.c_int * 2)(self.H, self.H), P(self.h1), P(self.h2), self.act, (ctypes.c_float * 2)(self.args.drop, 0.0),
-            (ctypes.c_uint64 * 2)(0x5eed, 0), A(self.sf), None))
-
-    def two_layer_launches(self):
-        return (self.args.fused2 and not self.packed and len(self.W) == 2 and self.args.dtype == "bf16" and
-                bool(self.L.gcnpt_fused2_supported(self.T, self.Din, self.H, self.H, self.act, self.compute)))
-
-    def calls(self, k=0):
-        """The launches of one step, in order (name, callable)."""
-        if self.fused:
-            return [("pack", self.pack_all), ("stack_fwd", lambda: self.stack_fwd(k)), ("stack_bwd", lambda: self.stack_bwd(k)),
-                    ("stack_bwd_weight", lambda: self.stack_bwd_weight(k))]
-        if self.args.split_weight_grad:
-            return [("pack", self.pack_all), ("fwd0", lambda: self.fwd(0)), ("fwd1", lambda: self.fwd(1)),
-                    ("bwd_data1", lambda: self.bwd_data(1, k)), ("bwd_weight1", lambda: self.bwd_weight(1, k)),
-                    ("bwd_data0", lambda: self.bwd_data(0, k)), ("bwd_weight0", lambda: self.bwd_weight(0, k))]
-        if self.two_layer_launches():
-            return [("pack", self.pack_all), ("fwd", self.fwd_all), ("bwd_data1", lambda: self.bwd_data(1, k)),
-                    ("bwd_data0", lambda: self.bwd_data(0, k)), ("bwd_weight", lambda: self.bwd_weight_all(k))]
-        if self.carries_wgrad():
-            return [("pack", self.pack_all), ("fwd0", lambda: self.fwd(0)), ("fwd1", lambda: self.fwd(1)),
-                    ("bwd_data1", lambda: self.bwd_data(1, k)), ("bwd_data0+wgrad1", lambda: self.bwd_data_wgrad(k)),
-                    ("bwd_weight0", lambda: self.bwd_weight(0, k))]
-        return [("pack", self.pack_all), ("fwd0", lambda: self.fwd(0)), ("fwd1", lambda: self.fwd(1)),
-                ("bwd_data1", lambda: self.bwd_data(1, k)), ("bwd_data0", lambda: self.bwd_data(0, k)),
-                ("bwd_weight", lambda: self.bwd_weight_all(k))]
-
     def step(self, k=0, with_prune=False):
         """
-        One step.  With --streams 2 the tree build, which only needs the loader tensors, runs beside the weight pack on a
-        side stream (fork and join are inside the step, so they become parallel branches of the captured graph).
+        One step for hipGraph capture.  With --streams 2 the tree build, which only needs the loader tensors, runs beside the weight pack
+        on a side stream (fork and join are inside the step, so they become parallel branches of the captured graph).
         """
-        if self.args.streams == 1 or self.fused:
-            merged = bool(with_prune) and not self.args.separate_pack and not self.fused and not self.args.fused2
-            if with_prune == "cached":
-                self.gather(pack=merged)
-            elif with_prune:
-                self.prune(pack=merged)
-            for _, call in self.calls(k)[1 if merged else 0:]:
-                call()
+        if self.args.streams == 1 or not with_prune:
+            self.step_native(k, with_prune)
             return
         main = torch.cuda.current_stream()
         side = self.side
-        if with_prune:                                   # fork: the tree build beside the weight pack
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                self.gather() if with_prune == "cached" else self.prune()
-        calls = self.calls(k)
-        calls[0][1]()                                    # pack
-        if with_prune:
-            main.wait_stream(side)                       # join before the first layer
-        for _, call in calls[1:]:
-            call()
+        side.wait_stream(main)                           # fork: the tree build beside the weight pack
+        with torch.cuda.stream(side):
+            self.gather() if with_prune == "cached" else self.prune()
+        pack, fwd, bwd = self._native_args(k)
+        st, L = self._lib.stream(), self.L
+        self._lib.check(L.gcnpt_pack_weights_multi(st, *pack))
+        main.wait_stream(side)                           # join before the first layer
+        self._lib.check(L.gcnpt_layers_fwd(st, *fwd) or L.gcnpt_layers_bwd(st, *bwd))
 
-    # ---- algorithmic bytes per launch (DESIGN.md "Measurement"; SURVEY.md 8d) ----
+    # ---- bytes per launch (DESIGN.md "Measurement"; SURVEY.md 8d) ----
     def algorithmic_bytes(self):
+        """What THIS dataflow moves per launch (every input and output counted once, saved-operand images and packed weights included)."""
         e = 2 if self.args.dtype == "bf16" else 4
         N, B, T = self.rows, self.B, self.T
         csr = 32 * N            # one ELL head (count + 7 columns) per row; the CSR arrays are only touched by rows with > 7 entries
         out = {}
+        nl = len(self.W)
         for l, (H, Din) in enumerate([tuple(w.shape) for w in self.W]):
             wp = self.wf[l].numel()
             out["fwd%d" % l] = e * N * (Din + H) + wp + 4 * H + csr + self.sf[l].numel()
             # the top layer reads dY and Y, the layers below read the dZ the layer above left them; every layer but the bottom one
-            # also reads its input rows to leave dZ for the layer below (hand-over of gcnpt_layers_bwd)
-            top, bottom = l == len(self.W) - 1, l == 0
+            # also reads its input rows to leave dZ for the layer below (hand-over of gcnpt_layers_bwd) -- and, when the weight
+            # gradients ride, that dZ's fragment image; a layer writes its own dZ image only when no launch above did
+            top, bottom = l == nl - 1, l == 0
+            own_img = self.zf[l].numel() if (top or not self.riders) else 0
+            down_img = self.zf[l - 1].numel() if (self.riders and not bottom) else 0
             out["bwd_data%d" % l] = e * N * ((2 if top else 1) * H + (1 if bottom else 2) * Din) + self.wb[l].numel() + 2 * csr + \
-                self.zf[l].numel() + 4 * (H * Din + H)
+                own_img + down_img + 4 * (H * Din + H)
             out["bwd_weight%d" % l] = self.zf[l].numel() + self.sf[l].numel() + 4 * (H * Din + H)
             out["bwd_weight"] = out.get("bwd_weight", 0) + out["bwd_weight%d" % l]
-            if l == 1:
-                out["bwd_data0+wgrad1"] = out["bwd_data0"] + out["bwd_weight1"]
             out["pack"] = out.get("pack", 0) + 4 * H * Din + self.wf[l].numel() + self.wb[l].numel()
-        out["fwd"] = sum(out["fwd%d" % l] for l in range(len(self.W)))
-        out["bwd_data"] = sum(out["bwd_data%d" % l] for l in range(len(self.W)))
+        out["bwd_data0+wgrad1+wgrad0"] = out["bwd_data0"] + out["bwd_weight"]
         out["prune"] = 4 * 8 * N + N + 2 * (csr + 4 * B * (T + 1) + 4 * self.nnz) + N + 4 * (B + 1)
-        if self.fused:
-            (H, Din), grads = tuple(self.W[0].shape), 4 * self.n_grad
-            hf, gf = sum(t.numel() for t in self.hf), sum(t.numel() for t in self.gf)
-            # x in, h1 + h2 out, weights, bias, ELL, fragment images of the layer inputs, cleared accumulators
-            out["stack_fwd"] = e * N * (Din + 2 * H) + sum(t.numel() for t in self.wf) + 8 * H + csr + hf + grads
-            # gy, h2, h1 in, dx out, weights, ELL (both patterns), fragment images of G, bias gradients
-            out["stack_bwd"] = e * N * (3 * H + Din) + sum(t.numel() for t in self.wb) + 2 * csr + gf + 8 * H
-            out["stack_bwd_weight"] = hf + gf + 4 * (H * Din + H * H)
         return out
 
     def survey_bytes(self):
@@ -455,14 +349,14 @@ class Stack(object):
             per["bwd_weight%d" % l] = e * N * Din + 4 * Din * H + 4 * H
         L = len(self.W)
         per["bwd_weight"] = sum(per["bwd_weight%d" % l] for l in range(L))
-        if L > 1:
-            per["bwd_data0+wgrad1"] = per["bwd_data0"] + per["bwd_weight1"]
-        per["fwd"] = per["stack_fwd"] = sum(per["fwd%d" % l] for l in range(L))
-        per["bwd_data"] = per["stack_bwd"] = sum(per["bwd_data%d" % l] for l in range(L))
-        per["stack_bwd_weight"] = per["bwd_weight"]
+        per["bwd_data0+wgrad1+wgrad0"] = per["bwd_data0"] + per["bwd_weight"]
         per["pack"] = 0
         per["prune"] = 0
         return per
+
+    def survey_step_bytes(self):
+        sv = self.survey_bytes()
+        return sum(sv["fwd%d" % l] + sv["bwd_data%d" % l] + sv["bwd_weight%d" % l] for l in range(len(self.W)))
 
 
 def capture(fn, use_graph):
@@ -503,16 +397,17 @@ def timed(run, steps, warmup, barrier):
 
 def kernel_breakdown(stack, use_graph, rounds=100, reps=8):
     """
-    Duration of each kernel IN the step: the step is replayed truncated after its first k launches, HIP events around the
-    replays, and kernel k is charged t(k) - t(k-1).  Unlike timing a kernel alone back to back, this keeps the producer ->
-    consumer cache state of the real step (each kernel reads what the previous one wrote from other XCDs) and includes its
-    launch boundary.  One hipGraph holds `reps` copies of the truncated step (every launch of the step may be repeated: the
-    backward clears the accumulators the weight gradient adds into), so the 5 us a graph replay costs on the device is
-    spread over `reps` prefixes and the durations are those of back-to-back launches, as in the timed native-launch mode
-    and in the rocprofv3 summaries.  `prune` is timed as the step with the tree build minus the step without.
+    Duration of each launch IN the step: the step is replayed truncated after its first k launches (Stack.step_prefix: the same native
+    entry points, gcnpt_layers_bwd_range for the backward sweep), HIP events around the replays, and launch k is charged t(k) - t(k-1).
+    Unlike timing a kernel alone back to back, this keeps the producer -> consumer cache state of the real step (each kernel reads what
+    the previous one wrote from other XCDs) and includes its launch boundary.  One hipGraph holds `reps` copies of the truncated step
+    (every launch of the step may be repeated: the backward clears the accumulators the weight gradient adds into), so the 5 us a
+    graph replay costs on the device is spread over `reps` prefixes and the durations are those of back-to-back launches, as in the
+    timed native-launch mode and in the rocprofv3 summaries.  `prune` is timed as the step with the tree build minus the step without.
+    Also returns each launch's (grid, workgroup size, LDS bytes, kernel-argument bytes) for the launch-floor leg.
     """
-    calls = stack.calls(0)
-    stack.step()
+    names = stack.launch_names()
+    stack.step_native()
     torch.cuda.synchronize()
 
     def timed_replay(fn):
@@ -531,19 +426,35 @@ def kernel_breakdown(stack, use_graph, rounds=100, reps=8):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e-3 / (rounds * reps)
 
-    out, prev = {}, 0.0
-    for k in range(1, len(calls) + 1):
-        def prefix(k=k):
-            for _, c in calls[:k]:
-                c()
-        t = timed_replay(prefix)
-        out[calls[k - 1][0]] = max(t - prev, 1e-9)
+    out, shapes, prev = {}, [], 0.0
+    for k in range(1, len(names) + 1):
+        stack.step_prefix(k)
+        shapes.append(stack.last_launch())
+        t = timed_replay(lambda k=k: stack.step_prefix(k))
+        out[names[k - 1]] = max(t - prev, 1e-9)
         prev = t
     if stack.B * stack.T == stack.rows_full:      # (a pooled-only stack holds [B, Tc] trees: the pruner's arrays do not fit them)
-        out["prune"] = max(timed_replay(lambda: stack.step(0, with_prune=True)) - prev, 1e-9)
-    stack.step()          # leave consistent buffers behind
+        out["prune"] = max(timed_replay(lambda: stack.step_native(0, with_prune=True)) - prev, 1e-9)
+    stack.step_native()          # leave consistent buffers behind
     torch.cuda.synchronize()
-    return out
+    return out, shapes
+
+
+def launch_floor(stack, shapes, steps, launch):
+    """The step's launches -- same grids, workgroup sizes, LDS and kernel-argument sizes -- with bodies that return at entry, timed in
+    the same loop as the step (native: eager launches back to back; graph: one replay per step).  What is left of ms_per_step after
+    subtracting this floor is kernel work (one workgroup's dependent chain per launch)."""
+    L, lib = stack.L, stack._lib
+
+    def empty_step():
+        st = lib.stream()
+        for g, b, lds, ka in shapes:
+            rc = L.gcnpt_launch_empty(st, g, b, lds, ka)
+            if rc:
+                lib.check(rc)
+    run, _ = capture(empty_step, launch == "graph")
+    wall, _ = timed(lambda i: run(), steps, 50, lambda: None)
+    return wall / steps
 
 
 def cpu_baseline(args, seconds):
@@ -602,16 +513,57 @@ def cpu_baseline(args, seconds):
                                 note="oracle/gcn_ref.py, explicit NumPy/BLAS backward (round 1's baseline)"))
 
 
+def secondary_shapes(args, dev, seed, steps=150):
+    """BASELINE.json configs[4]'s shape on ONE GPU, driver-timed: B=128, T=300, 600 -> 300 -> 300, prune_k 2, bf16 -- padded with
+    full-length sentences (the SURVEY 8(d) byte count applies: fraction of the HBM peak over the whole step), token-packed with
+    TACRED-shaped lengths (north_star "packed"), and the per-GPU shard of an 8-way split (B=16), with and without its tree build."""
+    out = {}
+
+    def run_one(a, packed=False, with_prune=False):
+        s = Stack(a, dev, seed=seed, packed=packed)
+        fn = (lambda: s.step_native(0, with_prune)) if with_prune else s.step_native
+        fn()
+        torch.cuda.synchronize()
+        wall, _ = timed(lambda i: fn(), steps, 20, lambda: None)
+        t = wall / steps
+        r = {"ms_per_step": t * 1e3, "sentences_per_s": a.batch / t, "rows": s.rows, "steps": steps,
+             "survey_8d_bytes": s.survey_step_bytes(), "frac_of_hbm_peak_8d": s.survey_step_bytes() / t / 1e9 / HBM_PEAK_GBS,
+             "launches": ", ".join(s.launch_names())}
+        del s
+        torch.cuda.empty_cache()
+        return r
+
+    a = copy.copy(args)
+    a.batch, a.seq, a.din, a.hidden, a.prune_k, a.dtype, a.lengths = 128, 300, 600, 300, 2, "bf16", "full"
+    out["c5_shape"] = {"workload": "B=128 T=300 600->300->300 prune_k=2 bf16, one GPU",
+                       "padded_full_length": run_one(a)}
+    a2 = copy.copy(a)
+    a2.lengths = "tacred"
+    out["c5_shape"]["padded_tacred_lengths"] = run_one(a2)
+    out["c5_shape"]["packed_tacred_lengths"] = run_one(a2, packed=True)
+    a3 = copy.copy(a)
+    a3.batch = 16
+    shard = {"workload": "B=16 T=300 600->300->300 prune_k=2 bf16: one rank's share of configs[4] split 8 ways",
+             "layers_only": run_one(a3), "with_prune": run_one(a3, with_prune=True), "with_cached_trees": run_one(a3, with_prune="cached")}
+    shard["prune_us"] = (shard["with_prune"]["ms_per_step"] - shard["layers_only"]["ms_per_step"]) * 1e3
+    out["per_gpu_shard_of_8"] = shard
+    a4 = copy.copy(args)
+    a4.batch, a4.lengths, a4.dtype = 1024, "full", "bf16"
+    out["b1024_c2_widths"] = run_one(a4)
+    return out
+
+
 def self_launch(args):
     """
     `python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): start N fresh rank processes, one per
     GPU, BEFORE anything in this process touches the GPU (this parent never does: it only waits), and relay rank 0's single
     JSON line.  The children are this same script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, exactly what
-    `python -m torch.distributed.run --nproc-per-node N` would give them.  A rank that fails ends the others and the run
-    exits non-zero; nothing is restarted.
+    `python -m torch.distributed.run --nproc-per-node N` would give them.  ALL children are polled: the first one that exits
+    non-zero ends the others (by handle) and the run exits non-zero; nothing is restarted.
     """
     import socket
     import subprocess
+    import threading
     n = args.gpus
     one_dev = bool(os.environ.get("GCNPT_BENCH_ONE_DEVICE"))
     have = torch.cuda.device_count()                # counting devices does not initialise the GPU on this image
@@ -629,13 +581,26 @@ def self_launch(args):
         env.setdefault("OMP_NUM_THREADS", "4")
         out = subprocess.PIPE if r == 0 else sys.stderr           # only rank 0 owns the JSON line
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
-    line0, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for pr in procs[1:]:
-        if rc != 0 and pr.poll() is None:
-            pr.kill()                                               # by handle: these are exactly the processes started above
-        rc = pr.wait() or rc
-    text = line0.decode("utf-8", "replace") if line0 else ""
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad:
+            rc = bad[0]
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()                                        # by handle: these are exactly the processes started above
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.05)
+    for p in procs:
+        p.wait()
+    reader.join(timeout=10)
+    text = (chunks[0] if chunks else b"").decode("utf-8", "replace")
     lines = [ln for ln in text.splitlines() if ln.startswith("{")]
     if rc != 0 or len(lines) != 1:
         sys.stderr.write(text)
@@ -657,7 +622,7 @@ def main():
         if rank == 0:
             print("[bench] --gpus %d but WORLD_SIZE %d: they must agree" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
-    force_dist = bool(os.environ.get("GCNPT_BENCH_FORCE_DIST"))      # rehearsal: the N > 1 code path (RCCL init, overlapped all-reduce) with one rank
+    force_dist = bool(os.environ.get("GCNPT_BENCH_FORCE_DIST"))      # rehearsal: the N > 1 code path (RCCL init, all-reduce, update) with one rank
     saved_stdout = None
     if world > 1 or force_dist:
         # RCCL prints a version banner on stdout (C stdio) when the communicator is created; the contract is ONE JSON line on
@@ -681,6 +646,9 @@ def main():
         barrier = lambda: None  # noqa: E731
     dev = torch.device("cuda", local if world > 1 else 0)
     use_graph = not args.no_graph
+    from gcn_over_pruned_trees_amd import _lib
+    if args.no_riders:
+        _lib.set_option(_lib.OPT_SIDE_TILES, 0)
 
     # every rank draws its own shard of the global batch; GCNPT_BENCH_SAME_SHARD=1 (tests) gives all ranks rank 0's shard, so that
     # the all-reduced bucket must be exactly world x the one-rank bucket
@@ -688,10 +656,8 @@ def main():
     stack = Stack(args, dev, seed=shard_seed, packed=args.layout == "packed")
     from gcn_over_pruned_trees_amd.shard import OverlappedAllReduce
 
-    # ---- the timed step: layer stack fwd+bwd (+ overlapped gradient all-reduce when N > 1)
     multi = world > 1 or force_dist
-    # SUM, not AVG: the 1/world factor belongs to the optimizer's learning rate, and SUM is supported by every backend
-    reducer = OverlappedAllReduce(stack.buckets, dist, average=False) if multi else None
+    w0 = stack.wflat.clone()                                         # N > 1: the weights every trial / the timed region starts from
 
     def runner(mode, with_prune=False, n_buckets=1):
         """[(callable, is_graph)] per gradient bucket for a launch mode."""
@@ -703,46 +669,54 @@ def main():
             return fns
         return [capture(lambda k=k: stack.step(k, with_prune=with_prune), use_graph) for k in range(n_buckets)]
 
-    def make_run(replays, exchange="overlap"):
-        """A step + (N > 1) the all-reduce of the bucket it wrote.  exchange "overlap": asynchronous, on the communication stream,
-        beside the following steps (ring of buckets); "inline": a synchronous all_reduce, in line with the compute."""
-        def run(i):
-            k = i % N_BUCKETS if multi else 0
-            if reducer and exchange == "overlap":
-                reducer.before_write(k)
+    def make_run(replays, exchange, reducer=None):
+        """A step (+ for N > 1 the gradient exchange).  sync: the bucket is all-reduced on the compute stream's order (a synchronous
+        all_reduce: the collective's latency is in line with the step) and W -= lr * g (SUM over ranks / world) is applied on the device;
+        the next step's pack reads W, so step i+1 depends on all-reduce i: synchronous data-parallel SGD, as the reference's
+        per-step update (train.py:224-227).  async: ring of buckets, asynchronous all-reduce nobody consumes (upper bound)."""
+        def run_sync(i):
+            replays[0][0]()
+            dist.all_reduce(stack.buckets[0])                       # SUM: supported by every backend; the 1/world goes into the step size
+            stack.wflat.add_(stack.buckets[0], alpha=-SGD_LR / world)
+
+        def run_async(i):
+            k = i % N_BUCKETS
+            reducer.before_write(k)
             replays[k][0]()
-            if reducer:
-                if exchange == "overlap":
-                    reducer.after_write(k)
-                else:
-                    dist.all_reduce(stack.buckets[k])
-        return run
+            reducer.after_write(k)
+
+        def run_single(i):
+            replays[0][0]()
+        return run_single if not multi else (run_sync if exchange == "sync" else run_async)
+
+    modes = ["graph"] if args.launch == "graph" else (["native"] if args.launch == "native" else ["graph", "native"])
+    exchange = args.exchange if multi else None
+    nb = N_BUCKETS if (multi and exchange == "async") else 1
+    cands = {m: runner(m, n_buckets=nb) for m in modes}
+    reducer = OverlappedAllReduce(stack.buckets, dist, average=False) if (multi and exchange == "async") else None
 
     def drain():
         if reducer:
             reducer.finish()
         torch.cuda.synchronize()
 
-    modes = ["graph"] if (stack.fused or args.launch == "graph") else (["native"] if args.launch == "native" else ["graph", "native"])
-    cands = {m: runner(m, n_buckets=N_BUCKETS if multi else 1) for m in modes}
-    exchanges = (["overlap", "inline"] if args.exchange == "auto" else [args.exchange]) if multi else ["overlap"]
-    combos = [(m, x) for m in modes for x in exchanges]
-    (launch, exchange), trial = combos[0], {}
-    if len(combos) > 1:
-        # part of the warm-up: a short trial of each launch mode (and, for N > 1, of each way to run the exchange); every rank
-        # must take the same one: MAX over ranks decides
-        for m, x in combos:
-            w, _ = timed(make_run(cands[m], x), 200, 20, barrier)
+    launch, trial = modes[0], {}
+    if len(modes) > 1:
+        # part of the warm-up: a short trial of each launch mode; every rank must take the same one: MAX over ranks decides
+        for m in modes:
+            stack.wflat.copy_(w0)
+            w, _ = timed(make_run(cands[m], exchange, reducer), 200, 20, barrier)
             drain()
             if multi:
                 tm = torch.tensor([w], dtype=torch.float64, device=dev)
                 dist.all_reduce(tm, op=dist.ReduceOp.MAX)
                 w = float(tm.item())
-            trial[m + ("/" + x if multi else "")] = w / 200
-        launch, exchange = min(combos, key=lambda c: trial[c[0] + ("/" + c[1] if multi else "")])
+            trial[m] = w / 200
+        launch = min(modes, key=lambda m: trial[m])
     replays = cands[launch]
     graphed = replays[0][1]
-    wall, ev = timed(make_run(replays, exchange), args.steps, args.warmup, barrier)
+    stack.wflat.copy_(w0)
+    wall, ev = timed(make_run(replays, exchange, reducer), args.steps, args.warmup, barrier)
     drain()
     rank_ms = [wall / args.steps * 1e3]
     if multi:
@@ -751,10 +725,34 @@ def main():
         dist.all_gather(every, mine)
         rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
         wall = max(float(t.item()) for t in every)                 # contract: MAX over ranks
-    assert torch.isfinite(stack.buckets[0]).all() and torch.isfinite(stack.dx.float()).all()
-    # the bucket the LAST timed step wrote, after its all-reduce (drain() above): rank-sum of [dW0, db0, dW1, db1]
-    last_bucket = stack.buckets[(args.steps - 1) % N_BUCKETS if multi else 0]
+    assert torch.isfinite(stack.buckets[0]).all() and torch.isfinite(stack.dx.float()).all() and torch.isfinite(stack.wflat).all()
+    # the bucket the LAST timed step wrote, after its all-reduce: rank-sum of [dW0, db0, dW1, db1]
+    last_bucket = stack.buckets[(args.steps - 1) % N_BUCKETS if (multi and exchange == "async") else 0]
     grad_abs_sum = float(last_bucket.double().abs().sum().item())
+    weight_drift = float((stack.wflat - w0).double().abs().sum().item())      # > 0 iff the SGD updates were applied (N > 1, sync)
+
+    async_bound = None
+    if multi and exchange == "sync":
+        # labelled secondary: the free-running ring (not synchronous SGD)
+        stack.wflat.copy_(w0)
+        ring = OverlappedAllReduce(stack.buckets, dist, average=False)
+        fns = runner(launch, n_buckets=N_BUCKETS)
+
+        def run_ring(i):
+            k = i % N_BUCKETS
+            ring.before_write(k)
+            fns[k][0]()
+            ring.after_write(k)
+        n_a = min(args.steps, 400)
+        w_a, _ = timed(run_ring, n_a, 20, barrier)
+        ring.finish()
+        torch.cuda.synchronize()
+        tm = torch.tensor([w_a], dtype=torch.float64, device=dev)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        async_bound = {"ms_per_step": float(tm.item()) / n_a * 1e3, "value": args.batch * world * n_a / float(tm.item()), "steps": n_a,
+                       "note": "NOT synchronous SGD: ring of %d buckets, the all-reduce of step i runs beside steps i+1.. and nothing consumes "
+                               "it; what the exchange could hide at best" % N_BUCKETS}
+    stack.wflat.copy_(w0)
 
     result = None
     if rank == 0:
@@ -767,6 +765,7 @@ def main():
             wall_p, _ = timed(lambda i: run_p(), args.steps, min(args.warmup, 50), lambda: None)
             run_c = runner(launch, with_prune="cached")[0][0]
             wall_c, _ = timed(lambda i: run_c(), args.steps, min(args.warmup, 50), lambda: None)
+        names = stack.launch_names()
         result = {
             "metric": "GCN-layer fwd+bwd sentences/sec at batch=50 seq=100 h=200",
             "value": sent / wall, "unit": "sentences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -781,17 +780,17 @@ def main():
                        "ranks_started_by": ("bench.py itself (--gpus N without a launcher)" if os.environ.get("GCNPT_BENCH_SELF_LAUNCHED")
                                             else "torch.distributed.run / caller") if world > 1 else None,
                        "ms_per_step_by_rank": [round(t, 6) for t in rank_ms], "grad_bucket_abs_sum": grad_abs_sum,
-                       "launch": "hipGraph replay" if graphed else ("eager launches from 3 native calls per step (pack, gcnpt_layers_fwd_ws, gcnpt_layers_bwd_ws)"
-                                                                     if launch == "native" else "eager"),
-                       "layer_form": ("gather + matrix launch per layer and direction (csrc/rowsplit_kernels.hip, %d B workspace)" % stack.ws_n) if stack.ws_n and not stack.fused
-                                     else "one row-tile launch per layer and direction",
-                       "allreduce_stream_waits": reducer.stream_waits if reducer else None,
+                       "launch": "hipGraph replay" if graphed else "eager launches from 3 native calls per step (gcnpt_pack_weights_multi, gcnpt_layers_fwd, gcnpt_layers_bwd)",
+                       "kernels_per_step": ", ".join(names),
                        "launch_trial_us_per_step": {m: round(t * 1e6, 2) for m, t in trial.items()} or None, "nnz_per_batch": stack.nnz,
-                       "grad_allreduce": ("flat fp32 bucket %d B per step over RCCL, " % (4 * stack.n_grad)) +
-                                         ("overlapped with the following steps (ring of %d buckets)" % N_BUCKETS if exchange == "overlap"
-                                          else "synchronous, in line with the compute") if world > 1 else "none (1 GPU)"},
+                       "dp_mode": ("synchronous SGD: step -> all_reduce(SUM) of the flat fp32 bucket (%d B) over %s -> W -= lr*g/world on the device -> "
+                                   "the next step's weight pack reads W" % (4 * stack.n_grad, args.dist_backend)) if (multi and exchange == "sync")
+                                  else ("ASYNC RING (not synchronous SGD; --exchange async)" if multi else "none (1 GPU)"),
+                       "weight_abs_drift_after_timed_steps": weight_drift if multi else None},
             "event_ms_per_step": ev / args.steps * 1e3,
         }
+        if async_bound is not None:
+            result["async_upper_bound"] = async_bound
         if not args.no_secondary:
             result["with_prune"] = {"value": args.batch * args.steps / wall_p, "unit": "sentences/s", "ms_per_step": wall_p / args.steps * 1e3,
                                     "note": "rank 0, pruned-tree adjacency build inside every step; the tree launch carries the weight pack as a "
@@ -801,7 +800,6 @@ def main():
                                                    "pack rides in the same launch)"}
             if args.dtype == "bf16":
                 # the reference's own arithmetic: fp32 activations, exact fp32 MFMA (the strict-parity mode of the tests), same step
-                import copy
                 a32 = copy.copy(args)
                 a32.dtype = "fp32"
                 s32 = Stack(a32, dev, seed=shard_seed)
@@ -817,7 +815,7 @@ def main():
                                   "steps": n32, "note": "rank 0, same step with fp32 activations and exact fp32 MFMA (v_mfma_f32_16x16x4_f32): the "
                                                         "reference's own arithmetic, the mode the 1e-5 / 1e-4 parity tests run in"}
                 del s32
-        if not stack.fused and not args.no_secondary and args.layout == "padded":
+        if not args.no_secondary and args.layout == "padded":
             # the step with the reference's consumer in it (max pooling x3, gcn.py:116-121), with and without the dZ hand-over
             wp = {}
             for name, ho in (("two_ops", False), ("handover", True)):
@@ -834,7 +832,7 @@ def main():
                                       "note": "rank 0, the step plus the consumer's three max poolings forward and backward (gcnpt_pool3_fwd / _bwd); "
                                               "handover: the pooling's backward writes dZ of the top layer (gcnpt_pool3_bwd_dz, gcnpt_layers_bwd_dz), "
                                               "which then gathers one row per neighbour instead of dY, Y and the degree"}
-        if not stack.fused and not args.no_pooled_only and args.layout == "padded" and args.lengths == "tacred":
+        if not args.no_pooled_only and args.layout == "padded" and args.lengths == "tacred":
             sp = Stack(args, dev, seed=shard_seed, packed=True)
             if launch == "native":
                 run_q = sp.step_native
@@ -849,7 +847,7 @@ def main():
                 "note": "rank 0, the same step on token-packed rows (gcnpt_pack_trees: sum(len) rows, no padding slots); every real token's "
                         "row is bit-identical to the padded batch's"}
             del sp
-        if not stack.fused and not args.no_pooled_only and args.layout == "padded":
+        if not args.no_pooled_only and args.layout == "padded":
             sc = Stack(args, dev, seed=shard_seed, pooled_only=True)
             if launch == "native":
                 run_k = sc.step_native
@@ -867,13 +865,12 @@ def main():
             del sc
         alg = stack.algorithmic_bytes()
         if not args.no_kernel_breakdown:
-            kt = kernel_breakdown(stack, use_graph)
+            kt, shapes = kernel_breakdown(stack, use_graph)
             step_keys = [k for k in kt if k != "prune"]
-            result["config"]["kernels_per_step"] = ", ".join(k for k, _ in stack.calls(0))
             dom = max(step_keys, key=lambda k: kt[k])
             sv = stack.survey_bytes()
             # HBM-side bytes per launch from separate rocprofv3 --pmc passes (tools/profile_round.sh): only quoted when that recording was
-            # made for THIS shape / dtype / launch list (its "meta"), otherwise null -- a replayed number for another workload is no evidence
+            # made for THIS shape / dtype / launch list AND these kernel sources (hash of csrc/*.hip, *.h), otherwise null
             traffic, traffic_src = None, None
             tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tf):
@@ -881,10 +878,11 @@ def main():
                     rec = json.load(f)
                 meta = rec.get("meta", {})
                 here = dict(batch=args.batch, seq=args.seq, din=args.din, hidden=args.hidden, prune_k=args.prune_k, dtype=args.dtype,
-                            lengths=args.lengths, kernels=[k for k, _ in stack.calls(0)])
+                            lengths=args.lengths, kernels=names, source_hash=source_hash())
                 if all(meta.get(k) == v for k, v in here.items()):
                     traffic = rec.get("traffic", {}).get(dom)
-                    traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload at git %s, 2*FETCH+WRITE)" % meta.get("git_sha", "?")
+                    traffic_src = ("profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload and these kernel "
+                                   "sources, hash %s, 2*FETCH+WRITE)" % meta.get("source_hash"))
             gbs = sv[dom] / kt[dom] / 1e9
             result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                   "traffic": traffic, "traffic_source": traffic_src,
@@ -903,6 +901,18 @@ def main():
                                        "dataflow_bytes": tot_b, "dataflow_frac_of_hbm_peak": tot_b / sum(kt[k] for k in step_keys) / 1e9 / HBM_PEAK_GBS,
                                        "note": "survey_8d_bytes = SURVEY.md 8(d)'s formula for the layer math alone (S recomputed, no saved images, no pack), "
                                                "over the WHOLE timed step (ms_per_step); dataflow_bytes = what this implementation moves, over the summed kernel times"}
+            if not args.no_floor and world == 1:
+                floor = launch_floor(stack, shapes, min(args.steps, 2000), launch)
+                result["launch_floor_us"] = floor * 1e6
+                result["chain_us"] = (wall / args.steps - floor) * 1e6
+                result["launch_floor"] = {"launches": [{"name": n, "grid": s[0], "block": s[1], "lds_bytes": s[2], "kernarg_bytes": s[3]}
+                                                       for n, s in zip(names, shapes)],
+                                          "per_launch_us": floor * 1e6 / len(shapes),
+                                          "note": "the step's %d launches with the same grid / workgroup size / LDS / kernel-argument size and bodies that return "
+                                                  "at entry (gcnpt_launch_empty), timed in the same %s loop as the step; chain_us = ms_per_step - launch_floor_us "
+                                                  "is what the kernels' own work adds" % (len(shapes), "hipGraph" if graphed else "native eager-launch")}
+        if not args.no_secondary_shapes and world == 1 and args.layout == "padded":
+            result["secondary_shapes"] = secondary_shapes(args, dev, shard_seed)
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         sys.stdout.flush()

@@ -9,7 +9,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GCNPT_LIB") or os.path.join(_HERE, "csrc", "libgcnpt.so")   # GCNPT_LIB: diagnostic builds
 
 F32, BF16 = 0, 1
-ABI_VERSION = 5            # GCNPT_ABI_VERSION of the include/gcnpt.h this binding was written against
+ABI_VERSION = 6            # GCNPT_ABI_VERSION of the include/gcnpt.h this binding was written against
+OPT_DETERMINISTIC, OPT_FOUR_WAVES, OPT_SIDE_TILES = 0, 1, 2      # gcnpt_set_option keys (include/gcnpt.h)
 OK, E_INVALID, E_PRUNE_NEGATIVE, E_NO_SUBJECT, E_NO_LCA, E_CYCLE, E_BAD_HEAD, E_ASSERT, E_CAPACITY, E_HIP, E_UNSUPPORTED, E_LENGTH = \
     0, -1, -2, -3, -4, -5, -6, -7, -8, -9, -10, -11
 
@@ -27,19 +28,17 @@ SIGNATURES = {
     "gcnpt_pack_weights_multi": (_i, [_p, _i, _p, _p, _p, _i, _p, _p]),
     "gcnpt_frag_bytes": (_sz, [_i, _i, _i]),
     "gcnpt_layer_fwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _f, _u64, _p, _p]),
-    "gcnpt_layer_fwd_ws": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _f, _u64, _p, _p] + [_p, _sz]),
     "gcnpt_layer_bwd_data": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _f, _p, _p, _p, _p, _f, _i]),
-    "gcnpt_layer_bwd_data_wgrad": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _f, _p, _p, _p, _p, _f, _i] + [_p, _p, _i, _i, _p, _p]),
-    "gcnpt_layer_bwd_data_ws": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _f, _p, _p, _p, _p, _f, _i] + [_p, _sz]),
+    "gcnpt_layer_bwd_data_ex": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _f, _p, _p, _p, _p, _f, _i] + [_p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "gcnpt_layers_bwd_range": (_i, [_p, _i] + [_p] * 8 + [_i, _i] + [_p] * 4 + [_i] + [_p] * 5 + [_i, _i, _i]),
+    "gcnpt_set_option": (_i, [_i, _i]),
+    "gcnpt_get_option": (_i, [_i]),
+    "gcnpt_last_launch": (_i, [_p, _p, _p, _p]),
+    "gcnpt_launch_empty": (_i, [_p, _i, _i, _i, _i]),
     "gcnpt_layer_bwd_weight": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _i]),
     "gcnpt_layer_bwd_weight_multi": (_i, [_p, _i, _p, _p, _i, _i, _p, _p, _p, _p, _i]),
     "gcnpt_layers_fwd": (_i, [_p, _i, _p, _i] + [_p] * 6 + [_i, _i] + [_p] * 4 + [_i] + [_p] * 4),
     "gcnpt_layers_bwd": (_i, [_p, _i] + [_p] * 8 + [_i, _i] + [_p] * 4 + [_i] + [_p] * 5),
-    "gcnpt_layers_workspace_bytes": (_sz, [_i, _i, _i, _p, _p, _i]),
-    "gcnpt_layers_fwd_ws": (_i, [_p, _i, _p, _i] + [_p] * 6 + [_i, _i] + [_p] * 4 + [_i] + [_p] * 4 + [_p, _sz]),
-    "gcnpt_layers_bwd_ws": (_i, [_p, _i] + [_p] * 8 + [_i, _i] + [_p] * 4 + [_i] + [_p] * 5 + [_i, _p, _sz]),
-    "gcnpt_fused2_supported": (_i, [_i] * 6),
-    "gcnpt_fused2_fwd": (_i, [_p] * 8 + [_i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p]),
     "gcnpt_pack_trees": (_i, [_p] * 10 + [_i, _i, _i] + [_p] * 10 + [_i, _i, _p]),
     "gcnpt_pack_rows": (_i, [_p, _p, _i, _p, _i, _i, _i, _p]),
     "gcnpt_unpack_rows": (_i, [_p, _p, _i, _p, _i, _i, _i, _p]),
@@ -64,11 +63,6 @@ SIGNATURES = {
     "gcnpt_bilinear_de_planes": (_i, [_i, _i, _i, _i]),
     "gcnpt_bilinear_bwd_e": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "gcnpt_bilinear_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
-    "gcnpt_stack_supported": (_i, [_i, _i, _i, _i, _i]),
-    "gcnpt_stack_frag_bytes": (_sz, [_i, _i, _i]),
-    "gcnpt_stack_fwd": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p]),
-    "gcnpt_stack_bwd": (_i, [_p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p]),
-    "gcnpt_stack_bwd_weight": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _p]),
 }
 
 
@@ -97,6 +91,13 @@ def lib():
             raise ImportError("libgcnpt.so has ABI version %d, this binding needs %d" % (handle.gcnpt_abi_version(), ABI_VERSION))
         _lib = handle
     return _lib
+
+
+def set_option(key, value):
+    """Process-wide option of the library (include/gcnpt.h, GCNPT_OPT_*); returns the previous value."""
+    old = lib().gcnpt_get_option(key)
+    check(lib().gcnpt_set_option(key, int(value)))
+    return old
 
 
 def check(rc):

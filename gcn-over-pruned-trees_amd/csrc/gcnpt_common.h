@@ -15,7 +15,7 @@ char* err_buf();   // thread-local, defined in capi.hip
 extern int g_debug_knob;      // diagnostic builds: timing-experiment switches (results become wrong)
 extern void* g_debug_stamps;   // diagnostic builds (-DGCNPT_STAMPS): device buffer for in-kernel time stamps
 #else
-// the shipped library has no mutable global state (include/gcnpt.h): the diagnostic hooks are compile-time constants here
+// the shipped library keeps no mutable global state but the option table of gcnpt_set_option: the diagnostic hooks are compile-time constants here
 constexpr int g_debug_knob = 0;
 constexpr void* g_debug_stamps = nullptr;
 #endif
@@ -43,6 +43,8 @@ constexpr void* g_debug_stamps = nullptr;
 #define GCNPT_STAMP_REAL(buf) do {} while (0)
 #endif
 int fail(int code, const char* fmt, ...);
+void note_launch(int grid, int block, size_t lds, size_t kernarg);      // thread-local record for gcnpt_last_launch (capi.hip)
+int option(int key);      // GCNPT_OPT_* of include/gcnpt.h (capi.hip): one relaxed atomic load, no environment access
 
 #define GCNPT_HIP_CHECK(expr)                                                                  \
     do {                                                                                       \

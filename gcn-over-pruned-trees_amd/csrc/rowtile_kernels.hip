@@ -15,630 +15,26 @@
 //   (4) the epilogue runs on the accumulators, the result is staged through LDS and leaves as
 //       whole rows in 16-byte stores.
 // The dense [B,T,T] bmm of the reference (gcn.py:269) never exists: aggregation is a gather.
-#include "layer_common.h"
-#include "wgrad_common.h"
-
-// the kernel's big outputs (rows, fragment images): plain stores, or -DGCNPT_NT_STORES=1 non-temporal ones (experiment: does leaving
-// less dirty data in the L2s shorten the launch boundary?  see DESIGN.md section 5)
-#if defined(GCNPT_NT_STORES) && GCNPT_NT_STORES
-template <typename V> __device__ __forceinline__ void gcnpt_out_store(V* p, const V& v) {
-    if constexpr (sizeof(V) == 16) {
-        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(p));
-    } else {
-        typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-        __builtin_nontemporal_store(__builtin_bit_cast(u32x2, v), reinterpret_cast<u32x2*>(p));
-    }
-}
-#define GCNPT_NT(ptr, val) gcnpt_out_store(ptr, val)
-#else
-#define GCNPT_NT_STORES 0
-#define GCNPT_NT(ptr, val) (*(ptr) = (val))
-#endif
-#define GCNPT_PLAIN(ptr, val) (*(ptr) = (val))
-// level 1: everything; 2: rows + the forward's S image (the dZ image is read by the very next launches); 3: rows only; 4: images only
-#define GCNPT_ROW_STORE(ptr, val) do { if (GCNPT_NT_STORES >= 1 && GCNPT_NT_STORES <= 3) GCNPT_NT(ptr, val); else GCNPT_PLAIN(ptr, val); } while (0)
-#define GCNPT_FRAG_STORE(bwd, ptr, val) do { if (GCNPT_NT_STORES == 1 || GCNPT_NT_STORES == 4 || (GCNPT_NT_STORES == 2 && !(bwd))) GCNPT_NT(ptr, val); else GCNPT_PLAIN(ptr, val); } while (0)
-
-namespace gcnpt {
-
-constexpr int ROWS = 32;             // token rows per workgroup (two 16-row MFMA tiles)
-constexpr int RT_THREADS = 512;      // 8 waves; wave w owns output tiles w, w+8, ...
-constexpr int RT_WAVES = RT_THREADS / WAVE;
-static_assert(RT_THREADS == 16 * ROWS, "the row store loop gives every row 16 threads (two rounds in the 4-wave form)");
-constexpr int NB_INLINE = 7;         // neighbours per row that the ELL head carries (include/gcnpt.h)
-#ifndef GCNPT_W_EARLY_NUM
-#define GCNPT_W_EARLY_NUM 1          // quarters of a wave's weight fragments requested before the adjacency is known (0..4 measured: 1 is best)
-#endif
-
-struct RowTileParams {
-    const void* src;        // fwd: h [N,K]      bwd: dY [N,K]
-    const void* yref;       // bwd: Y [N,K] (stored layer output)
-    const void* wfrag;      // packed B operand, gcnpt_pack_weights
-    const float* bias;      // fwd: [NOUT]
-    const int32_t* g_row_ptr;   // pattern gathered over (fwd: A, bwd: A^T): CSR, only read for rows with > 7 entries
-    const int32_t* g_col_idx;
-    const int32_t* g_ell;       // its ELL head: [8r] = entries of row r, [8r+1..8r+7] = first columns
-    const int32_t* d_ell;       // ELL head whose [8r] gives deg (always the forward pattern A)
-    void* out;              // [N,NOUT]; NULL = only the side outputs below are wanted
-    void* frag_out;         // NULL or fragment image (include/gcnpt.h) of the tile: fwd S = (A+I)h, bwd dZ
-    float* zero_a;          // NULL or accumulators to clear for the kernel that follows (bwd: dW, db)
-    float* zero_b;
-    int zero_a_n, zero_b_n;
-    int N, T, K, NOUT, Kpad;
-    unsigned chunk_magic;   // ceil(2^32 / (Kpad / 8)): division by the chunks per row as a multiply-high
-    int vec_in, vec_out;    // vec_in: 8 / 4 / 0 elements per row load (selects the VEC instantiation); vec_out: 16 / 8 / 0 bytes per row store
-    float scale;            // bwd: 1/(1-p) of the dropout applied to Y; fwd: 1/(1-drop_p)
-    float drop_p;           // fwd
-    unsigned drop_thresh16;
-    uint64_t seed;
-    const uint64_t* seed_dev;   // NULL, or a device word added to `seed` (a counter the caller advances between graph replays)
-    const void* relu_src;       // bwd: NULL, or this layer's INPUT rows [N,NOUT] (the stored output of the layer below): the result then
-    float next_scale;           //      leaves as that layer's dZ = dh * 1[input > 0] * next_scale / (deg + 1) instead of dh
-    unsigned long long* stamps;   // diagnostic builds only
-    int knob;
-};
-
-// DZIN (bwd only): `src` already holds dZ (the layer above wrote it, see relu_src), so the row loader is the forward's plain
-// gather -- one load per neighbour instead of three (dY, Y, degree).
-// (a device function: the launch of its own below, and the backward launch that also carries a weight gradient, share it; block_id /
-// n_blocks: this workgroup's tile number and the number of tiles, which that launch does not read off blockIdx / gridDim)
-// NWV: waves per workgroup.  8 for the headline batches (one workgroup per CU, the shortest chain); 4 for big batches, where two
-// workgroups share a CU (same registers per wave, half the waves each) and one's memory waits overlap the other's arithmetic.
-template <typename CT, typename IT, typename OT, bool BWD, int VEC, int NTW, int KSMAX, bool DZIN = false, int NWV = 8>
-__device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int block_id, const int n_blocks, unsigned char* smem_raw) {
-    constexpr int RTT = NWV * WAVE, RTW = NWV;                  // threads and waves of this workgroup
-    static_assert(BWD || !DZIN, "DZIN is a backward mode");
-    constexpr bool MASKED = BWD && !DZIN;                       // the loader computes dZ = dY * 1[Y>0] * scale / (deg+1) itself
-    constexpr int KSTEP = sizeof(CT) == 2 ? 32 : 16;            // K consumed per fragment
-    constexpr bool WIDE = MASKED && sizeof(IT) == 4;            // two fp32 streams per row: fewer rows in flight per thread
-    constexpr int ITEMS = WIDE ? 2 : 3;                         // 8-element chunks a thread gathers per batch
-    constexpr int NBU = WIDE ? 2 : 4;                           // neighbour rows fetched together
-    const int stride = lds_stride_dw(p.Kpad * (int)sizeof(CT) / 4) * 4 / (int)sizeof(CT);     // S row stride, CT elements
-    const int ncols_pass = RTW * NTW * 16;
-    const int ostride = out_stride_dw(min(round_up(p.NOUT, 16), ncols_pass) * (int)sizeof(OT) / 4) * 4 / (int)sizeof(OT);
-    const size_t s_bytes = (size_t)ROWS * stride * sizeof(CT);
-    CT* S = reinterpret_cast<CT*>(smem_raw);
-    // bwd: Z (the tile's own dZ rows, before aggregation) is only read by the fragment-image emission, the out tile O only
-    // written from the epilogue on: they share one region, with a barrier between the two uses
-    const size_t o_bytes = (size_t)ROWS * ostride * sizeof(OT);
-    const size_t zo_bytes = BWD ? (s_bytes > o_bytes ? s_bytes : o_bytes) : o_bytes;
-    CT* Z = reinterpret_cast<CT*>(smem_raw + s_bytes);
-    OT* O = reinterpret_cast<OT*>(smem_raw + s_bytes);
-    int* meta = reinterpret_cast<int*>(smem_raw + s_bytes + zo_bytes);
-    int* rell = meta;                         // [ROWS][8] ELL heads of the tile's rows (count, 7 sentence-local columns)
-    float* rinv = reinterpret_cast<float*>(meta + 8 * ROWS);   // [ROWS] fwd: 1/(deg+1)   bwd: scale/(deg+1)
-    float* rden = reinterpret_cast<float*>(meta + 9 * ROWS);   // [ROWS] deg+1
-    int* glist = meta + 10 * ROWS;            // [ROWS] tile rows that aggregate at least one entry, compacted
-    int* rsb = meta + 11 * ROWS;              // [ROWS] first row of the row's sentence (b * T)
-    int* gcount = meta + 12 * ROWS;           // [1] the number of entries of glist
-    float* sbias = reinterpret_cast<float*>(meta + 13 * ROWS);   // [max(RTT, columns of a pass)] fwd: the bias of this pass's columns
-
-    // `wave` through readfirstlane: the compiler then knows it is uniform and does every wave-dependent address in SALU
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one), each with its own L2, and a row's neighbours
-    // sit in its own sentence, i.e. in the adjacent tiles: XCD x takes a CONTIGUOUS run of tiles, so that the neighbour rows a tile
-    // gathers are rows the same L2 serves to the tiles next to it (speed only; any placement gives the same values)
-    const int xg = block_id & 7, xq = n_blocks >> 3, xr = n_blocks & 7;
-    const int tile_id = xg * xq + min(xg, xr) + (block_id >> 3);
-    const int r0 = tile_id * ROWS;
-    const IT* src = static_cast<const IT*>(p.src);
-    const IT* yref = static_cast<const IT*>(p.yref);
-    const uint4* wfrag = static_cast<const uint4*>(p.wfrag);
-    const int n_tiles = ceil_div(p.NOUT, 16);
-    const int ksteps = p.Kpad / KSTEP;
-    uint64_t seed_off = 0;                                  // scalar load, consumed in the epilogue
-    if (!BWD && p.seed_dev) seed_off = *p.seed_dev;
-    GCNPT_STAMP_REAL(p.stamps);
-    GCNPT_STAMP(p.stamps, 0);
-
-    // (1) the tile's adjacency: the 32 ELL heads (1 KiB) and the degrees for the denominators.  EVERY wave loads all of
-    //     them (64 lanes x 16 bytes; waves 1..7 hit wave 0's lines) and keeps its own copy of the derived tables: the load
-    //     is unconditional and first in the queue, and no wave waits for another one before it can start gathering.
-    const int erow = lane >> 1, ehalf = lane & 1;
-    const size_t er = (size_t)min(r0 + erow, p.N - 1);
-    const int4 ell_v = reinterpret_cast<const int4*>(p.g_ell)[er * 2 + ehalf];
-    const int deg_v = p.d_ell[er * 8];                                                   // gcn.py:261
-    const int sb_v = p.T ? (int)er / p.T * p.T : 0;   // the one division by T, done while the loads are on their way (T = 0: packed rows, columns are absolute)
-    float bias_v = 0.0f;                           // fwd: one bias element per thread, parked in LDS with the heads (registers are
-    if constexpr (!BWD) bias_v = p.bias[min(tid, p.NOUT - 1)];      // too scarce to carry 4 per tile through the whole kernel)
-    float bias_w = 0.0f;                           // (4 waves x 5 tiles: 320 columns per pass, a second element for the first 64 threads)
-    if constexpr (!BWD && RTW * NTW * 16 > RTT) bias_w = p.bias[min(RTT + tid, p.NOUT - 1)];
-
-    // own rows of the first batch (everyone)
-    const int nchunk = p.Kpad / 8;
-    auto div_chunk = [&](int x) { return (int)__umulhi((unsigned)x, p.chunk_magic); };    // x / nchunk, exact for x * nchunk < 2^32
-    const int n_items = ROWS * nchunk;
-    // VEC: 8 = rows read 16 bytes at a time (K % 8 == 0), 4 = in 8-byte (bf16) / 16-byte (f32) halves (K % 4 == 0), 0 = element loads
-    const int kmax8 = VEC == 8 ? p.K - 8 : (VEC == 4 ? p.K - 4 : p.K - 1);
-    auto ld8 = [&](const IT* base, size_t row, int k0c, raw8<IT>& dst) {
-        if constexpr (VEC == 8) issue8<IT, true>(base, row, p.K, k0c, dst);
-        else if constexpr (VEC == 4) issue8_half<IT>(base, row, p.K, k0c, dst);
-        else issue8<IT, false>(base, row, p.K, k0c, dst);
-    };
-    raw8<IT> self[ITEMS], selfy[ITEMS];
-    auto issue_self = [&](int batch) {
-#pragma unroll
-        for (int u = 0; u < ITEMS; ++u) {
-            const int it = (batch * ITEMS + u) * RTT + tid;
-            const int row = div_chunk(it), k0 = (it - row * nchunk) * 8;
-            const size_t r = (size_t)min(r0 + row, p.N - 1);
-            ld8(src, r, min(k0, kmax8), self[u]);
-            if (MASKED) ld8(yref, r, min(k0, kmax8), selfy[u]);
-        }
-    };
-    issue_self(0);
-
-    // (0) this wave's weight fragments.  The vector-memory counter retires IN ORDER: whatever is issued before the
-    //     neighbour loads of step (2) has to land before they can be consumed.  So only the first KS_EARLY k-steps go
-    //     out now (they drain while the ELL heads are on their way); the rest follows the neighbour loads.
-    constexpr int KS_EARLY = KSMAX * GCNPT_W_EARLY_NUM / 4;
-    uint4 wreg[KSMAX][NTW];
-    auto load_w = [&](int pass, int kc0, int ks_lo, int ks_hi) {
-#pragma unroll
-        for (int ks = 0; ks < KSMAX; ++ks)
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) {
-                if (ks < ks_lo || ks >= ks_hi) continue;                    // compile-time after unrolling
-                const int tl = min(pass * RTW * NTW + j * RTW + wave, n_tiles - 1);
-                const int kk = min(kc0 + ks, ksteps - 1);
-#ifdef GCNPT_STAMPS
-                if (p.knob & 1) { wreg[ks][j] = wfrag[lane]; continue; }          // experiment: no weight traffic
-#endif
-                wreg[ks][j] = wfrag[((size_t)tl * ksteps + kk) * 64 + lane];
-#ifdef GCNPT_STAMPS
-                if (p.knob & 16) {      // experiment (VERDICT item 2b by proxy): twice the weight bytes through the CU, as an fp32 source would need
-                    const uint4 extra = wfrag[((size_t)(n_tiles - 1 - tl) * ksteps + (ksteps - 1 - kk)) * 64 + lane];
-                    asm volatile("" ::"v"(extra.x), "v"(extra.y), "v"(extra.z), "v"(extra.w));
-                }
-#endif
-            }
-    };
-    // (The MFMAs run with swapped operands, weights as A, so a lane ends up with 4 CONSECUTIVE output columns of one row:
-    // columns 16 tile + 4 (lane>>4) + g.)
-    load_w(0, 0, 0, KS_EARLY);              // unconditional even when only the side outputs are wanted: a branch here would
-                                            // make every later wait assume the shorter queue
-
-    // park the heads in LDS and compact the rows that aggregate anything (a pruned tree keeps ~1 token in 8).  All
-    // waves write the same values to the same places; each reads back only after its own writes (wave_lds_fence).
-    {
-        const bool first = ehalf == 0;
-        const int e0 = (first && r0 + erow >= p.N) ? 0 : ell_v.x;                    // rows past the end aggregate nothing
-        reinterpret_cast<int4*>(rell)[erow * 2 + ehalf] = make_int4(e0, ell_v.y, ell_v.z, ell_v.w);
-        const float dn = (float)(deg_v + 1);
-        rsb[erow] = sb_v;
-        if constexpr (!BWD) {
-            sbias[tid] = bias_v;
-            if constexpr (RTW * NTW * 16 > RTT) { if (tid < RTW * NTW * 16 - RTT) sbias[RTT + tid] = bias_w; }
-        }
-        rinv[erow] = (BWD ? p.scale : 1.0f) / dn;       // both lanes of a row write it: a use under `first` only would let
-        rden[erow] = dn;                                // hipcc sink the degree load into that branch, behind a full wait
-        const bool agg = first && e0 > 0 && p.out != nullptr;
-        const unsigned long long m = __ballot(agg);
-        if (agg) glist[__popcll(m & ((1ull << lane) - 1ull))] = erow;
-        if (lane == 0) *gcount = __popcll(m);
-    }
-    GCNPT_STAMP(p.stamps, 1);
-    wave_lds_fence();
-    GCNPT_STAMP(p.stamps, 2);
-
-    // (2) gcn.py:269 as a gather, S[row,:] = x[row,:] + sum_{c in pattern row} x[c,:], in two maps that share one barrier:
-    //   (2a) rows that aggregate something, compacted: item gi = (list slot, 8-column chunk), so the ~4 such rows of a
-    //        tile spread over ALL waves and their neighbour loads (<= NBU per round; a pruned-tree row has 3-4 entries)
-    //        leave in ONE round trip per item.  The first 7 neighbours come from the ELL head in LDS, the (rare) rest
-    //        from col_idx; lanes without an e-th neighbour load their own row and drop it.
-    //   (2b) every other row is a plain copy of the loads issued at the top.
-    struct GItem { raw8<IT> s, sy, nb[NBU], nby[NBU]; int dcnt[NBU]; };
-    const int n_g = *gcount * nchunk;
-    auto g_decode = [&](int gi, int& row, int& k0, int& n) {
-        const bool has = gi < n_g;
-        const int li = has ? div_chunk(gi) : 0;
-        row = has ? glist[li] : 0;
-        k0 = has ? (gi - li * nchunk) * 8 : 0;
-        n = (has && k0 < p.K) ? rell[row * 8] : 0;
-        return has;
-    };
-    auto g_issue = [&](int gi, GItem& g) {
-        int row, k0, n;
-        g_decode(gi, row, k0, n);
-        const size_t r = (size_t)min(r0 + row, p.N - 1);
-        const int sbase = rsb[row];                                    // first row of this row's sentence
-        const int k0c = min(k0, kmax8);
-        ld8(src, r, k0c, g.s);
-        if (MASKED) ld8(yref, r, k0c, g.sy);
-#pragma unroll
-        for (int e = 0; e < NBU; ++e) {
-            // no e-th neighbour: the first 16 bytes of the tile's first row, one cache line for all such lanes.  (NOT the
-            // item's own row: hipcc would then reuse the load above, wait for it, and branch around the others.)
-            const bool on = e < min(n, NB_INLINE);
-            const size_t c = on ? (size_t)(sbase + rell[row * 8 + 1 + e]) : (size_t)r0;
-            const int kc = on ? k0c : 0;
-            ld8(src, c, kc, g.nb[e]);
-            if (MASKED) {
-                ld8(yref, c, kc, g.nby[e]);
-                g.dcnt[e] = p.d_ell[c * 8];
-            }
-        }
-    };
-    auto g_finish = [&](int gi, const GItem& g) {
-        int row, k0, n;
-        const bool has = g_decode(gi, row, k0, n);
-        const bool live = has && k0 < p.K;
-        const size_t rc = (size_t)min(r0 + row, p.N - 1);
-        const int sbase = rsb[row];
-        const int k0c = min(k0, kmax8);
-        float acc[8];
-        unpack8<IT>(g.s, live, acc);                                    // the explicit W(h) term, gcn.py:271
-        if (MASKED) {
-            float y[8];
-            unpack8<IT>(g.sy, live, y);
-            const float inv = rinv[row];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = (y[j] > 0.0f) ? acc[j] * inv : 0.0f;
-        }
-        const int n_ell = min(n, NB_INLINE);
-#pragma unroll
-        for (int e = 0; e < NBU; ++e) {
-            const bool on = e < n_ell;
-            float v[8];
-            unpack8<IT>(g.nb[e], on, v);
-            if (MASKED) {
-                float y[8];
-                unpack8<IT>(g.nby[e], on, y);
-                const float ninv = p.scale / (float)(g.dcnt[e] + 1);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] += (y[j] > 0.0f) ? v[j] * ninv : 0.0f;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] += v[j];
-            }
-        }
-        // rows with more than NBU entries (branching tree nodes, dense adjacency input): further round trips
-        auto round = [&](int e0, int lim, auto from_lds) {
-            raw8<IT> nb[NBU], nby[NBU];
-            float ninv[NBU];
-#pragma unroll
-            for (int e = 0; e < NBU; ++e) {
-                const bool on = e0 + e < lim;
-                size_t c;
-                if constexpr (decltype(from_lds)::value) {
-                    c = (size_t)(sbase + rell[row * 8 + 1 + min(e0 + e, NB_INLINE - 1)]);
-                } else {                                            // > 7 entries: continue in the CSR
-                    const int beg = p.T ? p.g_row_ptr[(size_t)(sbase / p.T) * (p.T + 1) + (rc - sbase)] : p.g_row_ptr[rc];
-                    c = (size_t)(sbase + p.g_col_idx[on ? beg + e0 + e : beg]);
-                }
-                c = on ? c : rc;
-                ld8(src, c, k0c, nb[e]);
-                if (MASKED) {
-                    ld8(yref, c, k0c, nby[e]);
-                    ninv[e] = p.scale / (float)(p.d_ell[c * 8] + 1);
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < NBU; ++e) {
-                const bool on = e0 + e < lim;
-                float v[8];
-                unpack8<IT>(nb[e], on, v);
-                if (MASKED) {
-                    float y[8];
-                    unpack8<IT>(nby[e], on, y);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[j] += (y[j] > 0.0f) ? v[j] * ninv[e] : 0.0f;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[j] += v[j];
-                }
-            }
-        };
-        for (int e0 = NBU; e0 < n_ell; e0 += NBU) round(e0, n_ell, std::true_type{});
-        for (int e0 = NB_INLINE; e0 < n; e0 += NBU) round(e0, n, std::false_type{});
-        if (has) tile<CT>::put8(S + (size_t)row * stride + k0, acc);
-    };
-
-    GItem g0;
-    g_issue(tid, g0);
-    load_w(0, 0, KS_EARLY, KSMAX);                              // 156 KB per workgroup at Din=360, H=200
-    GCNPT_STAMP(p.stamps, 3);
-
-    // (2b)
-    const int n_batches = ceil_div(n_items, ITEMS * RTT);
-    auto copy_batch = [&](int batch) {
-#pragma unroll
-        for (int u = 0; u < ITEMS; ++u) {
-            const int it = (batch * ITEMS + u) * RTT + tid;
-            if (it >= n_items) continue;
-            const int row = div_chunk(it), k0 = (it - row * nchunk) * 8;
-            const bool live = r0 + row < p.N && k0 < p.K;
-            if constexpr (!BWD && sizeof(IT) == 2 && sizeof(CT) == 2) {     // bf16 rows into a bf16 tile: the 16 bytes as they are
-                if (!(p.out && rell[row * 8] > 0))
-                    *reinterpret_cast<uint4*>(S + (size_t)row * stride + k0) = live ? self[u].a : make_uint4(0, 0, 0, 0);
-                continue;
-            }
-            float acc[8];
-            unpack8<IT>(self[u], live, acc);                            // the explicit W(h) term, gcn.py:271
-            if (MASKED) {
-                float y[8];
-                unpack8<IT>(selfy[u], live, y);
-                const float inv = rinv[row];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = (y[j] > 0.0f) ? acc[j] * inv : 0.0f;
-            }
-            if (BWD) {
-                if (p.frag_out) tile<CT>::put8(Z + (size_t)row * stride + k0, acc);
-            }
-            if (!(p.out && rell[row * 8] > 0)) tile<CT>::put8(S + (size_t)row * stride + k0, acc);   // else: (2a) writes it
-        }
-    };
-    copy_batch(0);
-    GCNPT_STAMP(p.stamps, 4);
-    // (2a) -- only the waves that own an item: the sums cost a wave ~120 VALU instructions whether its lanes are live or not
-    if (wave * WAVE < n_g) g_finish(tid, g0);
-    for (int base = RTT; base < n_g; base += RTT) {      // tiles with more than 512 / (K/8) aggregating rows
-        GItem g;
-        g_issue(base + tid, g);
-        g_finish(base + tid, g);
-    }
-    for (int batch = 1; batch < n_batches; ++batch) {                  // K > 384: the tile's own rows take several batches
-        issue_self(batch);
-        copy_batch(batch);
-    }
-    GCNPT_STAMP(p.stamps, 5);
-    __syncthreads();
-    GCNPT_STAMP(p.stamps, 6);
-
-    // side outputs: the tile in MFMA fragment order for the weight gradient (rows are its contraction index),
-    // and cleared accumulators for the kernel that follows
-    if (p.frag_out) {
-        uint4* F = static_cast<uint4*>(p.frag_out);
-        const CT* X = BWD ? Z : S;
-        const int w_tiles = ceil_div(p.K, 16);
-        if constexpr (sizeof(CT) == 2) {
-            const int i = lane & 15, g = lane >> 4, q4 = i >> 2, pp = i & 3;
-            const size_t nks = n_blocks;
-            for (int t = wave; t < w_tiles; t += RTW) {
-                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4_t*)(X + (size_t)(8 * g + q4) * stride + 16 * t + 4 * pp));
-                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4_t*)(X + (size_t)(8 * g + 4 + q4) * stride + 16 * t + 4 * pp));
-                uint4 u;
-                u.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
-                u.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
-                u.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
-                u.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
-                GCNPT_FRAG_STORE(BWD, &F[((size_t)t * nks + tile_id) * 64 + lane], u);
-            }
-        } else {
-            const int i = lane & 15, g = lane >> 4;
-            const size_t nks = (size_t)n_blocks * 2;
-            for (int tk = wave; tk < w_tiles * 2; tk += RTW) {
-                const int t = tk >> 1, kk = tk & 1;
-                uint4 u;
-                u.x = __float_as_uint(X[(size_t)(16 * kk + 4 * g + 0) * stride + 16 * t + i]);
-                u.y = __float_as_uint(X[(size_t)(16 * kk + 4 * g + 1) * stride + 16 * t + i]);
-                u.z = __float_as_uint(X[(size_t)(16 * kk + 4 * g + 2) * stride + 16 * t + i]);
-                u.w = __float_as_uint(X[(size_t)(16 * kk + 4 * g + 3) * stride + 16 * t + i]);
-                GCNPT_FRAG_STORE(BWD, &F[((size_t)t * nks + 2 * tile_id + kk) * 64 + lane], u);
-            }
-        }
-    }
-    if constexpr (BWD) {
-        if (p.frag_out) __syncthreads();                         // every wave has read its share of Z: the region becomes O
-    }
-    if (p.zero_a)
-        for (int i = block_id * RTT + tid; i < p.zero_a_n; i += n_blocks * RTT) p.zero_a[i] = 0.0f;
-    if (p.zero_b)
-        for (int i = block_id * RTT + tid; i < p.zero_b_n; i += n_blocks * RTT) p.zero_b[i] = 0.0f;
-    GCNPT_STAMP(p.stamps, 7);
-    if (!p.out) return;
-
-    // (3) + (4)
-    OT* out = static_cast<OT*>(p.out);
-    const int arow = lane & 15, kgrp = lane >> 4;
-    const int n_pass = ceil_div(n_tiles, RTW * NTW);
-
-    for (int pass = 0; pass < n_pass; ++pass) {
-        f32x4_t acc[2][NTW];
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) { acc[0][j] = (f32x4_t){0, 0, 0, 0}; acc[1][j] = (f32x4_t){0, 0, 0, 0}; }
-        const int tile0 = pass * RTW * NTW + wave;
-
-        for (int kc0 = 0; kc0 < ksteps; kc0 += KSMAX) {
-            if (pass > 0 || kc0 > 0) load_w(pass, kc0, 0, KSMAX);
-            // A fragments are read one k-step ahead of the MFMAs that use them
-            constexpr int AW = sizeof(CT) == 2 ? 8 : 4;                  // CT elements per lane per k-step (16 bytes)
-            uint4 a_cur[2], a_nxt[2];
-            auto read_a = [&](int kk, uint4 (&dst)[2]) {
-                dst[0] = *reinterpret_cast<const uint4*>(S + (size_t)arow * stride + kk * KSTEP + kgrp * AW);
-                dst[1] = *reinterpret_cast<const uint4*>(S + (size_t)(arow + 16) * stride + kk * KSTEP + kgrp * AW);
-            };
-            read_a(kc0, a_cur);
-#pragma unroll
-            for (int ks = 0; ks < KSMAX; ++ks) {
-                if (kc0 + ks < ksteps) {                                 // wave-uniform, no global load inside
-                    read_a(min(kc0 + ks + 1, ksteps - 1), a_nxt);
-#pragma unroll
-                    for (int j = 0; j < NTW; ++j) {
-                        if constexpr (sizeof(CT) == 2) {
-                            const bf16x8_t bq = __builtin_bit_cast(bf16x8_t, wreg[ks][j]);
-                            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq, __builtin_bit_cast(bf16x8_t, a_cur[0]), acc[0][j], 0, 0, 0);
-                            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq, __builtin_bit_cast(bf16x8_t, a_cur[1]), acc[1][j], 0, 0, 0);
-                        } else {
-                            const f32x4_t bq = __builtin_bit_cast(f32x4_t, wreg[ks][j]);
-                            const f32x4_t a0 = __builtin_bit_cast(f32x4_t, a_cur[0]), a1 = __builtin_bit_cast(f32x4_t, a_cur[1]);
-#pragma unroll
-                            for (int s = 0; s < 4; ++s) {
-                                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[s], a0[s], acc[0][j], 0, 0, 0);
-                                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[s], a1[s], acc[1][j], 0, 0, 0);
-                            }
-                        }
-                    }
-                    a_cur[0] = a_nxt[0]; a_cur[1] = a_nxt[1];
-                }
-            }
-        }
-
-        GCNPT_STAMP(p.stamps, 8);
-        // epilogue on the accumulators -> LDS out tile (tiles past the last real one hold duplicates: not stored).
-        // Lane (i = lane & 15, q = lane >> 4) holds, per 16x16 tile, row i and the 4 consecutive columns 4q..4q+3.
-        if (pass > 0) {
-            __syncthreads();                                             // previous pass's rows have left O
-            if constexpr (!BWD) {                                        // (NOUT > 512 only) this pass's bias
-                for (int c = tid; c < ncols_pass; c += RTT) sbias[c] = p.bias[min(pass * ncols_pass + c, p.NOUT - 1)];
-                __syncthreads();
-            }
-        }
-        float den[2], inv[2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) { den[mt] = rden[mt * 16 + (lane & 15)]; inv[mt] = rinv[mt * 16 + (lane & 15)]; }
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) {
-            const int tl = tile0 + j * RTW;
-            if (tl >= n_tiles) continue;
-            const int col0 = tl * 16 + (lane >> 4) * 4;
-            const int lcol0 = col0 - pass * ncols_pass;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const int row = mt * 16 + (lane & 15);
-                float v[4];
-                float bq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                if constexpr (!BWD) {
-                    const float4 bv = *reinterpret_cast<const float4*>(sbias + lcol0);
-                    bq[0] = bv.x; bq[1] = bv.y; bq[2] = bv.z; bq[3] = bv.w;
-                }
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float x = acc[mt][j][g];
-                    if (!BWD) {
-                        x = div_by(x + 2.0f * bq[g], den[mt], inv[mt]);   // gcn.py:270-271 (the bias enters twice), 390
-                        x = x > 0.0f ? x : 0.0f;                         // gcn.py:392
-                    }
-                    v[g] = x;
-                }
-                if (!BWD && p.drop_p > 0.0f) {                            // gcn.py:393: one hash per column pair
-#pragma unroll
-                    for (int h2 = 0; h2 < 2; ++h2) {
-                        const unsigned dh = drop_hash(p.seed + seed_off, (unsigned)(r0 + row), (unsigned)(col0 >> 1) + h2);
-                        v[2 * h2] = drop_keep(dh, 0u, p.drop_thresh16) ? v[2 * h2] * p.scale : 0.0f;
-                        v[2 * h2 + 1] = drop_keep(dh, 1u, p.drop_thresh16) ? v[2 * h2 + 1] * p.scale : 0.0f;
-                    }
-                }
-                OT* dst = O + (size_t)row * ostride + lcol0;
-                if constexpr (sizeof(OT) == 2) {
-                    uint2 pk;
-                    pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-                    pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-                    *reinterpret_cast<uint2*>(dst) = pk;
-                } else {
-                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                }
-            }
-        }
-        __syncthreads();
-        GCNPT_STAMP(p.stamps, 9);
-
-        // whole rows leave in 16-byte pieces (8-byte ones when the row width only allows those: bf16 rows of 300 columns)
-        const int c_lo = pass * ncols_pass, c_hi = min(p.NOUT, c_lo + ncols_pass);
-        const int width = c_hi - c_lo;
-        const OT* relu = BWD ? static_cast<const OT*>(p.relu_src) : nullptr;
-        auto store_rows = [&](auto vtag) {
-            using V = decltype(vtag);                                       // uint4 or uint2
-            constexpr int PER = (int)sizeof(V) / (int)sizeof(OT);
-            constexpr int NW = (int)sizeof(V) / 4;
-            const int pieces = width / PER;                                  // 16 threads per row: no division, 256 contiguous bytes each round
-#pragma unroll
-            for (int rh = 0; rh < ROWS; rh += RTT / 16) {                    // (one round with 8 waves, two with 4)
-            const int row = rh + (tid >> 4), r = r0 + row;
-            if (BWD && relu) {
-                // hand-over to the layer below: its dZ instead of dh (gcn.py:390-393 differentiated where the rows are at hand);
-                // the input rows are fetched in one batch, then masked and scaled while the tile leaves LDS
-                constexpr int RP = 4;
-                const float f = p.next_scale / rden[row];
-                const size_t rr = (size_t)min(r, p.N - 1) * p.NOUT + c_lo;
-                for (int pc0 = tid & 15; pc0 < pieces; pc0 += 16 * RP) {
-                    V hin[RP];
-#pragma unroll
-                    for (int u = 0; u < RP; ++u) hin[u] = *reinterpret_cast<const V*>(relu + rr + min(pc0 + 16 * u, pieces - 1) * PER);
-#pragma unroll
-                    for (int u = 0; u < RP; ++u) {
-                        const int pc = pc0 + 16 * u;
-                        if (pc >= pieces || r >= p.N) continue;
-                        V o = *reinterpret_cast<const V*>(O + (size_t)row * ostride + pc * PER);
-                        if constexpr (sizeof(OT) == 2) {
-                            unsigned* ow = reinterpret_cast<unsigned*>(&o);
-                            const unsigned* hw = reinterpret_cast<const unsigned*>(&hin[u]);
-#pragma unroll
-                            for (int q = 0; q < NW; ++q) {
-                                const float lo = bf16_to_f32((bf16_t)(hw[q] & 0xffffu)) > 0.0f ? bf16_to_f32((bf16_t)(ow[q] & 0xffffu)) * f : 0.0f;
-                                const float hi = bf16_to_f32((bf16_t)(hw[q] >> 16)) > 0.0f ? bf16_to_f32((bf16_t)(ow[q] >> 16)) * f : 0.0f;
-                                ow[q] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
-                            }
-                        } else {
-                            float* ow = reinterpret_cast<float*>(&o);
-                            const float* hw = reinterpret_cast<const float*>(&hin[u]);
-#pragma unroll
-                            for (int q = 0; q < NW; ++q) ow[q] = hw[q] > 0.0f ? ow[q] * f : 0.0f;
-                        }
-                        GCNPT_ROW_STORE(reinterpret_cast<V*>(out + (size_t)r * p.NOUT + c_lo + pc * PER), o);
-                    }
-                }
-            } else if (r < p.N) {
-                for (int pc = tid & 15; pc < pieces; pc += 16)
-                    GCNPT_ROW_STORE(reinterpret_cast<V*>(out + (size_t)r * p.NOUT + c_lo + pc * PER),
-                                    *reinterpret_cast<const V*>(O + (size_t)row * ostride + pc * PER));
-            }
-            }
-        };
-        constexpr int PER16 = 16 / (int)sizeof(OT), PER8 = 8 / (int)sizeof(OT);
-        if (p.vec_out == 16 && (width % PER16) == 0 && (c_lo % PER16) == 0) {
-            store_rows(uint4{});
-        } else if (p.vec_out >= 8 && (width % PER8) == 0 && (c_lo % PER8) == 0) {
-            store_rows(uint2{});
-        } else {
-            for (int it = tid; it < ROWS * width; it += RTT) {
-                const int row = it / width, c = it - row * width;
-                const int r = r0 + row;
-                if (r >= p.N) continue;
-                OT v = O[(size_t)row * ostride + c];
-                if (BWD && relu) {
-                    const OT hv = relu[(size_t)r * p.NOUT + c_lo + c];
-                    float x, hx;
-                    if constexpr (sizeof(OT) == 2) { x = bf16_to_f32(v); hx = bf16_to_f32(hv); } else { x = v; hx = hv; }
-                    x = hx > 0.0f ? x * (p.next_scale / rden[row]) : 0.0f;
-                    if constexpr (sizeof(OT) == 2) v = f32_to_bf16(x); else v = x;
-                }
-                out[(size_t)r * p.NOUT + c_lo + c] = v;
-            }
-        }
-    }
-    GCNPT_STAMP(p.stamps, 10);
-}
-
-
-template <typename CT, typename IT, typename OT, bool BWD, int VEC, int NTW, int KSMAX, bool DZIN = false, int NWV = 8>
-__global__ __launch_bounds__(NWV * WAVE, 2) void rowtile_kernel(const RowTileParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    rowtile_body<CT, IT, OT, BWD, VEC, NTW, KSMAX, DZIN, NWV>(p, (int)blockIdx.x, (int)gridDim.x, smem_raw);
-}
-
-// The backward-data launch of layer l with the WEIGHT GRADIENT OF LAYER l+1 as a side job: that gradient only needs the fragment images
-// the launches before this one have left (dZ_{l+1}, S_{l+1}), and a batch of <= ~6 k rows leaves a third of the CUs without a row tile.
-// Workgroups [0, n_tiles) are row tiles, workgroups [wg_first, gridDim.x) (wg_first = n_tiles rounded up to 8, so that the weight
-// gradient's block -> XCD map holds) contract one slice of one output block each.  The last launch of the sweep is then the bottom
-// layer's weight gradient alone: 7.5 us instead of 13.0 us for both layers (profiles/r02_bench.json).
-template <typename CT, typename IT, typename OT, int VEC, int NTW, int KSMAX>
-__global__ __launch_bounds__(RT_THREADS, 2) void rowtile_wgrad_kernel(const RowTileParams p, const WeightGradParams wg, const int n_tiles,
-                                                                      const int wg_first) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    if ((int)blockIdx.x < n_tiles) rowtile_body<CT, IT, OT, true, VEC, NTW, KSMAX, true>(p, (int)blockIdx.x, n_tiles, smem_raw);
-    else if ((int)blockIdx.x >= wg_first) weight_grad_body<CT, RT_WAVES, WG_NT, WG_KB>(wg, (int)blockIdx.x - wg_first, smem_raw);
-}
-
-}  // namespace gcnpt
+#include "rowtile_body.h"
 
 // =====================================================================================================
 // C-ABI
 // =====================================================================================================
 using namespace gcnpt;
+
+namespace gcnpt {
+thread_local SideWgrad t_side;
+#define GCNPT_RT_DECL(n) int rowtile_launch_part##n(hipStream_t s, const RowTileParams& p);
+GCNPT_RT_DECL(0) GCNPT_RT_DECL(1) GCNPT_RT_DECL(2) GCNPT_RT_DECL(3) GCNPT_RT_DECL(4) GCNPT_RT_DECL(5) GCNPT_RT_DECL(6) GCNPT_RT_DECL(7)
+GCNPT_RT_DECL(8) GCNPT_RT_DECL(9) GCNPT_RT_DECL(10) GCNPT_RT_DECL(11) GCNPT_RT_DECL(12) GCNPT_RT_DECL(13) GCNPT_RT_DECL(14)
+int rowtile_launch(int combo, int mode, hipStream_t s, const RowTileParams& p) {
+    typedef int (*fn_t)(hipStream_t, const RowTileParams&);
+    static const fn_t table[15] = {rowtile_launch_part0, rowtile_launch_part1, rowtile_launch_part2, rowtile_launch_part3, rowtile_launch_part4,
+                                   rowtile_launch_part5, rowtile_launch_part6, rowtile_launch_part7, rowtile_launch_part8, rowtile_launch_part9,
+                                   rowtile_launch_part10, rowtile_launch_part11, rowtile_launch_part12, rowtile_launch_part13, rowtile_launch_part14};
+    return table[combo * 3 + mode](s, p);
+}
+}  // namespace gcnpt
 
 // how rows of `width` elements of `es` bytes at base a (and b, if given) may be read: 8 elements per load when rows are 16-byte
 // aligned and whole chunks, 4 when they are aligned to half chunks (bf16: 8 bytes, f32: 16 bytes; width % 4 == 0), else element-wise
@@ -656,120 +52,23 @@ static int vec_bytes(int width, size_t es, const void* a, const void* b) {
     return 0;
 }
 
-// A weight gradient the next backward-data launch should carry (layers_bwd_impl sets it around that one call; thread-local because it
-// is only an argument that skips four levels of dispatch templates, not state: it never outlives the call that set it)
-struct SideWgrad { const WeightGradParams* wg = nullptr; int blocks = 0; bool carried = false; };
-static thread_local SideWgrad t_side;
-
-template <typename CT, typename IT, typename OT, bool BWD, int VEC, int NTW, int KSMAX, bool DZIN = false, int NWV = 8>
-static int launch_rowtile_cfg(hipStream_t s, const RowTileParams& p) {
-    const int stride = lds_stride_dw(p.Kpad * (int)sizeof(CT) / 4) * 4 / (int)sizeof(CT);
-    const int ncols_pass = NWV * NTW * 16;
-    const int ostride = out_stride_dw(std::min(round_up(p.NOUT, 16), ncols_pass) * (int)sizeof(OT) / 4) * 4 / (int)sizeof(OT);
-    const size_t s_bytes = (size_t)ROWS * stride * sizeof(CT), o_bytes = (size_t)ROWS * ostride * sizeof(OT);
-    const size_t lds = s_bytes + (BWD ? std::max(s_bytes, o_bytes) : o_bytes) +
-                       (size_t)ROWS * 13 * sizeof(int) + (size_t)std::max(NWV * WAVE, ncols_pass) * sizeof(float);
-    if (lds > 160 * 1024) return fail(GCNPT_E_UNSUPPORTED, "layer: K=%d needs %zu B of LDS per workgroup", p.K, lds);
-    const int n_tiles = ceil_div(p.N, ROWS);
-    // the uniform-precision instantiations can carry the layer above's weight gradient on the CUs that have no row tile
-    if constexpr (NWV == 8 && BWD && DZIN && std::is_same<IT, OT>::value && sizeof(CT) == sizeof(IT)) {
-        if (t_side.wg && t_side.blocks > 0) {
-            auto kern = rowtile_wgrad_kernel<CT, IT, OT, VEC, NTW, KSMAX>;
-            GCNPT_LDS_ATTR_ONCE(kern, 160 * 1024);
-            const int wg_first = round_up(n_tiles, 8);
-            hipLaunchKernelGGL(kern, dim3(wg_first + t_side.blocks), dim3(RT_THREADS), std::max(lds, weight_grad_lds(RT_WAVES)), s, p, *t_side.wg,
-                               n_tiles, wg_first);
-            GCNPT_HIP_CHECK(hipGetLastError());
-            t_side.carried = true;
-            return GCNPT_OK;
-        }
-    }
-    auto kern = rowtile_kernel<CT, IT, OT, BWD, VEC, NTW, KSMAX, DZIN, NWV>;
-    GCNPT_LDS_ATTR_ONCE(kern, 160 * 1024);
-    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(NWV * WAVE), lds, s, p);
-    GCNPT_HIP_CHECK(hipGetLastError());
-    return GCNPT_OK;
-}
-
-// Big batches (more row tiles than CUs): workgroups of 4 waves, two or three per CU, so that one workgroup's memory waits overlap another's
-// arithmetic (the 8-wave form keeps ~240 registers per wave: one workgroup per CU, nothing to overlap with).  Measured (C2 widths,
-// B = 64 ... 1024; C5 widths): slower below ~256 tiles (B = 80: +20 %), 3 % faster at B = 100, 9-12 % faster from B = 256 on and at the
-// C5 shape; not when the narrower workgroup needs one more column pass than the wide one (360 columns: 23 tiles = 20 + 3).
-// GCNPT_WAVES4=0 / 1 forces the choice (A/B, tests).
-static bool use_four_waves(const RowTileParams& p) {
-    const char* e = getenv("GCNPT_WAVES4");
-    if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
-    if (ceil_div(p.N, ROWS) <= 256) return false;
-    const int n_tiles = ceil_div(p.NOUT, 16);
-    const int pass8 = n_tiles <= 24 ? 1 : ceil_div(n_tiles, 32), pass4 = n_tiles <= 24 ? 1 : ceil_div(n_tiles, 20);
-    return pass4 <= pass8;
-}
-
-// output tiles per wave: the smallest of {2,3,4} that covers NOUT in one pass (8 waves x NTW x 16 columns),
-// with as many K-steps of weight fragments resident in registers as ~128 VGPRs allow.  Rows that cannot be
-// read 16 bytes at a time (width not a multiple of 8, unaligned base) take the element-load instantiation.
-template <typename CT, typename IT, typename OT, bool BWD, int VEC, bool DZIN>
-static int launch_rowtile_vec(hipStream_t s, const RowTileParams& p) {
-    const int n_tiles = ceil_div(p.NOUT, 16);
-    if (use_four_waves(p)) {                                  // 4 waves cover 8 / 12 / 16 column tiles per pass
-        if (n_tiles <= 4 * 2) return launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 2, 12, DZIN, 4>(s, p);
-        if (n_tiles <= 4 * 3) return launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 3, 7, DZIN, 4>(s, p);
-        if (n_tiles <= 4 * 4) return launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 4, 5, DZIN, 4>(s, p);
-        if (n_tiles > 20 && n_tiles <= 24) return launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 6, 3, DZIN, 4>(s, p);      // 360 columns in one pass
-        return launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 5, 4, DZIN, 4>(s, p);      // 300 / 600 columns: one / two passes of 20 tiles
-    }
-    if (n_tiles <= RT_WAVES * 2) {
-        // 13 k-steps = the C-GCN input width (2 x 200 BiLSTM states): one more resident k-step instead of a second load phase
-        if (p.Kpad / (sizeof(CT) == 2 ? 32 : 16) == 13) return launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 2, 13, DZIN>(s, p);
-        return launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 2, 12, DZIN>(s, p);
-    }
-    if (n_tiles <= RT_WAVES * 3) return launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 3, 7, DZIN>(s, p);
-    return launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 4, 5, DZIN>(s, p);
-}
-
-template <typename CT, typename IT, typename OT, bool BWD, bool DZIN = false>
-static int launch_rowtile(hipStream_t s, const RowTileParams& p) {
-    if (p.vec_in == 8) return launch_rowtile_vec<CT, IT, OT, BWD, 8, DZIN>(s, p);
-    if (p.vec_in == 4) return launch_rowtile_vec<CT, IT, OT, BWD, 4, DZIN>(s, p);
-    return launch_rowtile_cfg<CT, IT, OT, BWD, 0, 4, BWD ? 3 : 4, DZIN>(s, p);
-}
 
 template <bool BWD, bool DZIN = false>
 static int dispatch_rowtile(hipStream_t s, const RowTileParams& p, int in_dtype, int out_dtype, int compute) {
+    const int mode = BWD ? (DZIN ? 2 : 1) : 0;
     if (compute == GCNPT_F32) {
         if (in_dtype != GCNPT_F32 || out_dtype != GCNPT_F32)
             return fail(GCNPT_E_UNSUPPORTED, "compute_dtype f32 needs f32 activations");
-        return launch_rowtile<float, float, float, BWD, DZIN>(s, p);
+        return rowtile_launch(0, mode, s, p);
     }
-    if (in_dtype == GCNPT_F32 && out_dtype == GCNPT_F32) return launch_rowtile<bf16_t, float, float, BWD, DZIN>(s, p);
-    if (in_dtype == GCNPT_F32 && out_dtype == GCNPT_BF16) return launch_rowtile<bf16_t, float, bf16_t, BWD, DZIN>(s, p);
-    if (in_dtype == GCNPT_BF16 && out_dtype == GCNPT_F32) return launch_rowtile<bf16_t, bf16_t, float, BWD, DZIN>(s, p);
-    return launch_rowtile<bf16_t, bf16_t, bf16_t, BWD, DZIN>(s, p);
+    const int combo = in_dtype == GCNPT_F32 ? (out_dtype == GCNPT_F32 ? 1 : 2) : (out_dtype == GCNPT_F32 ? 3 : 4);
+    return rowtile_launch(combo, mode, s, p);
 }
-
-// big batches: the streaming kernels of rowstream_kernels.hip (1 = taken, 0 = does not apply, < 0 = error)
-int rowstream_try_fwd(hipStream_t s, const void* h, int h_dtype, const void* w_fwd, const float* bias, const int32_t* row_ptr,
-                      const int32_t* col_idx, const int32_t* ell, const int32_t* deg_ell, int N, int T, int Din, int H, void* out,
-                      int out_dtype, float drop_p, uint64_t seed, void* s_frag, const uint64_t* seed_dev, int vec_in, int vec_out);
-int rowstream_try_bwd(hipStream_t s, const void* dZ, int g_dtype, const void* w_bwd, const int32_t* ell, const int32_t* rowT_ptr,
-                      const int32_t* colT_idx, const int32_t* ellT, int N, int T, int Din, int H, void* dh, int dh_dtype, float* zero_dW,
-                      float* zero_db, const void* relu_src, float next_scale, int vec_in, int vec_out);
-bool rowstream_enabled();
-int launch_dz_rows(hipStream_t s, const void* dY, const void* Y, int dtype, const int32_t* ell, int N, int H, float scale, void* dz, void* z_frag,
-                   int mask);
-
-// big batches with a caller-provided workspace: the two-launch layer of rowsplit_kernels.hip (1 = taken, 0 = does not apply, < 0 = error)
-int rowsplit_layer(hipStream_t s, bool bwd, const void* src, int src_dtype, const void* wfrag, const float* bias, const int32_t* g_row_ptr,
-                   const int32_t* g_col_idx, const int32_t* g_ell, const int32_t* d_ell, int N, int T, int K, int NOUT, void* out, int out_dtype,
-                   float drop_p, uint64_t seed, const uint64_t* seed_dev, void* frag_out, float* zero_a, int zero_a_n, float* zero_b, int zero_b_n,
-                   const void* relu_src, float next_scale, void* ws, size_t ws_bytes);
-size_t rowsplit_agg_bytes(long long rows, int width);
-bool rowsplit_wanted(long long rows);
 
 static int layer_fwd_impl(void* stream, const void* h, int h_dtype, const void* w_fwd, const float* bias,
                           const int32_t* row_ptr, const int32_t* col_idx, const int32_t* ell, const int32_t* deg_ell,
                           int B, int T, int Din, int H, void* out, int out_dtype, int compute_dtype, float drop_p,
-                          uint64_t seed, void* s_frag, const uint64_t* seed_dev, void* ws, size_t ws_bytes) {
+                          uint64_t seed, void* s_frag, const uint64_t* seed_dev) {
     GCNPT_REQUIRE(h && w_fwd && bias && row_ptr && col_idx && ell && out, "layer_fwd: null pointer");
     GCNPT_REQUIRE(B > 0 && T >= 0 && Din > 0 && H > 0, "layer_fwd: sizes must be positive");
     GCNPT_REQUIRE(dtype_ok(h_dtype) && dtype_ok(out_dtype) && dtype_ok(compute_dtype), "layer_fwd: bad dtype");
@@ -786,25 +85,7 @@ static int layer_fwd_impl(void* stream, const void* h, int h_dtype, const void* 
     p.drop_p = drop_p; p.scale = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
     p.drop_thresh16 = (unsigned)((double)drop_p * 65536.0);
     p.seed = seed; p.seed_dev = seed_dev;
-    if (compute_dtype == GCNPT_BF16 && ws && !rowstream_enabled()) {
-        const int rc = rowsplit_layer((hipStream_t)stream, false, h, h_dtype, w_fwd, bias, row_ptr, col_idx, ell, p.d_ell, p.N, T, Din, H, out, out_dtype,
-                                      drop_p, seed, seed_dev, s_frag, nullptr, 0, nullptr, 0, nullptr, 1.0f, ws, ws_bytes);
-        if (rc != 0) return rc < 0 ? rc : GCNPT_OK;
-    }
-    if (compute_dtype == GCNPT_BF16) {
-        const int rc = rowstream_try_fwd((hipStream_t)stream, h, h_dtype, w_fwd, bias, row_ptr, col_idx, ell, deg_ell, p.N, T, Din, H, out, out_dtype,
-                                         drop_p, seed, s_frag, seed_dev, p.vec_in, p.vec_out);
-        if (rc != 0) return rc < 0 ? rc : GCNPT_OK;
-    }
     return dispatch_rowtile<false>((hipStream_t)stream, p, h_dtype, out_dtype, compute_dtype);
-}
-
-extern "C" int gcnpt_layer_fwd_ws(void* stream, const void* h, int h_dtype, const void* w_fwd, const float* bias,
-                                  const int32_t* row_ptr, const int32_t* col_idx, const int32_t* ell, const int32_t* deg_ell,
-                                  int B, int T, int Din, int H, void* out, int out_dtype, int compute_dtype, float drop_p,
-                                  uint64_t seed, void* s_frag, const uint64_t* seed_dev, void* workspace, size_t workspace_bytes) {
-    return layer_fwd_impl(stream, h, h_dtype, w_fwd, bias, row_ptr, col_idx, ell, deg_ell, B, T, Din, H, out, out_dtype, compute_dtype, drop_p, seed,
-                          s_frag, seed_dev, workspace, workspace_bytes);
 }
 
 extern "C" int gcnpt_layer_fwd(void* stream, const void* h, int h_dtype, const void* w_fwd, const float* bias,
@@ -812,55 +93,44 @@ extern "C" int gcnpt_layer_fwd(void* stream, const void* h, int h_dtype, const v
                                int B, int T, int Din, int H, void* out, int out_dtype, int compute_dtype, float drop_p,
                                uint64_t seed, void* s_frag, const uint64_t* seed_dev) {
     return layer_fwd_impl(stream, h, h_dtype, w_fwd, bias, row_ptr, col_idx, ell, deg_ell, B, T, Din, H, out, out_dtype, compute_dtype, drop_p, seed,
-                          s_frag, seed_dev, nullptr, 0);
+                          s_frag, seed_dev);
 }
+
+// One weight gradient some launch should compute: the two fragment images, the layer's widths, its accumulators
+struct WgradReq { const void* z; const void* s; int Din, H; float* dW; float* db; };
+// What a backward-data launch does beside its own rows
+struct BwdExtras {
+    void* down_z_frag = nullptr;        // fragment image of the dZ it hands down (needs relu_src and activations in the compute type)
+    float* down_zero_dW = nullptr;      // accumulators of the layer below to clear ([Din x down_Din], [Din])
+    float* down_zero_db = nullptr;
+    int down_Din = 0;
+};
 
 static int layer_bwd_data_impl(void* stream, const void* dY, const void* Y, int g_dtype, const void* w_bwd,
                                const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
                                const int32_t* ellT, int B, int T, int Din, int H, void* dh, int dh_dtype,
                                int compute_dtype, float scale, void* z_frag, float* zero_dW, float* zero_db,
-                               const void* relu_src, float next_scale, int src_is_dz, void* ws, size_t ws_bytes) {
+                               const void* relu_src, float next_scale, int src_is_dz, const BwdExtras& ex = BwdExtras{}) {
     GCNPT_REQUIRE(dY && (Y || src_is_dz) && w_bwd && ell && rowT_ptr && colT_idx && ellT, "layer_bwd_data: null pointer");
     GCNPT_REQUIRE(!relu_src || dh, "layer_bwd_data: relu_src without dh");
     GCNPT_REQUIRE(dh || z_frag, "layer_bwd_data: nothing to produce (dh and z_frag both NULL)");
     GCNPT_REQUIRE(B > 0 && T >= 0 && Din > 0 && H > 0, "layer_bwd_data: sizes must be positive");
     GCNPT_REQUIRE(dtype_ok(g_dtype) && dtype_ok(dh_dtype) && dtype_ok(compute_dtype), "layer_bwd_data: bad dtype");
+    GCNPT_REQUIRE(!ex.down_z_frag || (relu_src && dh_dtype == compute_dtype && ex.down_Din > 0),
+                  "layer_bwd_data: the image of the handed-down dZ needs relu_src, dh in the compute dtype and the width of the layer below");
     if (rows_of(B, T) > 0x7fffffffLL / 2) return fail(GCNPT_E_UNSUPPORTED, "layer_bwd_data: B*T too large");
     RowTileParams p{};
     p.stamps = static_cast<unsigned long long*>(g_debug_stamps); p.knob = g_debug_knob;
     p.src = dY; p.yref = Y; p.wfrag = w_bwd; p.bias = nullptr;
     p.g_row_ptr = rowT_ptr; p.g_col_idx = colT_idx; p.g_ell = ellT; p.d_ell = ell; p.out = dh;
-    p.frag_out = z_frag;
-    p.zero_a = zero_dW; p.zero_a_n = H * Din; p.zero_b = zero_db; p.zero_b_n = H;
+    p.frag_out = z_frag; p.frag_down = ex.down_z_frag;
+    p.zero_p[0] = zero_dW; p.zero_n[0] = H * Din; p.zero_p[1] = zero_db; p.zero_n[1] = H;
+    p.zero_p[2] = ex.down_zero_dW; p.zero_n[2] = Din * ex.down_Din; p.zero_p[3] = ex.down_zero_db; p.zero_n[3] = Din;
     p.N = (int)rows_of(B, T); p.T = T; p.K = H; p.NOUT = Din; p.Kpad = round_up(H, kstep_of(compute_dtype)); p.chunk_magic = 0xffffffffu / (unsigned)(p.Kpad / 8) + 1u;
     p.vec_in = vec_elems(H, esize(g_dtype), dY, src_is_dz ? nullptr : Y);
     p.vec_out = dh ? vec_bytes(Din, esize(dh_dtype), dh, relu_src) : 0;
     p.scale = scale; p.drop_p = 0.0f;
     p.relu_src = relu_src; p.next_scale = next_scale;
-    if (compute_dtype == GCNPT_BF16 && dh && ws && !rowstream_enabled() && rowsplit_wanted(p.N)) {
-        // big batches: gather + matrix launch (rowsplit_kernels.hip).  A top layer that starts from dY first writes its dZ rows (and their
-        // fragment image) into the workspace, behind the aggregated rows, so that the gather loads one row per neighbour
-        const size_t agg_part = rowsplit_agg_bytes(p.N, H);
-        if (!src_is_dz && H <= 960 && ws_bytes >= agg_part + (size_t)p.N * H * esize(g_dtype)) {
-            void* dz = static_cast<char*>(ws) + agg_part;
-            const int rc = launch_dz_rows((hipStream_t)stream, dY, Y, g_dtype, ell, p.N, H, scale, dz, z_frag, 1);
-            if (rc != GCNPT_OK) return rc;
-            dY = dz; src_is_dz = 1; z_frag = nullptr;               // (also what the row-tile kernel continues from, should the split not apply)
-            p.src = dY; p.frag_out = nullptr; p.vec_in = vec_elems(H, esize(g_dtype), dY, nullptr);
-        }
-        if (src_is_dz) {
-            const int rc = rowsplit_layer((hipStream_t)stream, true, dY, g_dtype, w_bwd, nullptr, rowT_ptr, colT_idx, ellT, ell, p.N, T, H, Din, dh,
-                                          dh_dtype, 0.0f, 0, nullptr, z_frag, zero_dW, H * Din, zero_db, H, relu_src, next_scale, ws, agg_part);
-            if (rc != 0) return rc < 0 ? rc : GCNPT_OK;
-        }
-    }
-    if (src_is_dz && compute_dtype == GCNPT_BF16 && dh) {
-        const int rc = rowstream_try_bwd((hipStream_t)stream, dY, g_dtype, w_bwd, ell, rowT_ptr, colT_idx, ellT, p.N, T, Din, H, dh, dh_dtype, zero_dW,
-                                         zero_db, relu_src, next_scale, p.vec_in, p.vec_out);
-        if (rc < 0) return rc;
-        if (rc == 1)       // the streaming kernel does not keep its input rows in LDS: their fragment image comes from a re-layout pass
-            return z_frag ? launch_dz_rows((hipStream_t)stream, dY, nullptr, g_dtype, ell, p.N, H, 1.0f, nullptr, z_frag, 0) : GCNPT_OK;
-    }
     if (src_is_dz) return dispatch_rowtile<true, true>((hipStream_t)stream, p, g_dtype, dh_dtype, compute_dtype);
     return dispatch_rowtile<true>((hipStream_t)stream, p, g_dtype, dh_dtype, compute_dtype);
 }
@@ -871,79 +141,85 @@ extern "C" int gcnpt_layer_bwd_data(void* stream, const void* dY, const void* Y,
                                     int compute_dtype, float scale, void* z_frag, float* zero_dW, float* zero_db,
                                     const void* relu_src, float next_scale, int src_is_dz) {
     return layer_bwd_data_impl(stream, dY, Y, g_dtype, w_bwd, ell, rowT_ptr, colT_idx, ellT, B, T, Din, H, dh, dh_dtype, compute_dtype, scale, z_frag,
-                               zero_dW, zero_db, relu_src, next_scale, src_is_dz, nullptr, 0);
+                               zero_dW, zero_db, relu_src, next_scale, src_is_dz);
 }
 
-extern "C" int gcnpt_layer_bwd_data_ws(void* stream, const void* dY, const void* Y, int g_dtype, const void* w_bwd,
-                                       const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
-                                       const int32_t* ellT, int B, int T, int Din, int H, void* dh, int dh_dtype,
-                                       int compute_dtype, float scale, void* z_frag, float* zero_dW, float* zero_db,
-                                       const void* relu_src, float next_scale, int src_is_dz, void* workspace, size_t workspace_bytes) {
-    return layer_bwd_data_impl(stream, dY, Y, g_dtype, w_bwd, ell, rowT_ptr, colT_idx, ellT, B, T, Din, H, dh, dh_dtype, compute_dtype, scale, z_frag,
-                               zero_dW, zero_db, relu_src, next_scale, src_is_dz, workspace, workspace_bytes);
-}
-
-// Offers the weight gradient of the layer ABOVE (its two fragment images, left by earlier launches) to the next backward-data launch of
-// this thread: taken by the row-tile launch of a small batch (<= 192 row tiles), see rowtile_wgrad_kernel.  p_out must outlive that call.
-static void offer_side_wgrad(WeightGradParams& p_out, const void* z_frag_up, const void* s_frag_up, int B, int T, int Din_up, int H_up,
-                             float* dW_up, float* db_up, int compute_dtype) {
-    t_side = SideWgrad{};
+// Plans up to SIDE_MAX weight gradients for the passenger workgroups of a backward-data launch over B x T rows: taken by the row-tile
+// launch of a small batch (<= GCNPT_OPT_SIDE_TILES row tiles), see rowtile_wgrad_kernel.  false: nothing can ride (the caller launches
+// the gradients on their own).
+static bool plan_side_wgrads(SideWgrads& sw, const WgradReq* req, int n, int B, int T, int compute_dtype) {
+    sw = SideWgrads{};
     const int n_tiles = ceil_div((int)rows_of(B, T), ROWS);
-    static const int max_tiles = [] { const char* e = getenv("GCNPT_SIDE_TILES"); return e ? atoi(e) : 192; }();     // (experiments)
-    if (!z_frag_up || !s_frag_up || !dW_up || !db_up || n_tiles > max_tiles || rowstream_enabled()) return;
+    if (n <= 0 || n > SIDE_MAX || n_tiles > option(GCNPT_OPT_SIDE_TILES)) return false;
     const int nks = n_tiles * (compute_dtype == GCNPT_BF16 ? 1 : 2);
-    const int blocks_l = ceil_div(ceil_div(H_up, 16), WG_MT) * ceil_div(ceil_div(Din_up, 16), WG_NT);
-    t_side.blocks = plan_weight_grad(p_out, z_frag_up, s_frag_up, nks, Din_up, H_up, dW_up, db_up, blocks_l, RT_WAVES, std::max(64, 256 - n_tiles),
-                                     WG_NT);
-    t_side.wg = &p_out;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) blocks += ceil_div(ceil_div(req[i].H, 16), WG_MT) * ceil_div(ceil_div(req[i].Din, 16), WG_NT);
+    for (int i = 0; i < SIDE_MAX; ++i) {
+        sw.first[i + 1] = sw.first[i];
+        if (i < n)
+            sw.first[i + 1] += plan_weight_grad(sw.l[i], req[i].z, req[i].s, nks, req[i].Din, req[i].H, req[i].dW, req[i].db, blocks, RT_WAVES,
+                                                std::max(64, 256 - n_tiles), WG_NT);
+    }
+    return true;
 }
 
-extern "C" int gcnpt_layer_bwd_weight(void* stream, const void* z_frag, const void* s_frag, int B, int T, int Din, int H,
-                                      float* dW, float* db, int compute_dtype);
-
-extern "C" int gcnpt_layer_bwd_data_wgrad(void* stream, const void* dY, const void* Y, int g_dtype, const void* w_bwd,
-                                          const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
-                                          const int32_t* ellT, int B, int T, int Din, int H, void* dh, int dh_dtype,
-                                          int compute_dtype, float scale, void* z_frag, float* zero_dW, float* zero_db,
-                                          const void* relu_src, float next_scale, int src_is_dz, const void* up_z_frag,
-                                          const void* up_s_frag, int up_Din, int up_H, float* up_dW, float* up_db) {
-    GCNPT_REQUIRE(up_z_frag && up_s_frag && up_dW && up_db && up_Din > 0 && up_H > 0, "layer_bwd_data_wgrad: the layer above's weight gradient needs "
-                  "its two fragment images, dW and db");
-    WeightGradParams side_p;
-    offer_side_wgrad(side_p, up_z_frag, up_s_frag, B, T, up_Din, up_H, up_dW, up_db, compute_dtype);
-    const int rc = layer_bwd_data_impl(stream, dY, Y, g_dtype, w_bwd, ell, rowT_ptr, colT_idx, ellT, B, T, Din, H, dh, dh_dtype, compute_dtype, scale,
-                                       z_frag, zero_dW, zero_db, relu_src, next_scale, src_is_dz, nullptr, 0);
-    const bool carried = t_side.carried;
-    t_side = SideWgrad{};
-    if (rc != GCNPT_OK) return rc;
-    return carried ? GCNPT_OK : gcnpt_layer_bwd_weight(stream, up_z_frag, up_s_frag, B, T, up_Din, up_H, up_dW, up_db, compute_dtype);
-}
-
-// ---- the whole layer loop / its autograd in one host call: the launches above, back to back (no kernel of their own) ----
 extern "C" int gcnpt_layer_bwd_weight_multi(void* stream, int n_layers, const void* const* z_frag, const void* const* s_frag,
                                             int B, int T, const int* Din, const int* H, float* const* dW, float* const* db,
                                             int compute_dtype);
+
+// the weight gradients of `req` in a launch of their own
+static int launch_wgrads(void* stream, const WgradReq* req, int n, int B, int T, int compute_dtype) {
+    constexpr int MAXR = 8;
+    const void* zf[MAXR]; const void* sf[MAXR]; float* dW[MAXR]; float* db[MAXR]; int Din[MAXR], H[MAXR];
+    for (int i = 0; i < n; ++i) { zf[i] = req[i].z; sf[i] = req[i].s; dW[i] = req[i].dW; db[i] = req[i].db; Din[i] = req[i].Din; H[i] = req[i].H; }
+    return n ? gcnpt_layer_bwd_weight_multi(stream, n, zf, sf, B, T, Din, H, dW, db, compute_dtype) : GCNPT_OK;
+}
+
+// backward-data of one layer + the extras; the weight gradients of `req` ride in the launch when they can, else follow it
+static int bwd_data_with_riders(void* stream, const void* dY, const void* Y, int g_dtype, const void* w_bwd, const int32_t* ell,
+                                const int32_t* rowT_ptr, const int32_t* colT_idx, const int32_t* ellT, int B, int T, int Din, int H, void* dh,
+                                int dh_dtype, int compute_dtype, float scale, void* z_frag, float* zero_dW, float* zero_db, const void* relu_src,
+                                float next_scale, int src_is_dz, const BwdExtras& ex, const WgradReq* req, int n_req) {
+    SideWgrads sw;
+    t_side = SideWgrad{};
+    if (n_req > 0 && plan_side_wgrads(sw, req, n_req, B, T, compute_dtype)) t_side.sw = &sw;
+    const int rc = layer_bwd_data_impl(stream, dY, Y, g_dtype, w_bwd, ell, rowT_ptr, colT_idx, ellT, B, T, Din, H, dh, dh_dtype, compute_dtype, scale,
+                                       z_frag, zero_dW, zero_db, relu_src, next_scale, src_is_dz, ex);
+    const bool carried = t_side.carried;
+    t_side = SideWgrad{};
+    if (rc != GCNPT_OK) return rc;
+    return carried ? GCNPT_OK : launch_wgrads(stream, req, n_req, B, T, compute_dtype);
+}
+
+extern "C" int gcnpt_layer_bwd_data_ex(void* stream, const void* dY, const void* Y, int g_dtype, const void* w_bwd,
+                                       const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
+                                       const int32_t* ellT, int B, int T, int Din, int H, void* dh, int dh_dtype,
+                                       int compute_dtype, float scale, void* z_frag, float* zero_dW, float* zero_db,
+                                       const void* relu_src, float next_scale, int src_is_dz, void* down_z_frag, float* down_zero_dW,
+                                       float* down_zero_db, int down_Din, int n_riders, const void* const* r_z_frag,
+                                       const void* const* r_s_frag, const int* r_Din, const int* r_H, float* const* r_dW, float* const* r_db) {
+    GCNPT_REQUIRE(n_riders >= 0 && n_riders <= SIDE_MAX, "layer_bwd_data_ex: 0..%d weight gradients can ride", SIDE_MAX);
+    GCNPT_REQUIRE(n_riders == 0 || (r_z_frag && r_s_frag && r_Din && r_H && r_dW && r_db), "layer_bwd_data_ex: null rider arrays");
+    WgradReq req[SIDE_MAX];
+    for (int i = 0; i < n_riders; ++i) {
+        GCNPT_REQUIRE(r_z_frag[i] && r_s_frag[i] && r_dW[i] && r_db[i] && r_Din[i] > 0 && r_H[i] > 0,
+                      "layer_bwd_data_ex: rider %d needs its two fragment images, dW, db and positive widths", i);
+        req[i] = WgradReq{r_z_frag[i], r_s_frag[i], r_Din[i], r_H[i], r_dW[i], r_db[i]};
+    }
+    BwdExtras ex;
+    ex.down_z_frag = down_z_frag; ex.down_zero_dW = down_zero_dW; ex.down_zero_db = down_zero_db; ex.down_Din = down_Din;
+    return bwd_data_with_riders(stream, dY, Y, g_dtype, w_bwd, ell, rowT_ptr, colT_idx, ellT, B, T, Din, H, dh, dh_dtype, compute_dtype, scale, z_frag,
+                                zero_dW, zero_db, relu_src, next_scale, src_is_dz, ex, req, n_riders);
+}
+
+// ---- the whole layer loop / its autograd in one host call: the launches above, back to back (no kernel of their own) ----
 constexpr int LAYERS_MAX = 8;
 
-// Workspace of the big-batch path (rowsplit_kernels.hip): [aggregated rows: rows x widest layer side, bf16][dZ of the top layer]
-static size_t ws_agg_part(int n_layers, long long rows, const int* Din, const int* H) {
-    int kmax = 0;
-    for (int l = 0; l < n_layers; ++l) kmax = std::max(kmax, std::max(Din[l], H[l]));
-    return rowsplit_agg_bytes(rows, kmax);
-}
-
-extern "C" size_t gcnpt_layers_workspace_bytes(int n_layers, int B, int T, const int* Din, const int* H, int top_dtype) {
-    if (n_layers < 1 || n_layers > LAYERS_MAX || !Din || !H || B <= 0 || T < 0 || !dtype_ok(top_dtype)) return 0;
-    const long long rows = rows_of(B, T);
-    if (!rowsplit_wanted(rows)) return 0;
-    return ws_agg_part(n_layers, rows, Din, H) + (size_t)((rows * H[n_layers - 1] * (long long)esize(top_dtype) + 255) / 256 * 256);
-}
-
-extern "C" int gcnpt_layers_fwd_ws(void* stream, int n_layers, const void* x, int x_dtype, const void* const* w_fwd,
-                                   const float* const* bias, const int32_t* row_ptr, const int32_t* col_idx, const int32_t* ell,
-                                   const int32_t* deg_ell, int B, int T, const int* Din, const int* H, void* const* out,
-                                   const int* out_dtype, int compute_dtype, const float* drop_p, const uint64_t* seed,
-                                   void* const* s_frag, const uint64_t* seed_dev, void* workspace, size_t workspace_bytes) {
+extern "C" int gcnpt_layers_fwd(void* stream, int n_layers, const void* x, int x_dtype, const void* const* w_fwd,
+                                const float* const* bias, const int32_t* row_ptr, const int32_t* col_idx, const int32_t* ell,
+                                const int32_t* deg_ell, int B, int T, const int* Din, const int* H, void* const* out,
+                                const int* out_dtype, int compute_dtype, const float* drop_p, const uint64_t* seed,
+                                void* const* s_frag, const uint64_t* seed_dev) {
     GCNPT_REQUIRE(n_layers >= 1 && n_layers <= LAYERS_MAX, "layers_fwd: 1..%d layers per call", LAYERS_MAX);
     GCNPT_REQUIRE(x && w_fwd && bias && Din && H && out && out_dtype && drop_p && seed, "layers_fwd: null pointer");
     for (int l = 1; l < n_layers; ++l)
@@ -952,8 +228,7 @@ extern "C" int gcnpt_layers_fwd_ws(void* stream, int n_layers, const void* x, in
     int h_dtype = x_dtype;
     for (int l = 0; l < n_layers; ++l) {
         const int rc = layer_fwd_impl(stream, h, h_dtype, w_fwd[l], bias[l], row_ptr, col_idx, ell, deg_ell, B, T, Din[l], H[l], out[l],
-                                      out_dtype[l], compute_dtype, drop_p[l], seed[l], s_frag ? s_frag[l] : nullptr, seed_dev, workspace,
-                                      workspace_bytes);
+                                      out_dtype[l], compute_dtype, drop_p[l], seed[l], s_frag ? s_frag[l] : nullptr, seed_dev);
         if (rc != GCNPT_OK) return rc;
         h = out[l];
         h_dtype = out_dtype[l];
@@ -961,20 +236,16 @@ extern "C" int gcnpt_layers_fwd_ws(void* stream, int n_layers, const void* x, in
     return GCNPT_OK;
 }
 
-extern "C" int gcnpt_layers_fwd(void* stream, int n_layers, const void* x, int x_dtype, const void* const* w_fwd,
-                                const float* const* bias, const int32_t* row_ptr, const int32_t* col_idx, const int32_t* ell,
-                                const int32_t* deg_ell, int B, int T, const int* Din, const int* H, void* const* out,
-                                const int* out_dtype, int compute_dtype, const float* drop_p, const uint64_t* seed,
-                                void* const* s_frag, const uint64_t* seed_dev) {
-    return gcnpt_layers_fwd_ws(stream, n_layers, x, x_dtype, w_fwd, bias, row_ptr, col_idx, ell, deg_ell, B, T, Din, H, out, out_dtype, compute_dtype,
-                               drop_p, seed, s_frag, seed_dev, nullptr, 0);
-}
-
+// The backward sweep.  Small batches (<= GCNPT_OPT_SIDE_TILES row tiles) with weight gradients: every launch that hands its dZ down also
+// leaves that dZ's fragment image (and clears the layer below's accumulators), so the weight gradient of layer l is computable as soon
+// as the launch ABOVE layer l's backward-data has ended, and rides in layer l's launch on the CUs without a row tile (the top layer's
+// gradient, whose image the top launch itself writes, rides one launch later, together with the next one).  An L >= 2 sweep is then L
+// launches.  Big batches / mixed precisions: every layer writes its own image and ONE launch at the end computes all weight gradients.
 static int layers_bwd_impl(void* stream, int n_layers, const void* gy, const void* const* Y, const int* y_dtype,
                            const void* const* w_bwd, const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
                            const int32_t* ellT, int B, int T, const int* Din, const int* H, void* const* dh,
                            const int* dh_dtype, int compute_dtype, const float* scale, void* const* z_frag,
-                           const void* const* s_frag, float* const* dW, float* const* db, bool gy_is_dz, void* ws, size_t ws_bytes) {
+                           const void* const* s_frag, float* const* dW, float* const* db, bool gy_is_dz, int first_launch, int n_launches) {
     GCNPT_REQUIRE(n_layers >= 1 && n_layers <= LAYERS_MAX, "layers_bwd: 1..%d layers per call", LAYERS_MAX);
     GCNPT_REQUIRE(gy && Y && y_dtype && w_bwd && Din && H && dh && dh_dtype && scale, "layers_bwd: null pointer");
     GCNPT_REQUIRE(!z_frag || (s_frag && dW && db), "layers_bwd: weight gradients need z_frag, s_frag, dW and db");
@@ -982,70 +253,48 @@ static int layers_bwd_impl(void* stream, int n_layers, const void* gy, const voi
         GCNPT_REQUIRE(Din[l] == H[l - 1], "layers_bwd: layer %d reads %d columns but layer %d writes %d", l, Din[l], l - 1, H[l - 1]);
         GCNPT_REQUIRE(dh[l] && dh_dtype[l] == y_dtype[l - 1], "layers_bwd: dh[%d] must exist and have the dtype of Y[%d]", l, l - 1);
     }
+    const int n_tiles = ceil_div((int)rows_of(B, T), ROWS);
+    const bool riders = z_frag && n_tiles <= option(GCNPT_OPT_SIDE_TILES);
     const void* g = gy;
-    // Big batches: the top layer's dZ = gy * 1[Y > 0] * scale / (deg + 1) is written out once (into the memory of dh[0], which is only
-    // written by the LAST launch of the sweep and is at least as large) so that the top layer, too, gathers ready-made rows on the
-    // streaming kernel (rowstream_kernels.hip) instead of deriving three loads per neighbour
-    const int top = n_layers - 1;
-    bool top_is_dz = false;
-    if (!gy_is_dz && rowstream_enabled() && n_layers >= 2 && compute_dtype == GCNPT_BF16 && rows_of(B, T) >= 16384 && dh[0] && dh[top] &&
-        (size_t)Din[0] * esize(dh_dtype[0]) >= (size_t)H[top] * esize(y_dtype[top]) && aligned16(dh[0])) {
-        const int rc = launch_dz_rows((hipStream_t)stream, gy, Y[top], y_dtype[top], ell, (int)rows_of(B, T), H[top], scale[top], dh[0],
-                                      z_frag ? z_frag[top] : nullptr, 1);
-        if (rc != GCNPT_OK) return rc;
-        g = dh[0];
-        top_is_dz = true;
-    }
-    // Small batches: the weight gradient of layer l+1 rides in the backward-data launch of layer l (rowtile_wgrad_kernel); what is
-    // left for the launch at the end of the sweep is the bottom layer (and any layer whose launch could not carry one)
-    bool wg_done[LAYERS_MAX] = {};
-    WeightGradParams side_p;
-    auto offer_side = [&](int l) {                      // called before the backward-data launch of layer l: carry layer l+1's gradient?
-        t_side = SideWgrad{};
-        if (!z_frag || l + 1 >= n_layers) return;
-        offer_side_wgrad(side_p, z_frag[l + 1], s_frag[l + 1], B, T, Din[l + 1], H[l + 1], dW[l + 1], db[l + 1], compute_dtype);
-    };
-    auto close_side = [&](int l) {
-        if (t_side.carried) wg_done[l + 1] = true;
-        t_side = SideWgrad{};
-    };
+    bool img_ready[LAYERS_MAX] = {}, wg_done[LAYERS_MAX] = {};
+    int launch = 0;
+    auto wanted = [&](void) { const bool w = launch >= first_launch && launch < first_launch + n_launches; ++launch; return w; };
     for (int l = n_layers - 1; l >= 0; --l) {
-        if (l == top && top_is_dz) {
-            const int rc = layer_bwd_data_impl(stream, g, Y[l], y_dtype[l], w_bwd[l], ell, rowT_ptr, colT_idx, ellT, B, T, Din[l], H[l], dh[l],
-                                               dh_dtype[l], compute_dtype, scale[l], nullptr, z_frag ? dW[l] : nullptr, z_frag ? db[l] : nullptr,
-                                               Y[l - 1], scale[l - 1], 1, ws, ws_bytes);
-            if (rc != GCNPT_OK) return rc;
-            g = dh[l];
-            continue;
-        }
         if (dh[l] || z_frag) {
             // every layer but the bottom one hands the layer below its dZ ready-made (dh[l] then holds dZ of layer l-1), and every
             // layer but the top one receives it: one load per neighbour in the gather instead of three
             const bool hand_down = l > 0, handed = l < n_layers - 1 || gy_is_dz;
-            offer_side(l);
-            const int rc = layer_bwd_data_impl(stream, g, Y[l], y_dtype[l], w_bwd[l], ell, rowT_ptr, colT_idx, ellT, B, T, Din[l], H[l],
-                                               dh[l], dh_dtype[l], compute_dtype, scale[l], z_frag ? z_frag[l] : nullptr,
-                                               z_frag ? dW[l] : nullptr, z_frag ? db[l] : nullptr, hand_down ? Y[l - 1] : nullptr,
-                                               hand_down ? scale[l - 1] : 1.0f, handed ? 1 : 0, ws, ws_bytes);
-            close_side(l);
-            if (rc != GCNPT_OK) return rc;
+            const bool own_image = z_frag && !img_ready[l];
+            BwdExtras ex;
+            if (riders && hand_down && dh_dtype[l] == compute_dtype) {
+                ex.down_z_frag = z_frag[l - 1]; ex.down_zero_dW = dW[l - 1]; ex.down_zero_db = db[l - 1]; ex.down_Din = Din[l - 1];
+            }
+            WgradReq req[SIDE_MAX];
+            int req_l[SIDE_MAX], n_req = 0;
+            if (riders && handed)
+                for (int u = n_layers - 1; u >= 0 && n_req < SIDE_MAX; --u)
+                    if (img_ready[u] && !wg_done[u]) { req[n_req] = WgradReq{z_frag[u], s_frag[u], Din[u], H[u], dW[u], db[u]}; req_l[n_req++] = u; }
+            if (wanted()) {
+                const int rc = bwd_data_with_riders(stream, g, Y[l], y_dtype[l], w_bwd[l], ell, rowT_ptr, colT_idx, ellT, B, T, Din[l], H[l], dh[l],
+                                                    dh_dtype[l], compute_dtype, scale[l], own_image ? z_frag[l] : nullptr,
+                                                    own_image ? dW[l] : nullptr, own_image ? db[l] : nullptr, hand_down ? Y[l - 1] : nullptr,
+                                                    hand_down ? scale[l - 1] : 1.0f, handed ? 1 : 0, ex, req, n_req);
+                if (rc != GCNPT_OK) return rc;
+            }
+            for (int i = 0; i < n_req; ++i) wg_done[req_l[i]] = true;          // carried, or launched right behind
+            if (z_frag) img_ready[l] = true;
+            if (ex.down_z_frag) img_ready[l - 1] = true;
         }
         g = dh[l];
     }
     if (!z_frag) return GCNPT_OK;
     // the weight gradients no launch has carried, in one launch
-    const void* zf_r[LAYERS_MAX];
-    const void* sf_r[LAYERS_MAX];
-    float* dW_r[LAYERS_MAX];
-    float* db_r[LAYERS_MAX];
-    int Din_r[LAYERS_MAX], H_r[LAYERS_MAX], n_r = 0;
-    for (int l = 0; l < n_layers; ++l) {
-        if (wg_done[l]) continue;
-        zf_r[n_r] = z_frag[l]; sf_r[n_r] = s_frag[l]; dW_r[n_r] = dW[l]; db_r[n_r] = db[l]; Din_r[n_r] = Din[l]; H_r[n_r] = H[l];
-        ++n_r;
-    }
-    if (n_r == 0) return GCNPT_OK;
-    return gcnpt_layer_bwd_weight_multi(stream, n_r, zf_r, sf_r, B, T, Din_r, H_r, dW_r, db_r, compute_dtype);
+    WgradReq rest[LAYERS_MAX];
+    int n_r = 0;
+    for (int l = 0; l < n_layers; ++l)
+        if (!wg_done[l]) rest[n_r++] = WgradReq{z_frag[l], s_frag[l], Din[l], H[l], dW[l], db[l]};
+    if (n_r == 0 || !wanted()) return GCNPT_OK;
+    return launch_wgrads(stream, rest, n_r, B, T, compute_dtype);
 }
 
 extern "C" int gcnpt_layers_bwd(void* stream, int n_layers, const void* gy, const void* const* Y, const int* y_dtype,
@@ -1054,7 +303,7 @@ extern "C" int gcnpt_layers_bwd(void* stream, int n_layers, const void* gy, cons
                                 const int* dh_dtype, int compute_dtype, const float* scale, void* const* z_frag,
                                 const void* const* s_frag, float* const* dW, float* const* db) {
     return layers_bwd_impl(stream, n_layers, gy, Y, y_dtype, w_bwd, ell, rowT_ptr, colT_idx, ellT, B, T, Din, H, dh, dh_dtype, compute_dtype, scale,
-                           z_frag, s_frag, dW, db, false, nullptr, 0);
+                           z_frag, s_frag, dW, db, false, 0, 1 << 30);
 }
 
 // the same sweep when the caller already holds dZ of the TOP layer (gcnpt_pool3_bwd_dz leaves it): the top layer then gathers one
@@ -1065,16 +314,18 @@ extern "C" int gcnpt_layers_bwd_dz(void* stream, int n_layers, const void* dz_to
                                    const int* dh_dtype, int compute_dtype, const float* scale, void* const* z_frag,
                                    const void* const* s_frag, float* const* dW, float* const* db) {
     return layers_bwd_impl(stream, n_layers, dz_top, Y, y_dtype, w_bwd, ell, rowT_ptr, colT_idx, ellT, B, T, Din, H, dh, dh_dtype, compute_dtype,
-                           scale, z_frag, s_frag, dW, db, true, nullptr, 0);
+                           scale, z_frag, s_frag, dW, db, true, 0, 1 << 30);
 }
 
-// both sweeps with the big-batch workspace (gcnpt_layers_workspace_bytes; NULL / too small: exactly the calls above)
-extern "C" int gcnpt_layers_bwd_ws(void* stream, int n_layers, const void* gy, const void* const* Y, const int* y_dtype,
-                                   const void* const* w_bwd, const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
-                                   const int32_t* ellT, int B, int T, const int* Din, const int* H, void* const* dh,
-                                   const int* dh_dtype, int compute_dtype, const float* scale, void* const* z_frag,
-                                   const void* const* s_frag, float* const* dW, float* const* db, int gy_is_dz, void* workspace,
-                                   size_t workspace_bytes) {
+// launches [first_launch, first_launch + n_launches) of the sweep gcnpt_layers_bwd would enqueue (measurement: bench.py charges a launch
+// t(k) - t(k-1) from truncated steps; a partial sweep leaves partial results)
+extern "C" int gcnpt_layers_bwd_range(void* stream, int n_layers, const void* gy, const void* const* Y, const int* y_dtype,
+                                      const void* const* w_bwd, const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
+                                      const int32_t* ellT, int B, int T, const int* Din, const int* H, void* const* dh,
+                                      const int* dh_dtype, int compute_dtype, const float* scale, void* const* z_frag,
+                                      const void* const* s_frag, float* const* dW, float* const* db, int gy_is_dz, int first_launch,
+                                      int n_launches) {
+    GCNPT_REQUIRE(first_launch >= 0 && n_launches >= 0, "layers_bwd_range: negative range");
     return layers_bwd_impl(stream, n_layers, gy, Y, y_dtype, w_bwd, ell, rowT_ptr, colT_idx, ellT, B, T, Din, H, dh, dh_dtype, compute_dtype, scale,
-                           z_frag, s_frag, dW, db, gy_is_dz != 0, workspace, workspace_bytes);
+                           z_frag, s_frag, dW, db, gy_is_dz != 0, first_launch, n_launches);
 }

@@ -58,6 +58,7 @@ extern "C" int gcnpt_pack_weights_multi(void* stream, int n_layers, const float*
     if (dtype == GCNPT_BF16) hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(grid), dim3(256), 0, s, p);
     GCNPT_HIP_CHECK(hipGetLastError());
+    note_launch(grid, 256, 0, sizeof(p));
     return GCNPT_OK;
 }
 
@@ -89,11 +90,10 @@ int plan_weight_grad(WeightGradParams& p, const void* z_frag, const void* s_frag
     // (big batches, wg_budget 768: 4-wave workgroups, three per CU, so that every CU's L1 path streams fragments -- with one slice a
     // 128 x 300-token batch ran on 135 workgroups for 121 us)
     int want = std::max(1, std::min(ceil_div(p.nks, waves), wg_budget / std::max(blocks_in_launch, mb * nb)));
-    // GCNPT_DETERMINISTIC=1: one slice, i.e. every element of dW / db is summed by exactly ONE workgroup in a fixed order and meets
+    // GCNPT_OPT_DETERMINISTIC: one slice, i.e. every element of dW / db is summed by exactly ONE workgroup in a fixed order and meets
     // its zero-initialised accumulator in a single atomic add: run-to-run bit-identical gradients, as the reference's CPU / single-GPU
     // path gives, at the price of the split contraction's parallelism
-    const char* det = getenv("GCNPT_DETERMINISTIC");
-    if (det && det[0] == '1') want = 1;
+    if (option(GCNPT_OPT_DETERMINISTIC) == 1) want = 1;
     int slices = want >= 8 ? want / 8 * 8 : (want >= 4 ? 4 : (want >= 2 ? 2 : 1));
     p.ks_per_wg = ceil_div(p.nks, slices);
     p.mb = mb; p.nb = nb; p.slices = slices;
@@ -107,6 +107,7 @@ static int launch_weight_grad_cfg(hipStream_t s, const WeightGradMulti& mp) {
     const size_t lds = weight_grad_lds(NW);      // 49 / 98 KiB
     GCNPT_LDS_ATTR_ONCE((weight_grad_kernel<CT, NW, NT, KB>), 160 * 1024);
     hipLaunchKernelGGL((weight_grad_kernel<CT, NW, NT, KB>), dim3(mp.first[mp.n]), dim3(NW * WAVE), lds, s, mp);
+    note_launch(mp.first[mp.n], NW * WAVE, lds, sizeof(mp));
     GCNPT_HIP_CHECK(hipGetLastError());
     return GCNPT_OK;
 }
@@ -156,20 +157,3 @@ extern "C" int gcnpt_layer_bwd_weight(void* stream, const void* z_frag, const vo
     return gcnpt_layer_bwd_weight_multi(stream, 1, &z_frag, &s_frag, B, T, &Din, &H, &dW, &db, compute_dtype);
 }
 
-// weight gradients of the sentence-resident stack: dW_l += G_l^T h_l from the two per-sentence fragment images
-// (db_l is added by gcnpt_stack_bwd itself)
-extern "C" int gcnpt_stack_bwd_weight(void* stream, int n_layers, const void* const* g_frag, const void* const* h_frag, int B, int T,
-                                      int Din, int H, float* const* dW) {
-    GCNPT_REQUIRE(g_frag && h_frag && dW && n_layers >= 1 && n_layers <= 8, "stack_bwd_weight: bad argument");
-    GCNPT_REQUIRE(B > 0 && T > 0 && Din > 0 && H > 0, "stack_bwd_weight: sizes must be positive");
-    const int nks = B * ceil_div(T, 32);
-    WeightGradMulti mp{};
-    mp.n = n_layers;
-    for (int l = 0; l < n_layers; ++l) {
-        GCNPT_REQUIRE(g_frag[l] && h_frag[l] && dW[l], "stack_bwd_weight: null pointer (layer %d)", l);
-        const int din_l[1] = {l == 0 ? Din : H}, h_l[1] = {H};
-        mp.first[l + 1] = mp.first[l] + plan_weight_grad(mp.l[l], g_frag[l], h_frag[l], nks, l == 0 ? Din : H, H, dW[l], nullptr,
-                                                         n_layers * wg_blocks(1, din_l, h_l, wg_nt(nks)), wg_waves(n_layers, nks), wg_budget(nks), wg_nt(nks));
-    }
-    return launch_weight_grad((hipStream_t)stream, mp, GCNPT_BF16, wg_waves(n_layers, nks), wg_nt(nks));
-}

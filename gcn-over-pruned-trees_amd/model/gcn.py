@@ -16,12 +16,13 @@ direction, reached through the C-ABI of include/gcnpt.h.  Embeddings, the option
 the output MLP stay ordinary PyTorch-ROCm modules, as in the reference.
 
 New optional `opt` keys (defaults reproduce the reference): `gcn_dtype` = 'fp32' | 'bf16' (MFMA operand /
-activation storage type inside the layer stack), `gcn_fused` = False (bf16 only; True: run the whole stack with the
-sentence-resident one-launch-per-direction kernels when the shape fits; slower than one launch per layer at every batch size measured), `gcn_check_trees` = True (synchronise once per forward to
+activation storage type inside the layer stack), `gcn_check_trees` = True (synchronise once per forward to
 raise on malformed trees the way the reference does; False keeps the step free of host syncs), `gcn_packed` = False (True: the
 layer loop runs on token-packed rows, sum(len) instead of B*T, padding only at the module boundary), `gcn_graph_rng` = False
 (True: dropout seeds that survive hipGraph capture), `gcn_pool_handover` = True (layer stack + poolings as one op whose backward
-hands the top layer its dZ), `gcn_pack_with_trees` = True (the tree launch also packs the weights in a training step) -- with `gcn_check_trees=False` a whole training step of the no-LSTM
+hands the top layer its dZ), `gcn_pack_with_trees` = True (the tree launch also packs the weights in a training step),
+`gcn_reuse_packed_weights` = False (True: a TRAINING forward may reuse the packed weight images of the previous one while the weights'
+version counters stand still -- gradient accumulation; off by default because `p.data` updates do not bump them) -- with `gcn_check_trees=False` a whole training step of the no-LSTM
 model can be captured with torch.cuda.graph and replayed, see tests/test_gpu_parity.py::test_training_step_graph_capture).
 """
 import ctypes
@@ -162,13 +163,6 @@ class WeightPack(object):
                 _lib.ptr_array(self.wf), _lib.ptr_array(self.wb))
 
 
-def _layers_workspace(lib, L, B, T, dims, top_dtype, dev):
-    """Scratch for the big-batch layer path (include/gcnpt.h, gcnpt_layers_workspace_bytes); None when that path does not apply."""
-    ints = lambda v: (ctypes.c_int * L)(*v)  # noqa: E731
-    n = lib.gcnpt_layers_workspace_bytes(L, B, T, ints([k for _, k in dims]), ints([h for h, _ in dims]), _lib.dtype_code(top_dtype))
-    return torch.empty((n,), dtype=torch.uint8, device=dev) if n else None
-
-
 class _GCNLayersFn(torch.autograd.Function):
     """The reference's layer loop (model/gcn.py:266-393) as ONE autograd op over the per-layer kernels: one launch packs
     every layer's weights, one launch per layer and direction does the layer, one launch at the end of the backward sweep
@@ -192,7 +186,8 @@ class _GCNLayersFn(torch.autograd.Function):
         # the fragment-order images only change when an optimizer step (or a load_state_dict) rewrites a weight in place, which bumps
         # the tensor's version counter: a module passes its cache and eval() / gradient-accumulation forwards skip the pack launch;
         # a training step that builds its trees in the same forward gets them from that launch's side job (WeightPack)
-        cache = None if torch.cuda.is_current_stream_capturing() else cfg.get("wcache")     # (a captured step must contain its pack)
+        cache = None if torch.cuda.is_current_stream_capturing() else cfg.get("wcache")     # (a captured step must contain its pack;
+        # the module passes its cache only where reuse is safe, see GCN._cache_usable)
         key = WeightPack.key_of(Ws, compute, dev)
         pre = cfg.get("prepacked")
         if pre is not None and pre.key == key and pre.launched:
@@ -211,15 +206,14 @@ class _GCNLayersFn(torch.autograd.Function):
         g_ell = trees.empty_ell() if cfg["no_adj"] else trees.ell
         outs = [torch.empty(lead + (H,), dtype=cfg["out_dtype"] if l == L - 1 else cfg["mid_dtype"], device=dev) for l, (H, _) in enumerate(dims)]
         s_frag = [torch.empty((lib.gcnpt_frag_bytes(rows, K, compute),), **u8) if need_w else None for _, K in dims]
-        # every layer's launch from ONE native call (gcnpt_layers_fwd_ws): no interpreter time between the launches.  Big batches get a
-        # scratch workspace and run every layer as gather + matrix launch (csrc/rowsplit_kernels.hip); ws None: the row-tile kernels
-        ws = _layers_workspace(lib, L, B, T, dims, outs[-1].dtype, dev)
-        _lib.check(lib.gcnpt_layers_fwd_ws(
+        # every layer's launch from ONE native call (gcnpt_layers_fwd): no interpreter time between the launches
+        _lib.check(lib.gcnpt_layers_fwd(
             st, L, _lib.ptr(x), _lib.dtype_code(x.dtype), _lib.ptr_array(wf), _lib.ptr_array(b32), _lib.ptr(trees.row_ptr),
             _lib.ptr(trees.col_idx), _lib.ptr(g_ell), _lib.ptr(trees.ell), B, T, ints([k for _, k in dims]), ints([h for h, _ in dims]),
             _lib.ptr_array(outs), ints([_lib.dtype_code(o.dtype) for o in outs]), compute, (ctypes.c_float * L)(*cfg["drop_p"]),
-            (ctypes.c_uint64 * L)(*cfg["seed"]), _lib.ptr_array(s_frag), _lib.ptr(cfg.get("seed_dev")), _lib.ptr(ws),
-            ws.numel() if ws is not None else 0))
+            (ctypes.c_uint64 * L)(*cfg["seed"]), _lib.ptr_array(s_frag), _lib.ptr(cfg.get("seed_dev"))))
+        if cfg.get("acts") is not None:
+            cfg["acts"].extend(outs)          # every layer's stored output (what the backward reads): tests drive the oracle's backward with them
         ctx.trees, ctx.cfg, ctx.dims, ctx.shape, ctx.need_w = trees, cfg, dims, (B, T, Din, L), need_w
         ctx.rows, ctx.lead = rows, lead
         ctx.x_dtype = x.dtype
@@ -271,15 +265,13 @@ class _GCNLayersFn(torch.autograd.Function):
             dWs = [torch.empty((H, K), dtype=torch.float32, device=dev) for H, K in dims]       # cleared by bwd_data, filled at the end
             dbs = [torch.empty((H,), dtype=torch.float32, device=dev) for H, _ in dims]
         ints = lambda v: (ctypes.c_int * L)(*v)  # noqa: E731
-        # the backward sweep and all weight gradients from ONE native call (gcnpt_layers_bwd_ws; gy_is_dz: its first tensor already is dZ)
-        ws = _layers_workspace(lib, L, B, T, dims, outs[-1].dtype, dev)
-        _lib.check(lib.gcnpt_layers_bwd_ws(
+        # the backward sweep and all weight gradients from ONE native call (gcnpt_layers_bwd; _bwd_dz: its first tensor already is dZ)
+        _lib.check((lib.gcnpt_layers_bwd if pool is None else lib.gcnpt_layers_bwd_dz)(
             st, L, _lib.ptr(g), _lib.ptr_array(list(outs)), ints([_lib.dtype_code(o.dtype) for o in outs]), _lib.ptr_array(list(wb)),
             _lib.ptr(trees.ell), _lib.ptr(trees.rowT_ptr), _lib.ptr(trees.colT_idx), _lib.ptr(g_ellT), B, T, ints([k for _, k in dims]),
             ints([h for h, _ in dims]), _lib.ptr_array(dhs), ints([_lib.dtype_code(t) for t in in_dtypes]), compute,
             (ctypes.c_float * L)(*scales), _lib.ptr_array(z_frag) if want_w else None, _lib.ptr_array(list(s_frag)) if want_w else None,
-            _lib.ptr_array(dWs) if want_w else None, _lib.ptr_array(dbs) if want_w else None, 0 if pool is None else 1, _lib.ptr(ws),
-            ws.numel() if ws is not None else 0))
+            _lib.ptr_array(dWs) if want_w else None, _lib.ptr_array(dbs) if want_w else None))
         g = dhs[0]
         grads = [None] * (2 * L)
         if want_w:
@@ -290,11 +282,11 @@ class _GCNLayersFn(torch.autograd.Function):
 
 
 def gcn_layers(x, weights, biases, trees, drop_p=None, seeds=None, compute_dtype=torch.float32, out_dtype=torch.float32, no_adj=False,
-               seed_dev=None, wcache=None, pool=None, prepacked=None):
+               seed_dev=None, wcache=None, pool=None, prepacked=None, acts=None):
     """
     The reference's whole layer loop (model/gcn.py:266-393) over the per-layer kernels.  x [B,T,Din] float32/bfloat16 CUDA;
     weights / biases: lists of the nn.Linear parameters (any widths that chain); drop_p[l]: dropout applied to the output of
-    layer l (0 for the last); wcache: an empty dict the caller keeps -- the packed weight images are reused while the weights'
+    layer l (0 for the last); acts: None or a list that receives every layer's stored output; wcache: an empty dict the caller keeps -- the packed weight images are reused while the weights'
     version counters stand still; pool: see below.  compute_dtype float32 = exact fp32 MFMA (activations stay float32), bfloat16 = bf16 operands
     and bf16 activations between the layers, fp32 accumulation; the last layer's output has out_dtype.
     """
@@ -307,7 +299,7 @@ def gcn_layers(x, weights, biases, trees, drop_p=None, seeds=None, compute_dtype
         x, out_dtype = (x.float() if x.dtype != torch.float32 else x), torch.float32
     cfg = dict(drop_p=[float(p) for p in (drop_p or [0.0] * L)], seed=[int(s) for s in (seeds or [0] * L)], compute=compute,
                mid_dtype=torch.float32 if compute == _lib.F32 else torch.bfloat16, out_dtype=out_dtype, no_adj=bool(no_adj),
-               seed_dev=seed_dev, wcache=wcache, pool=None, prepacked=prepacked)
+               seed_dev=seed_dev, wcache=wcache, pool=None, prepacked=prepacked, acts=acts)
     if pool is not None:
         # pool = (subj_pos, obj_pos, 'max' | 'avg' | 'sum'): the op returns float32 [B, 3H] = pool3(h_L, trees.pool_mask, subj_pos, obj_pos)
         # instead of h_L (padded layout only)
@@ -319,94 +311,11 @@ def gcn_layers(x, weights, biases, trees, drop_p=None, seeds=None, compute_dtype
     return _GCNLayersFn.apply(x, trees, cfg, *params)
 
 
-class _GCNStackFn(torch.autograd.Function):
-    """The whole L-layer stack as ONE op: sentence-resident kernels (csrc/stack_kernels.hip), one launch per direction."""
-
-    @staticmethod
-    def forward(ctx, x, trees, cfg, *params):
-        Ws, bs = params[0::2], params[1::2]
-        L = len(Ws)
-        B, T, Din = x.shape
-        H = Ws[0].shape[0]
-        lib, st, dev = _lib.lib(), _lib.stream(), x.device
-        x = x.contiguous()
-        dims = [(H, Din if l == 0 else H) for l in range(L)]
-        w32 = [w.detach().to(torch.float32).contiguous() for w in Ws]
-        b32 = [b.detach().to(torch.float32).contiguous() for b in bs]
-        u8 = dict(dtype=torch.uint8, device=dev)
-        wf = [torch.empty((lib.gcnpt_packed_bytes(h, k, _lib.BF16),), **u8) for h, k in dims]
-        wb = [torch.empty((lib.gcnpt_packed_bytes(k, h, _lib.BF16),), **u8) for h, k in dims]
-        ints = lambda v: (ctypes.c_int * L)(*v)  # noqa: E731
-        _lib.check(lib.gcnpt_pack_weights_multi(st, L, _lib.ptr_array(w32), ints([h for h, _ in dims]), ints([k for _, k in dims]),
-                                                _lib.BF16, _lib.ptr_array(wf), _lib.ptr_array(wb)))
-        need_w = any(p.requires_grad for p in params)
-        h_out = [torch.empty((B, T, H), dtype=torch.bfloat16 if l < L - 1 else cfg["out_dtype"], device=dev) for l in range(L)]
-        h_frag = [torch.empty((lib.gcnpt_stack_frag_bytes(B, T, k),), **u8) for _, k in dims] if need_w else [None] * L
-        g_ell = trees.empty_ell() if cfg["no_adj"] else trees.ell
-        _lib.check(lib.gcnpt_stack_fwd(
-            st, L, _lib.ptr(x), _lib.dtype_code(x.dtype), _lib.ptr_array(wf), _lib.ptr_array(b32), _lib.ptr(trees.row_ptr),
-            _lib.ptr(trees.col_idx), _lib.ptr(g_ell), _lib.ptr(trees.ell), B, T, Din, H, _lib.ptr_array(h_out),
-            _lib.dtype_code(cfg["out_dtype"]), (ctypes.c_float * L)(*cfg["drop_p"]), (ctypes.c_uint64 * L)(*cfg["seed"]),
-            _lib.ptr_array(h_frag), None, None, _lib.ptr(cfg.get("seed_dev"))))
-        ctx.save_for_backward(*h_out, *wb, *[f for f in h_frag if f is not None])
-        ctx.trees, ctx.cfg, ctx.dims, ctx.shape, ctx.need_w = trees, cfg, dims, (B, T, Din, H, L), need_w
-        ctx.x_dtype = x.dtype
-        ctx.param_dtypes = [p.dtype for p in params]
-        return h_out[-1]
-
-    @staticmethod
-    def backward(ctx, gout):
-        B, T, Din, H, L = ctx.shape
-        saved = ctx.saved_tensors
-        h_out, wb, h_frag = saved[:L], saved[L:2 * L], saved[2 * L:]
-        trees, cfg = ctx.trees, ctx.cfg
-        lib, st, dev = _lib.lib(), _lib.stream(), gout.device
-        gout = gout.to(h_out[-1].dtype).contiguous()
-        want_w = ctx.need_w and any(ctx.needs_input_grad[3:])
-        dx = torch.empty((B, T, Din), dtype=ctx.x_dtype, device=dev) if ctx.needs_input_grad[0] else None
-        g_frag, dWs, dbs = [None] * L, [None] * L, [None] * L
-        if want_w:
-            g_frag = [torch.empty((lib.gcnpt_stack_frag_bytes(B, T, H),), dtype=torch.uint8, device=dev) for _ in range(L)]
-            sizes = [h * k for h, k in ctx.dims] + [h for h, _ in ctx.dims]
-            flat = torch.zeros((sum(sizes),), dtype=torch.float32, device=dev)          # one memset for every accumulator
-            parts = torch.split(flat, sizes)
-            dWs = [parts[l].view(ctx.dims[l]) for l in range(L)]
-            dbs = list(parts[L:])
-        scale = [1.0 / (1.0 - p) if p > 0 else 1.0 for p in cfg["drop_p"]]
-        g_ellT = trees.empty_ell() if cfg["no_adj"] else trees.ellT
-        _lib.check(lib.gcnpt_stack_bwd(
-            st, L, _lib.ptr(gout), _lib.ptr_array(h_out), _lib.dtype_code(gout.dtype), _lib.ptr_array(wb), _lib.ptr(trees.ell),
-            _lib.ptr(trees.rowT_ptr), _lib.ptr(trees.colT_idx), _lib.ptr(g_ellT), B, T, Din, H, _lib.ptr(dx),
-            _lib.dtype_code(ctx.x_dtype), (ctypes.c_float * L)(*scale), _lib.ptr_array(g_frag), _lib.ptr_array(dbs)))
-        grads = [None] * (2 * L)
-        if want_w:
-            _lib.check(lib.gcnpt_stack_bwd_weight(st, L, _lib.ptr_array(g_frag), _lib.ptr_array(list(h_frag)), B, T, Din, H,
-                                                  _lib.ptr_array(dWs)))
-            for l in range(L):
-                grads[2 * l] = dWs[l].to(ctx.param_dtypes[2 * l])
-                grads[2 * l + 1] = dbs[l].to(ctx.param_dtypes[2 * l + 1])
-        return (dx, None, None) + tuple(grads)
-
-
-def gcn_stack_supported(T, Din, H, n_layers, compute_dtype=torch.bfloat16):
-    """Whether the sentence-resident one-launch-per-direction kernels handle this shape (else: one gcn_layer per layer)."""
-    return bool(_lib.lib().gcnpt_stack_supported(int(T), int(Din), int(H), int(n_layers), _lib.dtype_code(compute_dtype)))
-
-
-def gcn_stack(x, weights, biases, trees, drop_p=None, seeds=None, out_dtype=torch.float32, no_adj=False, seed_dev=None):
-    """
-    The reference's whole layer loop (model/gcn.py:266-393) as one op.  x [B,T,Din] float32/bfloat16 CUDA; weights /
-    biases: lists of the nn.Linear parameters; drop_p[l]: dropout applied to the output of layer l (0 for the last).
-    bf16 MFMA operands with fp32 accumulation; needs gcn_stack_supported(T, Din, H, L).
-    """
-    if not isinstance(trees, PrunedTrees):
-        raise TypeError("trees must be a PrunedTrees (see model.tree.prune_to_csr / adj_to_csr)")
-    _lib.require_gpu(x)
-    L = len(weights)
-    cfg = dict(drop_p=[float(p) for p in (drop_p or [0.0] * L)], seed=[int(s) for s in (seeds or [0] * L)],
-               out_dtype=out_dtype, no_adj=bool(no_adj), seed_dev=seed_dev)
-    params = [t for wb in zip(weights, biases) for t in wb]
-    return _GCNStackFn.apply(x, trees, cfg, *params)
+def gcn_layers_with_acts(x, weights, biases, trees, **kw):
+    """gcn_layers plus the list of every layer's stored output (detached; the last one is the op's result before any pooling)."""
+    acts = []
+    out = gcn_layers(x, weights, biases, trees, acts=acts, **kw)
+    return out, [a.detach() for a in acts]
 
 
 class _EmbedFn(torch.autograd.Function):
@@ -653,9 +562,7 @@ class GCN(nn.Module):
             return None
         Ws = [lin.weight for lin in self.W]
         compute = _lib.dtype_code(self.compute_dtype)
-        if B is not None and self._stack_path(B, T, Ws[0].shape[1]):
-            return None
-        if not torch.cuda.is_current_stream_capturing() and self._wcache.get("key") == WeightPack.key_of(Ws, compute, dev):
+        if self._cache_usable() and self._wcache.get("key") == WeightPack.key_of(Ws, compute, dev):
             return None
         return WeightPack(Ws, compute, dev)
 
@@ -663,11 +570,22 @@ class GCN(nn.Module):
         """The next forward takes the weight images from `pack` (a WeightPack a tree launch has filled); None clears it."""
         self._prepacked = pack
 
-    def _stack_path(self, B, T, Din):
-        # the sentence-resident kernels (one launch per direction) are opt-in: since the row-tile kernel runs big batches with 4-wave
-        # workgroups, one launch per layer is faster at every batch size measured (profiles/r02_stack_vs_layers.json: B = 256 ... 1024)
-        return bool(self.compute_dtype == torch.bfloat16 and self.opt.get('gcn_fused', False)
-                    and gcn_stack_supported(T, Din, self.mem_dim, self.layers))
+    def _cache_usable(self):
+        """Whether this forward may reuse the packed weight images of an earlier one.  The cache is keyed on the weights' storage and
+        version counters, and an in-place update through `p.data` (the reference's own MyAdagrad does that, utils/torch_utils.py:84-88;
+        so do EMA / clipping code) changes the values WITHOUT bumping the counter: a training forward therefore always re-packs (one
+        4 us launch, or none when the tree launch carries it), unless opt['gcn_reuse_packed_weights'] says the caller knows its weights
+        stand still between forwards (gradient accumulation).  eval() / no_grad forwards reuse: call invalidate_weight_cache() after
+        writing to `p.data` by hand there."""
+        if torch.cuda.is_current_stream_capturing():
+            return False                                                  # a captured step must contain its pack
+        ok = (not self.training) or (not torch.is_grad_enabled()) or bool(self.opt.get('gcn_reuse_packed_weights', False))
+        if not ok:
+            self._wcache.clear()      # a training forward is (presumably) followed by an update: what an earlier eval() cached is void after it
+        return ok
+
+    def invalidate_weight_cache(self):
+        self._wcache.clear()
 
     def _dropout_plan(self):
         """(p per layer, seed per layer, device seed word or None) for this forward -- gcn.py:393: every layer but the last."""
@@ -804,7 +722,8 @@ class GCN(nn.Module):
             Ws, bs = [lin.weight for lin in self.W], [lin.bias for lin in self.W]
             xp = packed.pack_rows(gcn_inputs if gcn_inputs.dtype in (torch.float32, torch.bfloat16) else gcn_inputs.float())
             pre, self._prepacked = getattr(self, "_prepacked", None), None
-            hp = gcn_layers(xp, Ws, bs, packed, ps, seeds, self.compute_dtype, torch.float32, no_adj, seed_dev, self._wcache, prepacked=pre)
+            wcache = self._wcache if self._cache_usable() else None
+            hp = gcn_layers(xp, Ws, bs, packed, ps, seeds, self.compute_dtype, torch.float32, no_adj, seed_dev, wcache, prepacked=pre)
             return packed.unpack_rows(hp), packed.padded.pool_mask
         trees = adj if isinstance(adj, PrunedTrees) else adj_to_csr(adj, want_label=False)   # gcn.py:260-262
         no_adj = bool(self.opt.get('no_adj', False))                                           # gcn.py:264-265
@@ -812,16 +731,14 @@ class GCN(nn.Module):
         B, T, Din = x.shape
         ps, seeds, seed_dev = self._dropout_plan()
         Ws, bs = [lin.weight for lin in self.W], [lin.bias for lin in self.W]
-        if self._stack_path(B, T, Din):
-            # whole stack in one launch per direction (sentence-resident kernels)
-            return gcn_stack(x, Ws, bs, trees, ps, seeds, torch.float32, no_adj, seed_dev), trees.pool_mask
         pre, self._prepacked = getattr(self, "_prepacked", None), None      # a request serves ONE forward
+        wcache = self._wcache if self._cache_usable() else None
         req = getattr(self, "_pool_req", None)
         if req is not None:
             # GCNRelationModel asked for the pooled vectors directly (it would pool h next, gcn.py:116-121): stack + pooling as one op
-            return _Pooled(gcn_layers(x, Ws, bs, trees, ps, seeds, self.compute_dtype, torch.float32, no_adj, seed_dev, self._wcache, pool=req,
+            return _Pooled(gcn_layers(x, Ws, bs, trees, ps, seeds, self.compute_dtype, torch.float32, no_adj, seed_dev, wcache, pool=req,
                                       prepacked=pre)), trees.pool_mask
-        x = gcn_layers(x, Ws, bs, trees, ps, seeds, self.compute_dtype, torch.float32, no_adj, seed_dev, self._wcache, prepacked=pre)
+        x = gcn_layers(x, Ws, bs, trees, ps, seeds, self.compute_dtype, torch.float32, no_adj, seed_dev, wcache, prepacked=pre)
         return x, trees.pool_mask
 
 

@@ -7,7 +7,11 @@ the sentence-sharded scheme of SURVEY.md 8(e):
     global batch is split BY SENTENCE and every rank prunes + runs the layer stack on its shard with
     no data-path collective;
   * the only exchange is the parameter gradient: ONE flat fp32 bucket per step, all-reduced
-    (messages are 0.45-4.8 MB, i.e. latency-bound on xGMI, so one bucket and overlap with compute);
+    (messages are 0.45-4.8 MB, i.e. latency-bound on xGMI, so one bucket), followed by the optimizer step -- synchronous SGD, as the
+    reference updates every step (train.py:224-227);
+  * the word-embedding table is fine-tuned as a whole by default (model/gcn.py:45,84-88; train.py:61) but a batch touches at most
+    B*T of its V rows: its gradient is exchanged as (row ids, rows) by all-gather (SparseRowExchange) instead of all-reducing the
+    dense [V,300] tensor (~60 MB per step at TACRED's vocabulary against < 1 MB);
   * pooled sentence vectors are all-gathered only when a consumer needs the global batch
     (predict()'s concatenate/unsort, model/trainer.py:121-123).
 
@@ -60,8 +64,10 @@ class FlatGradBucket(object):
     are unequal; with equal shards use the default 1/world.
     """
 
-    def __init__(self, params):
-        self.params = [p for p in params if p.requires_grad]
+    def __init__(self, params, exclude=()):
+        """exclude: parameters exchanged some other way (the embedding table of SparseRowExchange)."""
+        skip = {id(p) for p in exclude}
+        self.params = [p for p in params if p.requires_grad and id(p) not in skip]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros((n,), dtype=torch.float32, device=dev)
@@ -144,6 +150,92 @@ class OverlappedAllReduce(object):
     def finish(self):
         for k in range(len(self.buckets)):
             self.before_write(k)
+
+
+class SparseRowExchange(object):
+    """
+    Data-parallel exchange of a ROW-SPARSE gradient -- the word-embedding table's (model/gcn.py:45; fine-tuned as a whole unless
+    `topn` says otherwise, gcn.py:84-88): every rank contributes the rows its shard touched, as (row ids, rows), through two
+    all-gathers (padded to the largest contribution), and every rank ends up with the same coalesced rank-sum.  Volume per step:
+    world x touched x (E + 1) words instead of V x E.
+
+        ids, rows = SparseRowExchange(dist).exchange(idx, g)        # idx int64 [n], g [n, E]: gradient of table[idx]
+        table.grad = ex.as_sparse(ids, rows, table.shape)             # for an optimizer that takes sparse gradients (SGD, Adagrad)
+        ex.add_into(dense_grad, ids, rows)                            # or: the dense gradient a dense all-reduce would have given
+
+    topn (gcn.py:84-88, torch_utils.keep_partial_grad): rows >= topn get no gradient; padding_idx rows neither (nn.Embedding).
+    weight: this rank's share of the global batch (shard size / global size); default: plain sum.
+    """
+
+    def __init__(self, dist, topn=None, padding_idx=None):
+        self.dist, self.topn, self.padding_idx = dist, topn, padding_idx
+        self.last_volume_bytes = 0
+
+    def local_rows(self, idx, g):
+        """Coalesce this rank's contribution: unique ids (ascending) and the sum of their gradient rows."""
+        idx = idx.reshape(-1)
+        g = g.reshape(idx.numel(), -1)
+        keep = torch.ones_like(idx, dtype=torch.bool)
+        if self.topn is not None:
+            keep &= idx < self.topn
+        if self.padding_idx is not None:
+            keep &= idx != self.padding_idx
+        idx, g = idx[keep], g[keep]
+        ids, inv = torch.unique(idx, return_inverse=True)
+        rows = torch.zeros((ids.numel(), g.shape[1]), dtype=g.dtype, device=g.device)
+        rows.index_add_(0, inv, g)
+        return ids, rows
+
+    def exchange(self, idx, g, weight=None):
+        dist = self.dist
+        ids, rows = self.local_rows(idx, g)
+        if weight is not None:
+            rows = rows * weight
+        world = dist.get_world_size()
+        n = torch.tensor([ids.numel()], dtype=torch.int64, device=ids.device)
+        counts = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(counts, n)
+        counts = [int(c.item()) for c in counts]
+        width = max(max(counts), 1)
+        ids_pad = torch.zeros((width,), dtype=torch.int64, device=ids.device)
+        rows_pad = torch.zeros((width, rows.shape[1]), dtype=rows.dtype, device=rows.device)
+        ids_pad[: ids.numel()] = ids
+        rows_pad[: ids.numel()] = rows
+        all_ids = [torch.empty_like(ids_pad) for _ in range(world)]
+        all_rows = [torch.empty_like(rows_pad) for _ in range(world)]
+        dist.all_gather(all_ids, ids_pad)
+        dist.all_gather(all_rows, rows_pad)
+        cat_ids = torch.cat([a[:c] for a, c in zip(all_ids, counts)])
+        cat_rows = torch.cat([a[:c] for a, c in zip(all_rows, counts)])
+        out_ids, inv = torch.unique(cat_ids, return_inverse=True)                  # rank order is fixed: every rank sums in the same order
+        out_rows = torch.zeros((out_ids.numel(), cat_rows.shape[1]), dtype=cat_rows.dtype, device=cat_rows.device)
+        out_rows.index_add_(0, inv, cat_rows)
+        self.last_volume_bytes = world * width * (rows.shape[1] * rows.element_size() + 8)
+        return out_ids, out_rows
+
+    @staticmethod
+    def as_sparse(ids, rows, shape):
+        return torch.sparse_coo_tensor(ids.unsqueeze(0), rows, size=tuple(shape)).coalesce()
+
+    @staticmethod
+    def add_into(dense, ids, rows):
+        dense.index_add_(0, ids, rows.to(dense.dtype))
+        return dense
+
+
+def sync_sgd_step(dist, bucket, lr, sparse=(), weight=None):
+    """One synchronous data-parallel SGD update, the reference's per-step optimizer.step() (train.py:224-227; plain SGD is its default,
+    train.py:82): all-reduce the flat bucket (FlatGradBucket; weight = this rank's share of the global batch, default 1/world), exchange
+    the row-sparse gradients [(param, idx, g, SparseRowExchange)], then p -= lr * grad on every rank.  After it every rank holds the
+    same weights a single process would hold after the same step on the concatenated batch."""
+    bucket.all_reduce(dist, weight=weight)
+    w = weight if weight is not None else 1.0 / dist.get_world_size()
+    with torch.no_grad():
+        for p, v in zip(bucket.params, bucket.views):
+            p.add_(v, alpha=-lr)
+        for p, idx, g, ex in sparse:
+            ids, rows = ex.exchange(idx, g, weight=w)
+            p.index_add_(0, ids, rows.to(p.dtype), alpha=-lr)
 
 
 def all_gather_pooled(dist, pooled, sizes=None):

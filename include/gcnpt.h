@@ -11,7 +11,8 @@
  *
  * Conventions
  *   - plain C types only; every pointer marked [dev] is a DEVICE pointer owned by the caller
- *     (PyTorch-ROCm allocations in practice); the library allocates nothing and keeps no global state.
+ *     (PyTorch-ROCm allocations in practice); the library allocates nothing and keeps no global state except the option
+ *     table below (gcnpt_set_option), which no call reads from the environment.
  *   - `stream` is a hipStream_t passed as void*.  Every call only ENQUEUES work on that stream and never
  *     synchronises, so calls can be captured into a hipGraph.
  *   - return value: 0 = enqueued, <0 = error (GCNPT_E_*); the text is in gcnpt_last_error() (thread-local).
@@ -40,7 +41,7 @@
 extern "C" {
 #endif
 
-#define GCNPT_ABI_VERSION 5
+#define GCNPT_ABI_VERSION 6
 
 /* element types of activation / gradient buffers and of the MFMA operands */
 #define GCNPT_F32 0
@@ -63,6 +64,31 @@ extern "C" {
 
 int gcnpt_abi_version(void);
 const char* gcnpt_last_error(void);
+
+/* ---- process-wide options (the only mutable state of the library) ---------------------------------------------------------
+ * Kernel-selection and numerics switches that are not per-call arguments.  The defaults come from the environment variables of
+ * the same names ONCE, when the library is loaded; nothing reads the environment afterwards.  Setting an option is a relaxed
+ * atomic store: it affects calls that start after it.
+ *   GCNPT_OPT_DETERMINISTIC (env GCNPT_DETERMINISTIC, default 0)  1: every element of dW / db is summed by exactly ONE workgroup in a
+ *       fixed order (one contraction slice): run-to-run bit-identical weight gradients, as the reference's single-device autograd
+ *       gives (model/gcn.py:270-271), at the price of the split contraction's parallelism
+ *   GCNPT_OPT_FOUR_WAVES    (env GCNPT_WAVES4, default -1 = by batch size)  0 / 1 forces the 8- / 4-wave form of the layer kernel
+ *   GCNPT_OPT_SIDE_TILES    (env GCNPT_SIDE_TILES, default 192)  batches of up to this many 32-row tiles carry their weight gradients
+ *       as passengers of the backward-data launches (gcnpt_layers_bwd) */
+#define GCNPT_OPT_DETERMINISTIC 0
+#define GCNPT_OPT_FOUR_WAVES 1
+#define GCNPT_OPT_SIDE_TILES 2
+#define GCNPT_OPT_COUNT 3
+int gcnpt_set_option(int option, int value);
+int gcnpt_get_option(int option);
+
+/* ---- measurement aids (no reference counterpart) --------------------------------------------------------------
+ * gcnpt_last_launch: grid, workgroup size, dynamic LDS bytes and kernel-argument bytes of the calling thread's most recent launch of
+ * the layer path (pack, layer forward / backward-data, weight gradient).  gcnpt_launch_empty: enqueues a kernel of that shape whose
+ * body returns at entry.  bench.py's launch-floor leg replays a step's launches with empty bodies to show how much of a step is
+ * dispatch / ramp / drain rather than kernel work. */
+int gcnpt_last_launch(int* grid, int* block, int* lds_bytes, int* kernarg_bytes);
+int gcnpt_launch_empty(void* stream, int grid, int block, int lds_bytes, int kernarg_bytes);
 
 /* ---- A1-A4: model/gcn.py:96-110 (lengths, head_to_tree x B, tree_to_adj x B, upload) ------------------
  * One workgroup per sentence prunes the dependency tree to the tokens within `prune_k` of the
@@ -177,7 +203,8 @@ int gcnpt_layer_bwd_weight_multi(void* stream, int n_layers, const void* const* 
  *   dh_dtype[l] (= y_dtype[l-1] for l > 0; dh[0] may be NULL when the input needs no gradient; dh[l] for l > 0 is scratch for
  *   the caller: it holds dZ of layer l-1, see the hand-over above); scale[l] = 1/(1-p_l) of the
  *   dropout layer l's forward applied.  z_frag == NULL: no weight gradients (dW, db, s_frag unused); otherwise z_frag[l],
- *   s_frag[l], dW[l], db[l] for every layer, and the L weight gradients follow in ONE launch (gcnpt_layer_bwd_weight_multi). */
+ *   s_frag[l], dW[l], db[l] for every layer; the weight gradients ride in the backward-data launches (small batches, see
+ *   gcnpt_layer_bwd_data_ex) or follow in ONE launch (gcnpt_layer_bwd_weight_multi). */
 int gcnpt_layers_fwd(void* stream, int n_layers, const void* x, int x_dtype, const void* const* w_fwd, const float* const* bias,
                      const int32_t* row_ptr, const int32_t* col_idx, const int32_t* ell, const int32_t* deg_ell, int B, int T,
                      const int* Din, const int* H, void* const* out, const int* out_dtype, int compute_dtype,
@@ -187,47 +214,6 @@ int gcnpt_layers_bwd(void* stream, int n_layers, const void* gy, const void* con
                      const int32_t* ellT, int B, int T, const int* Din, const int* H, void* const* dh, const int* dh_dtype,
                      int compute_dtype, const float* scale, void* const* z_frag, const void* const* s_frag, float* const* dW,
                      float* const* db);
-
-/* ---- optional: two stacked layers' FORWARD in ONE launch without any inter-workgroup wait (csrc/fused_kernels.hip) -----------
- * The layer loop of model/gcn.py:266-393 for num_layers = 2 (the reference's default, train.py:57) without the kernel boundary
- * between the layers: a workgroup owns 32 token rows and computes layer 0 also for the neighbours of its rows that other
- * workgroups own (they lie within T-1 rows: the adjacency is block diagonal, model/tree.py:167-204), so layer 1 gathers from
- * its own LDS.  bf16 MFMA operands and bf16 rows between the layers, fp32 accumulation; every output is bit-identical to two
- * gcnpt_layer_fwd calls.  MEASURED SLOWER than two launches at B=50, T=100 (32 us against 18 us, DESIGN.md section 5: the halo is
- * ~50 % extra first-layer rows and the gather/epilogue phases are VALU-bound), so gcnpt_layers_fwd does NOT use it; it stays as
- * a tested opt-in.  gcnpt_fused2_supported: 1 when the shape fits (widths multiples of 8, Din/32 and H0/32 k-steps among the
- * instantiated pairs, 32 + 2 (T-1) <= 256 window rows, LDS).
- *   gcnpt_fused2_fwd: x [B*T,Din] bf16 -> h1 [B*T,H[0]] bf16 (layer 0's output, dropout drop_p[0] applied) and h2 [B*T,H[1]] of
- *     out_dtype; w_fwd / bias / drop_p / seed / s_frag: host arrays of 2 entries, meaning as in gcnpt_layer_fwd. */
-int gcnpt_fused2_supported(int T, int Din, int H0, int H1, int out_dtype, int compute_dtype);
-int gcnpt_fused2_fwd(void* stream, const void* x, const void* const* w_fwd, const float* const* bias, const int32_t* row_ptr,
-                     const int32_t* col_idx, const int32_t* ell, const int32_t* deg_ell, int B, int T, int Din, const int* H, void* h1,
-                     void* h2, int out_dtype, const float* drop_p, const uint64_t* seed, void* const* s_frag, const uint64_t* seed_dev);
-
-/* ---- optional: the whole L-layer stack in ONE launch per direction (sentence-resident kernels) ---------------
- * A workgroup owns a whole sentence (T <= 112 rows) and runs every layer with the inter-layer activations in LDS;
- * aggregation is done after the matrix product ((A+I)(h W^T)), LDS -> LDS, so nothing is ever gathered from HBM.
- * bf16 MFMA operands / fp32 accumulate only; gcnpt_stack_supported() says whether a shape fits, otherwise use the
- * per-layer entry points above (which these agree with to rounding).  Host arrays of n_layers device pointers.
- *   gcnpt_stack_fwd : x [B*T,Din] -> h_out[l] = h_{l+1} [B*T,H] (bf16 for l < L-1, out_dtype for the last);
- *                     h_frag[l]: NULL or gcnpt_stack_frag_bytes(B,T,width_l) bytes, the fragment image of the layer
- *                     INPUT h_l (k-steps of 32 rows per sentence); zero_dW / zero_db: NULL or accumulators to clear.
- *   gcnpt_stack_bwd : dY, Y[l] = h_{l+1} -> dx (NULL = not wanted), g_frag[l] = image of G_l = (A+I)^T dZ_l,
- *                     db[l] += 2 sum dZ_l  (scale[l] = 1/(1-drop_p[l]) of the dropout applied to h_{l+1})
- *   gcnpt_stack_bwd_weight : dW[l] += G_l^T h_l  (both images; dW cleared beforehand, e.g. by gcnpt_stack_fwd) */
-int gcnpt_stack_supported(int T, int Din, int H, int n_layers, int compute_dtype);
-size_t gcnpt_stack_frag_bytes(int B, int T, int width);
-int gcnpt_stack_fwd(void* stream, int n_layers, const void* x, int x_dtype, const void* const* w_fwd,
-                    const float* const* bias, const int32_t* row_ptr, const int32_t* col_idx, const int32_t* ell,
-                    const int32_t* deg_ell, int B, int T, int Din, int H, void* const* h_out, int out_dtype,
-                    const float* drop_p, const uint64_t* seed, void* const* h_frag, float* const* zero_dW,
-                    float* const* zero_db, const uint64_t* seed_dev);
-int gcnpt_stack_bwd(void* stream, int n_layers, const void* dY, const void* const* Y, int g_dtype,
-                    const void* const* w_bwd, const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
-                    const int32_t* ellT, int B, int T, int Din, int H, void* dx, int dx_dtype, const float* scale,
-                    void* const* g_frag, float* const* db);
-int gcnpt_stack_bwd_weight(void* stream, int n_layers, const void* const* g_frag, const void* const* h_frag, int B, int T,
-                           int Din, int H, float* const* dW);
 
 /* ---- token-packed variable-length batches (north_star "packed") ----------------------------------------
  * The reference pads every batch to its longest sentence (data/loader.py:109-121, model/gcn.py:96-97,106): B*T token rows of
@@ -295,44 +281,29 @@ int gcnpt_layers_bwd_dz(void* stream, int n_layers, const void* dz_top, const vo
                         int compute_dtype, const float* scale, void* const* z_frag, const void* const* s_frag, float* const* dW,
                         float* const* db);
 
-/* gcnpt_layer_bwd_data for layer l that ALSO computes the weight gradient of the layer above it (up_*: that layer's two fragment images,
- * widths and accumulators, exactly gcnpt_layer_bwd_weight's arguments): for batches of up to 192 row tiles (6 144 token rows) the
- * gradient rides in the same launch, on the CUs that have no row tile (one launch boundary less on the step's critical path: the
- * last launch of a backward sweep is then the bottom layer's weight gradient alone); otherwise it is launched right after.
- * gcnpt_layers_bwd / _bwd_dz / _bwd_ws do this for every layer but the top one. */
-int gcnpt_layer_bwd_data_wgrad(void* stream, const void* dY, const void* Y, int g_dtype, const void* w_bwd, const int32_t* ell,
-                               const int32_t* rowT_ptr, const int32_t* colT_idx, const int32_t* ellT, int B, int T, int Din, int H,
-                               void* dh, int dh_dtype, int compute_dtype, float scale, void* z_frag, float* zero_dW, float* zero_db,
-                               const void* relu_src, float next_scale, int src_is_dz, const void* up_z_frag, const void* up_s_frag,
-                               int up_Din, int up_H, float* up_dW, float* up_db);
-
-/* EXPERIMENTAL, opt-in with the environment variable GCNPT_ROWSPLIT=1 (measured no faster than the default kernels).
- * Big batches (>= 16 384 token rows, bf16 compute): with a workspace the layer loop runs every layer as TWO launches -- a gather
- * that writes the rows aggregating at least one neighbour (plus the weight gradient's fragment image) and a matrix launch that shares
- * each weight fragment among 8-10 row tiles -- instead of one row-tile launch that pulls the whole weight matrix through its CU per
- * 32 rows (csrc/rowsplit_kernels.hip; same values bit for bit).  gcnpt_layers_workspace_bytes: bytes that path needs for this shape
- * (0: it does not apply or is not switched on, pass NULL); top_dtype = dtype of the top layer's output Y.  The workspace [dev] is scratch: nothing in it
- * outlives a call, one buffer serves forward and backward.  workspace NULL or smaller than asked for: exactly gcnpt_layers_fwd /
- * gcnpt_layers_bwd (gy_is_dz = 0) / gcnpt_layers_bwd_dz (gy_is_dz = 1).  reference: model/gcn.py:266-271, 390-393 and their autograd.
- * gcnpt_layer_fwd_ws / gcnpt_layer_bwd_data_ws: gcnpt_layer_fwd / gcnpt_layer_bwd_data with the same workspace (ask for the size with n_layers = 1). */
-size_t gcnpt_layers_workspace_bytes(int n_layers, int B, int T, const int* Din, const int* H, int top_dtype);
-int gcnpt_layer_fwd_ws(void* stream, const void* h, int h_dtype, const void* w_fwd, const float* bias, const int32_t* row_ptr,
-                       const int32_t* col_idx, const int32_t* ell, const int32_t* deg_ell, int B, int T, int Din, int H, void* out,
-                       int out_dtype, int compute_dtype, float drop_p, uint64_t seed, void* s_frag, const uint64_t* seed_dev,
-                       void* workspace, size_t workspace_bytes);
-int gcnpt_layer_bwd_data_ws(void* stream, const void* dY, const void* Y, int g_dtype, const void* w_bwd, const int32_t* ell,
+/* gcnpt_layer_bwd_data with the two extras the backward sweep of a SMALL batch (<= GCNPT_OPT_SIDE_TILES row tiles: a third of the CUs
+ * has no row tile) uses to get rid of its weight-gradient launches (model/gcn.py:270-271 differentiated; same sums as
+ * gcnpt_layer_bwd_weight):
+ *   down_z_frag / down_zero_dW / down_zero_db / down_Din   NULL / 0, or -- with relu_src given and dh_dtype == compute_dtype -- the
+ *       fragment image of the dZ this launch hands down (gcnpt_frag_bytes(B*T, Din, compute_dtype) bytes: it is the z_frag of the layer
+ *       BELOW, whose own launch then passes z_frag = NULL) and that layer's accumulators [Din x down_Din], [Din] to clear;
+ *   n_riders (0..2) weight gradients, each given by its two fragment images, widths and accumulators exactly as gcnpt_layer_bwd_weight
+ *       takes them (accumulators cleared by an EARLIER launch): they ride in this launch on the CUs without a row tile when the launch
+ *       is a src_is_dz one in a uniform precision, otherwise they are launched right behind it -- enqueued on return either way.
+ * gcnpt_layers_bwd / _bwd_dz use this for every layer: an L >= 2 sweep of a small batch is L launches. */
+int gcnpt_layer_bwd_data_ex(void* stream, const void* dY, const void* Y, int g_dtype, const void* w_bwd, const int32_t* ell,
                             const int32_t* rowT_ptr, const int32_t* colT_idx, const int32_t* ellT, int B, int T, int Din, int H,
                             void* dh, int dh_dtype, int compute_dtype, float scale, void* z_frag, float* zero_dW, float* zero_db,
-                            const void* relu_src, float next_scale, int src_is_dz, void* workspace, size_t workspace_bytes);
-int gcnpt_layers_fwd_ws(void* stream, int n_layers, const void* x, int x_dtype, const void* const* w_fwd, const float* const* bias,
-                        const int32_t* row_ptr, const int32_t* col_idx, const int32_t* ell, const int32_t* deg_ell, int B, int T,
-                        const int* Din, const int* H, void* const* out, const int* out_dtype, int compute_dtype, const float* drop_p,
-                        const uint64_t* seed, void* const* s_frag, const uint64_t* seed_dev, void* workspace, size_t workspace_bytes);
-int gcnpt_layers_bwd_ws(void* stream, int n_layers, const void* gy, const void* const* Y, const int* y_dtype,
-                        const void* const* w_bwd, const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
-                        const int32_t* ellT, int B, int T, const int* Din, const int* H, void* const* dh, const int* dh_dtype,
-                        int compute_dtype, const float* scale, void* const* z_frag, const void* const* s_frag, float* const* dW,
-                        float* const* db, int gy_is_dz, void* workspace, size_t workspace_bytes);
+                            const void* relu_src, float next_scale, int src_is_dz, void* down_z_frag, float* down_zero_dW,
+                            float* down_zero_db, int down_Din, int n_riders, const void* const* r_z_frag, const void* const* r_s_frag,
+                            const int* r_Din, const int* r_H, float* const* r_dW, float* const* r_db);
+/* Launches [first_launch, first_launch + n_launches) of the sweep gcnpt_layers_bwd (gy_is_dz = 0) / gcnpt_layers_bwd_dz (1) would
+ * enqueue, in its order (measurement aid: bench.py times truncated steps to charge each launch its in-step duration). */
+int gcnpt_layers_bwd_range(void* stream, int n_layers, const void* gy, const void* const* Y, const int* y_dtype,
+                           const void* const* w_bwd, const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
+                           const int32_t* ellT, int B, int T, const int* Din, const int* H, void* const* dh, const int* dh_dtype,
+                           int compute_dtype, const float* scale, void* const* z_frag, const void* const* s_frag, float* const* dW,
+                           float* const* db, int gy_is_dz, int first_launch, int n_launches);
 
 /* ---- N2: adj_type == 'diagonal_deprel', model/gcn.py:272-294 (+ 390-393) -------------------------------------------
  * No weight matrix: out[r] = dropout(relu((sum_{c: 0<adj[r,c]<42} E[deprel[c]]*h[c] + sum_{c: 42<adj[r,c]<84}

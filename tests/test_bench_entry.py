@@ -12,7 +12,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
-FAST = ["--no-cpu-baseline", "--no-kernel-breakdown", "--no-pooled-only", "--no-secondary"]
+FAST = ["--no-cpu-baseline", "--no-kernel-breakdown", "--no-pooled-only", "--no-secondary", "--no-secondary-shapes"]
 
 
 def _run(args, env=None, timeout=600):
@@ -60,3 +60,7 @@ def test_self_launch_two_ranks_one_device():
     assert d2["scaling"] == "weak" and d2["value"] > 0
     g1, g2 = d1["config"]["grad_bucket_abs_sum"], d2["config"]["grad_bucket_abs_sum"]
     assert g1 > 0 and abs(g2 - 2 * g1) <= 2e-3 * g2, (g1, g2)            # float atomics reorder the sums: not bit-exact
+    # the N > 1 headline is SYNCHRONOUS SGD: every step's all-reduce feeds a device-side update the next step's pack reads
+    assert d2["config"]["dp_mode"].startswith("synchronous SGD") and d2["config"]["weight_abs_drift_after_timed_steps"] > 0
+    assert "async_upper_bound" in d2 and "NOT synchronous" in d2["async_upper_bound"]["note"]
+    assert d1["config"]["dp_mode"] == "none (1 GPU)"

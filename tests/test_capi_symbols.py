@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(handle, n), "libgcnpt.so does not export %s" % n
     assert sorted(_lib.SIGNATURES) == names                      # the ctypes binding covers the header, nothing else
-    assert _lib.lib().gcnpt_abi_version() == _lib.ABI_VERSION == 5
+    assert _lib.lib().gcnpt_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_argument_validation_needs_no_gpu():
@@ -57,17 +57,27 @@ def test_argument_validation_needs_no_gpu():
     assert b"dh[1] must exist" in L.gcnpt_last_error()
     assert L.gcnpt_layers_bwd(None, 2, p, ptrs, two(0, 0), ptrs, p, p, p, p, 1, 1, two(8, 8), two(8, 8), ptrs, two(0, 0), 0, f2, ptrs, None, None, None) == _lib.E_INVALID
     assert b"weight gradients need" in L.gcnpt_last_error()
-    # the big-batch workspace: none below 16 384 token rows, [rows x widest side, bf16] + [rows x H_top] above
-    # (the two-launch layer form is opt-in: no workspace is asked for without GCNPT_ROWSPLIT=1)
-    os.environ.pop("GCNPT_ROWSPLIT", None)
-    assert L.gcnpt_layers_workspace_bytes(2, 128, 300, two(600, 300), two(300, 300), _lib.BF16) == 0
-    os.environ["GCNPT_ROWSPLIT"] = "1"
+    # the extended backward-data call: at most two weight gradients ride, each with both images and accumulators
+    assert L.gcnpt_layer_bwd_data_ex(None, p, p, 0, p, p, p, p, p, 1, 1, 8, 8, p, 0, 0, 1.0, None, None, None, None, 1.0, 1, None, None, None, 0,
+                                     3, ptrs, ptrs, two(8, 8), two(8, 8), ptrs, ptrs) == _lib.E_INVALID
+    assert b"can ride" in L.gcnpt_last_error()
+    assert L.gcnpt_layer_bwd_data_ex(None, p, p, 0, p, p, p, p, p, 1, 1, 8, 8, p, 0, 0, 1.0, None, None, None, None, 1.0, 1, None, None, None, 0,
+                                     1, none2, ptrs, two(8, 8), two(8, 8), ptrs, ptrs) == _lib.E_INVALID
+    # the image of the handed-down dZ needs relu_src and dh in the compute dtype
+    assert L.gcnpt_layer_bwd_data_ex(None, p, p, 0, p, p, p, p, p, 1, 1, 8, 8, p, 0, 0, 1.0, None, None, None, None, 1.0, 1, p, p, p, 8,
+                                     0, None, None, None, None, None, None) == _lib.E_INVALID
+    assert b"relu_src" in L.gcnpt_last_error()
+    # the option table: the library's one piece of process state, no environment access after load
+    assert L.gcnpt_get_option(_lib.OPT_SIDE_TILES) == 192 and L.gcnpt_get_option(_lib.OPT_FOUR_WAVES) == -1
+    assert L.gcnpt_set_option(99, 1) == _lib.E_INVALID and L.gcnpt_set_option(_lib.OPT_DETERMINISTIC, 2) == _lib.E_INVALID
+    old = _lib.set_option(_lib.OPT_DETERMINISTIC, 1)
+    os.environ["GCNPT_DETERMINISTIC"] = "0"                       # ignored: defaults were read once, at load
     try:
-        assert L.gcnpt_layers_workspace_bytes(2, 50, 100, two(360, 200), two(200, 200), _lib.BF16) == 0
-        assert L.gcnpt_layers_workspace_bytes(2, 128, 300, two(600, 300), two(300, 300), _lib.BF16) == 38400 * 600 * 2 + 38400 * 300 * 2
-        assert L.gcnpt_layers_workspace_bytes(9, 128, 300, two(600, 300), two(300, 300), _lib.BF16) == 0
+        assert L.gcnpt_get_option(_lib.OPT_DETERMINISTIC) == 1
     finally:
-        os.environ.pop("GCNPT_ROWSPLIT", None)
+        os.environ.pop("GCNPT_DETERMINISTIC", None)
+        _lib.set_option(_lib.OPT_DETERMINISTIC, old)
+    assert L.gcnpt_launch_empty(None, 0, 64, 0, 64) == _lib.E_INVALID
     assert L.gcnpt_compact_trees(None, p, p, None, None, None, p, None, p, p, 1, 4, 12, 0, 12, p, p, None, None, None, p, None, p, p, p, p) == _lib.E_INVALID
     assert L.gcnpt_compact_trees(None, p, p, None, None, None, p, None, p, p, 1, 4, 12, 4, 12, p, p, p, None, None, p, None, p, p, p, p) == _lib.E_INVALID
     assert b"labels wanted" in L.gcnpt_last_error()

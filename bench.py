@@ -160,9 +160,12 @@ class Stack(object):
         dims = [(H, Din), (H, H)]
         self.wf = [torch.empty((self.L.gcnpt_packed_bytes(h, d, self.compute),), dtype=torch.uint8, device=dev) for h, d in dims]
         self.wb = [torch.empty((self.L.gcnpt_packed_bytes(d, h, self.compute),), dtype=torch.uint8, device=dev) for h, d in dims]
-        # saved operands in MFMA fragment order: S_l = (A+I)h_l written by fwd, dZ_l written by the backward sweep
+        # saved operand in MFMA fragment order: S_l = (A+I)h_l written by fwd.  The weight gradient reads dZ_l as ROWS (activations are in
+        # the compute type's storage here, width % 4 == 0): no dZ image; widths that are not a multiple of 4 would need z_frag
         self.sf = [torch.empty((self.L.gcnpt_frag_bytes(R, d, self.compute),), dtype=torch.uint8, device=dev) for h, d in dims]
+        self.rows_form = H % 4 == 0
         self.zf = [torch.empty((self.L.gcnpt_frag_bytes(R, h, self.compute),), dtype=torch.uint8, device=dev) for h, d in dims]
+        self.zf_arg = [None, None] if self.rows_form else self.zf
         # flat gradient buckets [dW0, db0, dW1, db1] (one; a ring of them in the async exchange mode)
         self.buckets = [torch.zeros((self.n_grad,), dtype=torch.float32, device=dev) for _ in range(N_BUCKETS)]
         # loader-side pre-pruning (N4): a "dataset" of 20 batches pruned once; a step then only gathers its batch's rows
@@ -215,7 +218,7 @@ class Stack(object):
                    A([self.h1, self.h2]), act, self.compute, (ctypes.c_float * n)(self.args.drop, 0.0), (ctypes.c_uint64 * n)(0x5eed, 0),
                    A(self.sf), None)
             bwd = (n, P(self.gy), A([self.h1, self.h2]), act, A(self.wb), P(tr.ell), P(tr.rowT_ptr), P(tr.colT_idx), P(tr.ellT), self.B, self.T,
-                   Din, H, A([self.dx, self.dh1]), act, self.compute, (ctypes.c_float * n)(self.scale, 1.0), A(self.zf), A(self.sf),
+                   Din, H, A([self.dx, self.dh1]), act, self.compute, (ctypes.c_float * n)(self.scale, 1.0), A(self.zf_arg), A(self.sf),
                    A([g[0], g[2]]), A([g[1], g[3]]))
             vp = ctypes.c_void_p
             pack = (n, (vp * n)(*[w.data_ptr() for w in self.W]), H, Din, self.compute, A(self.wf), A(self.wb))
@@ -320,14 +323,13 @@ class Stack(object):
             wp = self.wf[l].numel()
             out["fwd%d" % l] = e * N * (Din + H) + wp + 4 * H + csr + self.sf[l].numel()
             # the top layer reads dY and Y, the layers below read the dZ the layer above left them; every layer but the bottom one
-            # also reads its input rows to leave dZ for the layer below (hand-over of gcnpt_layers_bwd) -- and, when the weight
-            # gradients ride, that dZ's fragment image; a layer writes its own dZ image only when no launch above did
+            # also reads its input rows to leave dZ for the layer below (hand-over of gcnpt_layers_bwd)
             top, bottom = l == nl - 1, l == 0
-            own_img = self.zf[l].numel() if (top or not self.riders) else 0
-            down_img = self.zf[l - 1].numel() if (self.riders and not bottom) else 0
+            own_img = 0 if self.rows_form else self.zf[l].numel()
             out["bwd_data%d" % l] = e * N * ((2 if top else 1) * H + (1 if bottom else 2) * Din) + self.wb[l].numel() + 2 * csr + \
-                own_img + down_img + 4 * (H * Din + H)
-            out["bwd_weight%d" % l] = self.zf[l].numel() + self.sf[l].numel() + 4 * (H * Din + H)
+                own_img + 4 * (H * Din + H)
+            # the weight gradient reads dZ (rows -- dY and Y for the top layer -- or the image) and the S image
+            out["bwd_weight%d" % l] = ((2 if top else 1) * e * N * H if self.rows_form else self.zf[l].numel()) + self.sf[l].numel() + 4 * (H * Din + H)
             out["bwd_weight"] = out.get("bwd_weight", 0) + out["bwd_weight%d" % l]
             out["pack"] = out.get("pack", 0) + 4 * H * Din + self.wf[l].numel() + self.wb[l].numel()
         out["bwd_data0+wgrad1+wgrad0"] = out["bwd_data0"] + out["bwd_weight"]
@@ -446,10 +448,16 @@ def launch_floor(stack, shapes, steps, launch):
     subtracting this floor is kernel work (one workgroup's dependent chain per launch)."""
     L, lib = stack.L, stack._lib
 
+    n = len(shapes)
+    cols = [(ctypes.c_int * n)(*[s[i] for s in shapes]) for i in range(4)]
+    # the real step is three native calls (pack | forward layers | backward sweep): the empty launches are grouped the same way
+    groups = [(0, 1), (1, 1 + len(stack.W)), (1 + len(stack.W), n)]
+    calls = [(hi - lo, [ctypes.cast(ctypes.byref(c, 4 * lo), ctypes.POINTER(ctypes.c_int)) for c in cols]) for lo, hi in groups if hi > lo]
+
     def empty_step():
         st = lib.stream()
-        for g, b, lds, ka in shapes:
-            rc = L.gcnpt_launch_empty(st, g, b, lds, ka)
+        for cnt, ptrs in calls:
+            rc = L.gcnpt_launch_empty_seq(st, cnt, *ptrs)
             if rc:
                 lib.check(rc)
     run, _ = capture(empty_step, launch == "graph")

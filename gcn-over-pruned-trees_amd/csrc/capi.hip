@@ -88,6 +88,16 @@ extern "C" int gcnpt_last_launch(int* grid, int* block, int* lds_bytes, int* ker
     return GCNPT_OK;
 }
 
+extern "C" int gcnpt_launch_empty(void* stream, int grid, int block, int lds_bytes, int kernarg_bytes);
+extern "C" int gcnpt_launch_empty_seq(void* stream, int n, const int* grid, const int* block, const int* lds_bytes, const int* kernarg_bytes) {
+    if (n < 0 || (n > 0 && (!grid || !block || !lds_bytes || !kernarg_bytes))) return gcnpt::fail(GCNPT_E_INVALID, "launch_empty_seq: bad argument");
+    for (int i = 0; i < n; ++i) {
+        const int rc = gcnpt_launch_empty(stream, grid[i], block[i], lds_bytes[i], kernarg_bytes[i]);
+        if (rc != GCNPT_OK) return rc;
+    }
+    return GCNPT_OK;
+}
+
 extern "C" int gcnpt_launch_empty(void* stream, int grid, int block, int lds_bytes, int kernarg_bytes) {
     if (grid <= 0 || block <= 0 || block > 1024 || lds_bytes < 0 || lds_bytes > 160 * 1024 || kernarg_bytes < 0)
         return gcnpt::fail(GCNPT_E_INVALID, "launch_empty: grid %d block %d lds %d kernarg %d", grid, block, lds_bytes, kernarg_bytes);

@@ -4,6 +4,7 @@
 #pragma once
 #include "layer_common.h"
 #include "wgrad_common.h"
+#include "wgrad_rows.h"
 
 // the kernel's big outputs (rows, fragment images): plain stores, or -DGCNPT_NT_STORES=1 non-temporal ones (experiment: does leaving
 // less dirty data in the L2s shorten the launch boundary?  see DESIGN.md section 5)
@@ -49,8 +50,6 @@ struct RowTileParams {
     const int32_t* d_ell;       // ELL head whose [8r] gives deg (always the forward pattern A)
     void* out;              // [N,NOUT]; NULL = only the side outputs below are wanted
     void* frag_out;         // NULL or fragment image (include/gcnpt.h) of the tile: fwd S = (A+I)h, bwd dZ
-    void* frag_down;        // bwd with relu_src: NULL or the fragment image of what leaves in `out`, i.e. of dZ of the layer BELOW (its weight
-                            // gradient can then run beside that layer's backward-data launch instead of after it)
     float* zero_p[4];       // NULL or accumulators to clear for the weight gradients that follow (bwd: dW, db of this layer / the layer below)
     int zero_n[4];
     int N, T, K, NOUT, Kpad;
@@ -567,7 +566,6 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
                             for (int q = 0; q < NW; ++q) ow[q] = hw[q] > 0.0f ? ow[q] * f : 0.0f;
                         }
                         GCNPT_ROW_STORE(reinterpret_cast<V*>(out + (size_t)r * p.NOUT + c_lo + pc * PER), o);
-                        if (p.frag_down) *reinterpret_cast<V*>(O + (size_t)row * ostride + pc * PER) = o;      // the tile becomes dZ of the layer below
                     }
                 }
             } else if (r < p.N) {
@@ -594,17 +592,8 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
                     if constexpr (sizeof(OT) == 2) { x = bf16_to_f32(v); hx = bf16_to_f32(hv); } else { x = v; hx = hv; }
                     x = hx > 0.0f ? x * (p.next_scale / rden[row]) : 0.0f;
                     if constexpr (sizeof(OT) == 2) v = f32_to_bf16(x); else v = x;
-                    if (p.frag_down) O[(size_t)row * ostride + c] = v;
                 }
                 out[(size_t)r * p.NOUT + c_lo + c] = v;
-            }
-        }
-        // hand-over, second half: the fragment image of the dZ rows that just left, for the layer below's weight gradient (rows past
-        // the end and columns past NOUT of the tile are zeros: zero S rows, zero-padded weights)
-        if constexpr (BWD && sizeof(OT) == sizeof(CT)) {
-            if (relu && p.frag_down) {
-                __syncthreads();
-                emit_image(static_cast<uint4*>(p.frag_down), O, ostride, pass * (ncols_pass / 16), ceil_div(width, 16), true);
             }
         }
     }
@@ -618,28 +607,52 @@ __global__ __launch_bounds__(NWV * WAVE, 2) void rowtile_kernel(const RowTilePar
     rowtile_body<CT, IT, OT, BWD, VEC, NTW, KSMAX, DZIN, NWV>(p, (int)blockIdx.x, (int)gridDim.x, smem_raw);
 }
 
-// A backward-data launch with WEIGHT GRADIENTS as a side job: a weight gradient only needs the two fragment images earlier launches have
-// left (dZ_l from the launch above -- the top layer's own loader, or the hand-over epilogue of layer l+1 --, S_l from the forward), and
+// A backward-data launch with WEIGHT GRADIENTS as a side job: a weight gradient only needs what earlier launches have left (the dZ rows
+// the layer above handed down -- this launch's own input -- or, for the top layer, dY and Y; the S image of the forward), and
 // a batch of <= ~6 k rows leaves a third of the CUs without a row tile.  Workgroups [0, n_tiles) are row tiles, workgroups
 // [wg_first, gridDim.x) (wg_first = n_tiles rounded up to 8, so that the weight gradient's block -> XCD map holds) contract one slice of
 // one output block of one of up to two layers each.  A two-layer backward sweep is then TWO launches: the top layer's backward-data
 // (which also leaves the bottom layer's dZ image) and the bottom layer's with both weight gradients riding.
 constexpr int SIDE_MAX = 2;
 struct SideWgrads {
-    WeightGradParams l[SIDE_MAX];
-    int first[SIDE_MAX + 1];            // passenger workgroups [first[i], first[i+1]) belong to l[i]; first[i] % 8 == 0
+    WgradRowsParams l[SIDE_MAX];
+    int first[SIDE_MAX + 1];            // units [first[i], first[i+1]) belong to l[i]
+    int tile_unit0;                     // units [0, tile_unit0) are dealt round-robin to the passenger workgroups; unit tile_unit0 + t is done by
+                                        // row-tile workgroup t AFTER its tile (the units need nothing this launch computes)
+    int vec[SIDE_MAX], masked[SIDE_MAX];
 };
+
+template <typename CT>
+__device__ __forceinline__ void side_unit(const SideWgrads& sw, const int u, unsigned char* smem_raw) {
+    const int li = u >= sw.first[1] ? 1 : 0;
+    const WgradRowsParams& w = sw.l[li];
+    const int uu = u - sw.first[li];
+    // (workgroup-uniform dispatch; the masked form only ever belongs to the top layer, which is l[0] when it rides)
+    if (sw.masked[li]) { if (sw.vec[li] == 8) wgrad_rows_unit<CT, 8, true>(w, uu, smem_raw); else wgrad_rows_unit<CT, 4, true>(w, uu, smem_raw); }
+    else               { if (sw.vec[li] == 8) wgrad_rows_unit<CT, 8, false>(w, uu, smem_raw); else wgrad_rows_unit<CT, 4, false>(w, uu, smem_raw); }
+}
 
 template <typename CT, typename IT, typename OT, int VEC, int NTW, int KSMAX>
 __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_wgrad_kernel(const RowTileParams p, const SideWgrads sw, const int n_tiles,
                                                                       const int wg_first) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int n_units = sw.first[SIDE_MAX];
     if ((int)blockIdx.x < n_tiles) {
         rowtile_body<CT, IT, OT, true, VEC, NTW, KSMAX, true>(p, (int)blockIdx.x, n_tiles, smem_raw);
+        const int u = sw.tile_unit0 + (int)blockIdx.x;
+        if (u < n_units) {                                   // workgroup-uniform
+            __syncthreads();                                 // the tile's LDS is free
+            side_unit<CT>(sw, u, smem_raw);
+        }
     } else if ((int)blockIdx.x >= wg_first) {
-        const int id = (int)blockIdx.x - wg_first;
-        const int li = id >= sw.first[1] ? 1 : 0;
-        weight_grad_body<CT, RT_WAVES, WG_NT, WG_KB>(sw.l[li], id - sw.first[li], smem_raw);
+        const int n_pass = (int)gridDim.x - wg_first;
+        GCNPT_STAMP_REAL(p.stamps);
+        GCNPT_STAMP(p.stamps, 0);
+        for (int u = (int)blockIdx.x - wg_first; u < sw.tile_unit0; u += n_pass) {
+            side_unit<CT>(sw, u, smem_raw);
+            __syncthreads();                                 // every wave has left the stages: the next unit may fill them
+        }
+        GCNPT_STAMP(p.stamps, 10);
     }
 }
 
@@ -649,7 +662,7 @@ namespace gcnpt {
 
 // Weight gradients the next backward-data launch should carry (layers_bwd_impl sets it around that one call; thread-local because it
 // is only an argument that skips four levels of dispatch templates, not state: it never outlives the call that set it)
-struct SideWgrad { const SideWgrads* sw = nullptr; bool carried = false; };
+struct SideWgrad { const SideWgrads* sw = nullptr; int passengers = 0; bool carried = false; };
 extern thread_local SideWgrad t_side;      // defined in rowtile_kernels.hip
 
 
@@ -675,9 +688,9 @@ static inline int launch_rowtile_cfg(hipStream_t s, const RowTileParams& p) {
             auto kern = rowtile_wgrad_kernel<CT, IT, OT, VEC, NTW, KSMAX>;
             GCNPT_LDS_ATTR_ONCE(kern, 160 * 1024);
             const int wg_first = round_up(n_tiles, 8);
-            hipLaunchKernelGGL(kern, dim3(wg_first + t_side.sw->first[SIDE_MAX]), dim3(RT_THREADS), std::max(lds, weight_grad_lds(RT_WAVES)), s, p,
-                               *t_side.sw, n_tiles, wg_first);
-            note_launch(wg_first + t_side.sw->first[SIDE_MAX], RT_THREADS, std::max(lds, weight_grad_lds(RT_WAVES)), sizeof(p) + sizeof(SideWgrads) + 8);
+            const int grid = wg_first + t_side.passengers;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(RT_THREADS), std::max(lds, wgrad_rows_lds(sizeof(CT) == 2 ? GCNPT_BF16 : GCNPT_F32)), s, p, *t_side.sw, n_tiles, wg_first);
+            note_launch(grid, RT_THREADS, std::max(lds, wgrad_rows_lds(sizeof(CT) == 2 ? GCNPT_BF16 : GCNPT_F32)), sizeof(p) + sizeof(SideWgrads) + 8);
             GCNPT_HIP_CHECK(hipGetLastError());
             t_side.carried = true;
             return GCNPT_OK;

@@ -89,6 +89,8 @@ int gcnpt_get_option(int option);
  * dispatch / ramp / drain rather than kernel work. */
 int gcnpt_last_launch(int* grid, int* block, int* lds_bytes, int* kernarg_bytes);
 int gcnpt_launch_empty(void* stream, int grid, int block, int lds_bytes, int kernarg_bytes);
+/* n of them back to back from ONE native call (host arrays), as gcnpt_layers_fwd / _bwd enqueue their launches */
+int gcnpt_launch_empty_seq(void* stream, int n, const int* grid, const int* block, const int* lds_bytes, const int* kernarg_bytes);
 
 /* ---- A1-A4: model/gcn.py:96-110 (lengths, head_to_tree x B, tree_to_adj x B, upload) ------------------
  * One workgroup per sentence prunes the dependency tree to the tokens within `prune_k` of the
@@ -202,9 +204,11 @@ int gcnpt_layer_bwd_weight_multi(void* stream, int n_layers, const void* const* 
  * gcnpt_layers_bwd:  top layer first, gy = gradient of out[L-1] in y_dtype[L-1]; dh[l] = gradient of layer l's input in
  *   dh_dtype[l] (= y_dtype[l-1] for l > 0; dh[0] may be NULL when the input needs no gradient; dh[l] for l > 0 is scratch for
  *   the caller: it holds dZ of layer l-1, see the hand-over above); scale[l] = 1/(1-p_l) of the
- *   dropout layer l's forward applied.  z_frag == NULL: no weight gradients (dW, db, s_frag unused); otherwise z_frag[l],
- *   s_frag[l], dW[l], db[l] for every layer; the weight gradients ride in the backward-data launches (small batches, see
- *   gcnpt_layer_bwd_data_ex) or follow in ONE launch (gcnpt_layer_bwd_weight_multi). */
+ *   dropout layer l's forward applied.  s_frag == NULL: no weight gradients (dW, db, z_frag unused); otherwise s_frag[l], dW[l],
+ *   db[l] for every layer.  z_frag[l] (or z_frag itself) may be NULL for a layer whose dZ rows take the rows form (y_dtype[l] ==
+ *   compute_dtype, H[l] % 4 == 0: see gcnpt_layer_bwd_weight_rows) -- no dZ image is written then; other layers need their z_frag[l].
+ *   The weight gradients ride in the backward-data launches (small batches, see gcnpt_layer_bwd_data_ex) or follow in one launch
+ *   per form. */
 int gcnpt_layers_fwd(void* stream, int n_layers, const void* x, int x_dtype, const void* const* w_fwd, const float* const* bias,
                      const int32_t* row_ptr, const int32_t* col_idx, const int32_t* ell, const int32_t* deg_ell, int B, int T,
                      const int* Din, const int* H, void* const* out, const int* out_dtype, int compute_dtype,
@@ -281,22 +285,30 @@ int gcnpt_layers_bwd_dz(void* stream, int n_layers, const void* dz_top, const vo
                         int compute_dtype, const float* scale, void* const* z_frag, const void* const* s_frag, float* const* dW,
                         float* const* db);
 
-/* gcnpt_layer_bwd_data with the two extras the backward sweep of a SMALL batch (<= GCNPT_OPT_SIDE_TILES row tiles: a third of the CUs
- * has no row tile) uses to get rid of its weight-gradient launches (model/gcn.py:270-271 differentiated; same sums as
- * gcnpt_layer_bwd_weight):
- *   down_z_frag / down_zero_dW / down_zero_db / down_Din   NULL / 0, or -- with relu_src given and dh_dtype == compute_dtype -- the
- *       fragment image of the dZ this launch hands down (gcnpt_frag_bytes(B*T, Din, compute_dtype) bytes: it is the z_frag of the layer
- *       BELOW, whose own launch then passes z_frag = NULL) and that layer's accumulators [Din x down_Din], [Din] to clear;
- *   n_riders (0..2) weight gradients, each given by its two fragment images, widths and accumulators exactly as gcnpt_layer_bwd_weight
- *       takes them (accumulators cleared by an EARLIER launch): they ride in this launch on the CUs without a row tile when the launch
- *       is a src_is_dz one in a uniform precision, otherwise they are launched right behind it -- enqueued on return either way.
- * gcnpt_layers_bwd / _bwd_dz use this for every layer: an L >= 2 sweep of a small batch is L launches. */
+/* ---- weight gradient from dZ ROWS (no dZ fragment image), and backward-data launches that carry weight gradients ----------------
+ * gcnpt_layer_bwd_weight_rows: the same dW / db as gcnpt_layer_bwd_weight (model/gcn.py:270-271 differentiated; dW, db cleared by the
+ * caller or an earlier launch), but the dZ operand is read as it lies in memory and transposed in LDS (csrc/wgrad_rows.h):
+ *   dz [dev] [B*T, H] of rows_dtype = the layer's dZ (what the layer above handed down, see relu_src of gcnpt_layer_bwd_data) -- or,
+ *   with Y given, the layer's dY, and dZ = dY * 1[Y > 0] * scale / (deg + 1) is formed on the fly (ell = the forward pattern's ELL head);
+ *   s_frag = the forward's S image.  Needs rows_dtype == compute_dtype, H % 4 == 0 and 8-byte (bf16) / 16-byte (f32) aligned rows;
+ *   GCNPT_E_UNSUPPORTED otherwise (use the image form).
+ * gcnpt_layer_bwd_data_ex: gcnpt_layer_bwd_data plus what the backward sweep of a SMALL batch (<= GCNPT_OPT_SIDE_TILES row tiles: a third
+ * of the CUs has no row tile) uses to get rid of its weight-gradient launches:
+ *   down_zero_dW / down_zero_db / down_Din   NULL / 0, or the accumulators [Din x down_Din], [Din] of the layer BELOW to clear (its
+ *       gradient will ride in its own backward-data launch);
+ *   n_riders (0..2) rows-form weight gradients, each given like gcnpt_layer_bwd_weight_rows's arguments (r_Y[i] NULL = r_dz[i] is dZ;
+ *       accumulators cleared by an EARLIER launch): they ride in this launch on the CUs without a row tile when the launch is a
+ *       src_is_dz one in a uniform precision, otherwise they are launched right behind it -- enqueued on return either way.
+ * gcnpt_layers_bwd / _bwd_dz use this for every layer: the gradient of layer l rides in layer l's own backward-data launch (its dZ rows
+ * are that launch's input), the top layer's in the launch below it: an L >= 2 sweep of a small batch is L launches. */
+int gcnpt_layer_bwd_weight_rows(void* stream, const void* dz, const void* Y, const int32_t* ell, float scale, int rows_dtype,
+                                const void* s_frag, int B, int T, int Din, int H, float* dW, float* db, int compute_dtype);
 int gcnpt_layer_bwd_data_ex(void* stream, const void* dY, const void* Y, int g_dtype, const void* w_bwd, const int32_t* ell,
                             const int32_t* rowT_ptr, const int32_t* colT_idx, const int32_t* ellT, int B, int T, int Din, int H,
                             void* dh, int dh_dtype, int compute_dtype, float scale, void* z_frag, float* zero_dW, float* zero_db,
-                            const void* relu_src, float next_scale, int src_is_dz, void* down_z_frag, float* down_zero_dW,
-                            float* down_zero_db, int down_Din, int n_riders, const void* const* r_z_frag, const void* const* r_s_frag,
-                            const int* r_Din, const int* r_H, float* const* r_dW, float* const* r_db);
+                            const void* relu_src, float next_scale, int src_is_dz, float* down_zero_dW, float* down_zero_db,
+                            int down_Din, int n_riders, const void* const* r_dz, const void* const* r_Y, const float* r_scale,
+                            const void* const* r_s_frag, const int* r_Din, const int* r_H, float* const* r_dW, float* const* r_db);
 /* Launches [first_launch, first_launch + n_launches) of the sweep gcnpt_layers_bwd (gy_is_dz = 0) / gcnpt_layers_bwd_dz (1) would
  * enqueue, in its order (measurement aid: bench.py times truncated steps to charge each launch its in-step duration). */
 int gcnpt_layers_bwd_range(void* stream, int n_layers, const void* gy, const void* const* Y, const int* y_dtype,

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """
 Developer diagnostic: per-phase cycle stamps of the hot kernels (needs `make -C gcn-over-pruned-trees_amd/csrc stamps`).
-Runs the bench workload once per kernel with libgcnpt_stamps.so and prints, per stamp interval, the median /
-max cycles over workgroups, the dispatch skew (100 MHz real time) and the first-start -> last-end span.
+Runs the bench workload with libgcnpt_stamps.so and prints, for every launch of the step, per stamp interval the median /
+max cycles over workgroups, the dispatch skew (100 MHz real time) and the first-start -> last-end span.  Row-tile workgroups stamp
+slots 0-10, a weight-gradient unit slots 11-14 (the LAST unit a workgroup ran), a passenger workgroup 0 (entry) and 10 (exit).
 Not part of the product; timings of this build are NOT quoted anywhere (the stamps forbid overlaps).
 """
 import ctypes
@@ -19,8 +20,31 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 
 
+def report(name, s):
+    s = s[(s != 0).any(1)]
+    print("== %s: %d workgroups stamped" % (name, len(s)))
+    groups = {}
+    for row in s:
+        key = tuple(k for k in range(15) if row[k] != 0)
+        groups.setdefault(key, []).append(row)
+    for slots, rows in sorted(groups.items(), key=lambda kv: -len(kv[1])):
+        r = np.array(rows)
+        print("  -- %d workgroups with stamps %s" % (len(r), list(slots)))
+        real = r[:, 15]
+        if (real != 0).all():
+            print("     dispatch skew (real time, 10 ns ticks): start max-min = %d" % (real.max() - real.min()))
+        if len(slots) < 2:
+            continue
+        tot = r[:, slots[-1]] - r[:, slots[0]]
+        print("     first start -> last end: %d cycles; per-WG total median %d max %d" %
+              (r[:, slots[-1]].max() - r[:, slots[0]].min(), np.median(tot), tot.max()))
+        order = sorted(slots, key=lambda k: np.median(r[:, k]))
+        for a, b in zip(order[:-1], order[1:]):
+            d = r[:, b] - r[:, a]
+            print("     %2d -> %2d : median %7d  p90 %7d  max %7d cycles" % (a, b, np.median(d), np.percentile(d, 90), d.max()))
+
+
 def main():
-    sys.argv = [sys.argv[0]] + sys.argv[1:]
     args = bench.parse()
     dev = torch.device("cuda:0")
     stack = bench.Stack(args, dev, seed=1234)
@@ -33,32 +57,33 @@ def main():
     L.gcnpt_debug_set_knob(knob)
     print("knob =", knob)
     buf = torch.zeros((4096 * 16,), dtype=torch.int64, device=dev)
-    calls = [("prune", stack.prune)] + stack.calls(0)[1:]
+    names = stack.launch_names()
     for _ in range(5):
-        stack.step()
+        stack.step_native()
     torch.cuda.synchronize()
-    for name, call in calls:
+    for k in range(2, len(names) + 1):              # (the pack kernel has no stamps)
         L.gcnpt_debug_set_stamps(None)
         for _ in range(3):
-            stack.step()
+            stack.step_native()
+        stack.step_prefix(k - 1)
         torch.cuda.synchronize()
         buf.zero_()
         L.gcnpt_debug_set_stamps(buf.data_ptr())
-        call()
+        # launch k alone, behind the real prefix: its predecessors ran unstamped
+        pack, fwd, bwd = stack._native_args(0)
+        st, nl = stack._lib.stream(), len(stack.W)
+        if k - 1 <= nl:
+            l = k - 2
+            stack._lib.check(L.gcnpt_layers_fwd(st, l + 1, *fwd[1:]) if l == 0 else
+                             L.gcnpt_layer_fwd(st, stack._lib.ptr(stack.h1), stack.act, stack._lib.ptr(stack.wf[1]), stack._lib.ptr(stack.b[1]),
+                                               stack._lib.ptr(stack.trees.row_ptr), stack._lib.ptr(stack.trees.col_idx), stack._lib.ptr(stack.trees.ell), None,
+                                               stack.B, stack.T, stack.H, stack.H, stack._lib.ptr(stack.h2), stack.act, stack.compute, 0.0, 0,
+                                               stack._lib.ptr(stack.sf[1]), None))
+        else:
+            stack._lib.check(L.gcnpt_layers_bwd_range(st, *(bwd + (0, k - 2 - nl, 1))))
         torch.cuda.synchronize()
         L.gcnpt_debug_set_stamps(None)
-        s = buf.cpu().numpy().reshape(-1, 16).astype(np.int64)
-        s = s[s[:, 0] != 0]
-        slots = [k for k in range(15) if (s[:, k] != 0).all()]
-        real = s[:, 15]
-        print("== %s: %d workgroups, stamps %s" % (name, len(s), slots))
-        print("   dispatch skew (real time, 10 ns ticks): start max-min = %d ticks" % (real.max() - real.min()))
-        span = (s[:, slots[-1]].max() - s[:, slots[0]].min())
-        print("   first start -> last end: %d cycles; per-WG total median %d max %d" %
-              (span, np.median(s[:, slots[-1]] - s[:, slots[0]]), (s[:, slots[-1]] - s[:, slots[0]]).max()))
-        for a, b in zip(slots[:-1], slots[1:]):
-            d = s[:, b] - s[:, a]
-            print("   %2d -> %2d : median %7d  p90 %7d  max %7d cycles" % (a, b, np.median(d), np.percentile(d, 90), d.max()))
+        report(names[k - 1], buf.cpu().numpy().reshape(-1, 16).astype(np.int64))
 
 
 if __name__ == "__main__":

@@ -7,8 +7,8 @@ bench.py -- BASELINE.json metric: GCN-layer fwd+bwd sentences/sec at batch=50 se
 One "step" = the hot path over one synthetic TACRED-shaped batch of 50 sentences x 100 tokens
 (BASELINE.json configs[1]: 2-layer GCN, no LSTM, Din 360 -> 200 -> 200, prune_k 1, bf16 storage,
 fp32 accumulation, dropout 0.5 between the layers), entirely through the C-ABI of include/gcnpt.h:
-    pack W0+W1 -> layer0 fwd -> layer1 fwd -> layer1 bwd-data (+ dZ0 image) -> layer0 bwd-data with both weight gradients riding
-(five launches from three native calls: gcnpt_pack_weights_multi, gcnpt_layers_fwd, gcnpt_layers_bwd).
+    pack W0+W1 -> layer0 fwd -> layer1 fwd -> layer1 bwd-data -> layer0 bwd-data with layer1's weight gradient riding -> layer0 bwd-weight
+(six launches from three native calls: gcnpt_pack_weights_multi, gcnpt_layers_fwd, gcnpt_layers_bwd).
 Inputs (x, gy, weights, the loader's integer tensors) are resident in HBM before the timed region.
 `value` is the layer stack alone, as the metric says; `with_prune` / `with_cached_trees` repeat the measurement with the
 pruned-tree adjacency build / its assembly from a pre-pruned dataset inside every step.
@@ -59,8 +59,8 @@ def parse():
     ap.add_argument("--drop", type=float, default=0.5)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-riders", action="store_true",
-                    help="A/B: weight gradients in one launch of their own at the end of the backward sweep (gcnpt_set_option SIDE_TILES 0) "
-                         "instead of as passengers of the backward-data launches")
+                    help="A/B: both weight gradients in one launch of their own at the end of the backward sweep (gcnpt_set_option SIDE_TILES 0) "
+                         "instead of layer 1's riding in layer 0's backward-data launch")
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="2 = run the tree build beside the weight pack on a side stream (only matters for with_prune / with_cached_trees); "
                          "measured slower on MI355X (85 -> 88 us with the pruner, 68 -> 82 with cached trees): parallel graph branches cost more than they hide")
@@ -160,12 +160,9 @@ class Stack(object):
         dims = [(H, Din), (H, H)]
         self.wf = [torch.empty((self.L.gcnpt_packed_bytes(h, d, self.compute),), dtype=torch.uint8, device=dev) for h, d in dims]
         self.wb = [torch.empty((self.L.gcnpt_packed_bytes(d, h, self.compute),), dtype=torch.uint8, device=dev) for h, d in dims]
-        # saved operand in MFMA fragment order: S_l = (A+I)h_l written by fwd.  The weight gradient reads dZ_l as ROWS (activations are in
-        # the compute type's storage here, width % 4 == 0): no dZ image; widths that are not a multiple of 4 would need z_frag
+        # saved operands in MFMA fragment order: S_l = (A+I)h_l written by fwd, dZ_l written by bwd_data
         self.sf = [torch.empty((self.L.gcnpt_frag_bytes(R, d, self.compute),), dtype=torch.uint8, device=dev) for h, d in dims]
-        self.rows_form = H % 4 == 0
         self.zf = [torch.empty((self.L.gcnpt_frag_bytes(R, h, self.compute),), dtype=torch.uint8, device=dev) for h, d in dims]
-        self.zf_arg = [None, None] if self.rows_form else self.zf
         # flat gradient buckets [dW0, db0, dW1, db1] (one; a ring of them in the async exchange mode)
         self.buckets = [torch.zeros((self.n_grad,), dtype=torch.float32, device=dev) for _ in range(N_BUCKETS)]
         # loader-side pre-pruning (N4): a "dataset" of 20 batches pruned once; a step then only gathers its batch's rows
@@ -178,7 +175,7 @@ class Stack(object):
         self.side = torch.cuda.Stream(device=dev)
         if packed:
             self.B, self.T = self.rows, 0                   # what the C-ABI takes for packed rows (include/gcnpt.h, gcnpt_pack_trees)
-        # small batches: the weight gradients ride in the backward-data launches (gcnpt_layer_bwd_data_ex), the sweep is L launches
+        # small batches: layer 1's weight gradient rides in layer 0's backward-data launch (gcnpt_layer_bwd_data_wgrad)
         self.riders = (self.rows + 31) // 32 <= self.L.gcnpt_get_option(_lib.OPT_SIDE_TILES)
 
     def grads(self, k):
@@ -218,7 +215,7 @@ class Stack(object):
                    A([self.h1, self.h2]), act, self.compute, (ctypes.c_float * n)(self.args.drop, 0.0), (ctypes.c_uint64 * n)(0x5eed, 0),
                    A(self.sf), None)
             bwd = (n, P(self.gy), A([self.h1, self.h2]), act, A(self.wb), P(tr.ell), P(tr.rowT_ptr), P(tr.colT_idx), P(tr.ellT), self.B, self.T,
-                   Din, H, A([self.dx, self.dh1]), act, self.compute, (ctypes.c_float * n)(self.scale, 1.0), A(self.zf_arg), A(self.sf),
+                   Din, H, A([self.dx, self.dh1]), act, self.compute, (ctypes.c_float * n)(self.scale, 1.0), A(self.zf), A(self.sf),
                    A([g[0], g[2]]), A([g[1], g[3]]))
             vp = ctypes.c_void_p
             pack = (n, (vp * n)(*[w.data_ptr() for w in self.W]), H, Din, self.compute, A(self.wf), A(self.wb))
@@ -228,7 +225,7 @@ class Stack(object):
     def launch_names(self):
         """The launches of one step, in order (what gcnpt_layers_bwd enqueues follows csrc/rowtile_kernels.hip, layers_bwd_impl)."""
         if self.riders:
-            return ["pack", "fwd0", "fwd1", "bwd_data1", "bwd_data0+wgrad1+wgrad0"]
+            return ["pack", "fwd0", "fwd1", "bwd_data1", "bwd_data0+wgrad1", "bwd_weight0"]
         return ["pack", "fwd0", "fwd1", "bwd_data1", "bwd_data0", "bwd_weight"]
 
     def step_native(self, k=0, with_prune=False):
@@ -325,14 +322,12 @@ class Stack(object):
             # the top layer reads dY and Y, the layers below read the dZ the layer above left them; every layer but the bottom one
             # also reads its input rows to leave dZ for the layer below (hand-over of gcnpt_layers_bwd)
             top, bottom = l == nl - 1, l == 0
-            own_img = 0 if self.rows_form else self.zf[l].numel()
             out["bwd_data%d" % l] = e * N * ((2 if top else 1) * H + (1 if bottom else 2) * Din) + self.wb[l].numel() + 2 * csr + \
-                own_img + 4 * (H * Din + H)
-            # the weight gradient reads dZ (rows -- dY and Y for the top layer -- or the image) and the S image
-            out["bwd_weight%d" % l] = ((2 if top else 1) * e * N * H if self.rows_form else self.zf[l].numel()) + self.sf[l].numel() + 4 * (H * Din + H)
+                self.zf[l].numel() + 4 * (H * Din + H)
+            out["bwd_weight%d" % l] = self.zf[l].numel() + self.sf[l].numel() + 4 * (H * Din + H)
             out["bwd_weight"] = out.get("bwd_weight", 0) + out["bwd_weight%d" % l]
             out["pack"] = out.get("pack", 0) + 4 * H * Din + self.wf[l].numel() + self.wb[l].numel()
-        out["bwd_data0+wgrad1+wgrad0"] = out["bwd_data0"] + out["bwd_weight"]
+        out["bwd_data0+wgrad1"] = out["bwd_data0"] + out["bwd_weight1"]
         out["prune"] = 4 * 8 * N + N + 2 * (csr + 4 * B * (T + 1) + 4 * self.nnz) + N + 4 * (B + 1)
         return out
 
@@ -351,7 +346,7 @@ class Stack(object):
             per["bwd_weight%d" % l] = e * N * Din + 4 * Din * H + 4 * H
         L = len(self.W)
         per["bwd_weight"] = sum(per["bwd_weight%d" % l] for l in range(L))
-        per["bwd_data0+wgrad1+wgrad0"] = per["bwd_data0"] + per["bwd_weight"]
+        per["bwd_data0+wgrad1"] = per["bwd_data0"] + per["bwd_weight1"]
         per["pack"] = 0
         per["prune"] = 0
         return per
@@ -442,15 +437,15 @@ def kernel_breakdown(stack, use_graph, rounds=100, reps=8):
     return out, shapes
 
 
-def launch_floor(stack, shapes, steps, launch):
-    """The step's launches -- same grids, workgroup sizes, LDS and kernel-argument sizes -- with bodies that return at entry, timed in
-    the same loop as the step (native: eager launches back to back; graph: one replay per step).  What is left of ms_per_step after
-    subtracting this floor is kernel work (one workgroup's dependent chain per launch)."""
+def launch_floor(stack, shapes, steps, use_graph):
+    """The step's launches -- same grids, workgroup sizes, LDS and kernel-argument sizes -- with bodies that return at entry
+    (gcnpt_launch_empty_seq, grouped into the same three native calls as the real step).  Two numbers: `device` = per step when 8
+    steps' worth of empty launches are replayed as ONE hipGraph (the replay's fixed cost is spread out: what the dispatches cost the
+    device back to back), `native` = the same eager loop the timed step runs in (what the host can issue).  What is left of
+    ms_per_step after subtracting the device floor is the kernels' own work (one workgroup's dependent chain per launch)."""
     L, lib = stack.L, stack._lib
-
     n = len(shapes)
     cols = [(ctypes.c_int * n)(*[s[i] for s in shapes]) for i in range(4)]
-    # the real step is three native calls (pack | forward layers | backward sweep): the empty launches are grouped the same way
     groups = [(0, 1), (1, 1 + len(stack.W)), (1 + len(stack.W), n)]
     calls = [(hi - lo, [ctypes.cast(ctypes.byref(c, 4 * lo), ctypes.POINTER(ctypes.c_int)) for c in cols]) for lo, hi in groups if hi > lo]
 
@@ -460,9 +455,20 @@ def launch_floor(stack, shapes, steps, launch):
             rc = L.gcnpt_launch_empty_seq(st, cnt, *ptrs)
             if rc:
                 lib.check(rc)
-    run, _ = capture(empty_step, launch == "graph")
-    wall, _ = timed(lambda i: run(), steps, 50, lambda: None)
-    return wall / steps
+
+    wall, _ = timed(lambda i: empty_step(), steps, 50, lambda: None)
+    out = {"native": wall / steps, "device": None}
+    if use_graph:
+        reps = 8
+
+        def many():
+            for _ in range(reps):
+                empty_step()
+        run, graphed = capture(many, True)
+        if graphed:
+            w, _ = timed(lambda i: run(), max(steps // reps, 50), 10, lambda: None)
+            out["device"] = w / (max(steps // reps, 50) * reps)
+    return out
 
 
 def cpu_baseline(args, seconds):
@@ -910,15 +916,19 @@ def main():
                                        "note": "survey_8d_bytes = SURVEY.md 8(d)'s formula for the layer math alone (S recomputed, no saved images, no pack), "
                                                "over the WHOLE timed step (ms_per_step); dataflow_bytes = what this implementation moves, over the summed kernel times"}
             if not args.no_floor and world == 1:
-                floor = launch_floor(stack, shapes, min(args.steps, 2000), launch)
+                fl = launch_floor(stack, shapes, min(args.steps, 2000), use_graph)
+                floor = fl["device"] if fl["device"] is not None else fl["native"]
                 result["launch_floor_us"] = floor * 1e6
                 result["chain_us"] = (wall / args.steps - floor) * 1e6
                 result["launch_floor"] = {"launches": [{"name": n, "grid": s[0], "block": s[1], "lds_bytes": s[2], "kernarg_bytes": s[3]}
                                                        for n, s in zip(names, shapes)],
                                           "per_launch_us": floor * 1e6 / len(shapes),
+                                          "native_loop_us_per_step": fl["native"] * 1e6,
                                           "note": "the step's %d launches with the same grid / workgroup size / LDS / kernel-argument size and bodies that return "
-                                                  "at entry (gcnpt_launch_empty), timed in the same %s loop as the step; chain_us = ms_per_step - launch_floor_us "
-                                                  "is what the kernels' own work adds" % (len(shapes), "hipGraph" if graphed else "native eager-launch")}
+                                                  "at entry (gcnpt_launch_empty_seq): launch_floor_us = per step when 8 steps of them replay as one hipGraph "
+                                                  "(device-side dispatch cost, back to back); native_loop_us_per_step = the same three native calls per step "
+                                                  "issued eagerly (host issue rate: with empty kernels the host, not the device, is the limit); "
+                                                  "chain_us = ms_per_step - launch_floor_us is what the kernels' own work adds" % len(shapes)}
         if not args.no_secondary_shapes and world == 1 and args.layout == "padded":
             result["secondary_shapes"] = secondary_shapes(args, dev, shard_seed)
         if not args.no_cpu_baseline and world == 1:

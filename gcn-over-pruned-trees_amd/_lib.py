@@ -29,8 +29,7 @@ SIGNATURES = {
     "gcnpt_frag_bytes": (_sz, [_i, _i, _i]),
     "gcnpt_layer_fwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _f, _u64, _p, _p]),
     "gcnpt_layer_bwd_data": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _f, _p, _p, _p, _p, _f, _i]),
-    "gcnpt_layer_bwd_data_ex": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _f, _p, _p, _p, _p, _f, _i] + [_p, _p, _i, _i] + [_p] * 8),
-    "gcnpt_layer_bwd_weight_rows": (_i, [_p, _p, _p, _p, _f, _i, _p, _i, _i, _i, _i, _p, _p, _i]),
+    "gcnpt_layer_bwd_data_wgrad": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _f, _p, _p, _p, _p, _f, _i] + [_p, _p, _i, _i, _p, _p]),
     "gcnpt_layers_bwd_range": (_i, [_p, _i] + [_p] * 8 + [_i, _i] + [_p] * 4 + [_i] + [_p] * 5 + [_i, _i, _i]),
     "gcnpt_set_option": (_i, [_i, _i]),
     "gcnpt_get_option": (_i, [_i]),

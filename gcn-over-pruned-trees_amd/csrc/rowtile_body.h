@@ -4,7 +4,6 @@
 #pragma once
 #include "layer_common.h"
 #include "wgrad_common.h"
-#include "wgrad_rows.h"
 
 // the kernel's big outputs (rows, fragment images): plain stores, or -DGCNPT_NT_STORES=1 non-temporal ones (experiment: does leaving
 // less dirty data in the L2s shorten the launch boundary?  see DESIGN.md section 5)
@@ -607,53 +606,28 @@ __global__ __launch_bounds__(NWV * WAVE, 2) void rowtile_kernel(const RowTilePar
     rowtile_body<CT, IT, OT, BWD, VEC, NTW, KSMAX, DZIN, NWV>(p, (int)blockIdx.x, (int)gridDim.x, smem_raw);
 }
 
-// A backward-data launch with WEIGHT GRADIENTS as a side job: a weight gradient only needs what earlier launches have left (the dZ rows
-// the layer above handed down -- this launch's own input -- or, for the top layer, dY and Y; the S image of the forward), and
-// a batch of <= ~6 k rows leaves a third of the CUs without a row tile.  Workgroups [0, n_tiles) are row tiles, workgroups
+// A backward-data launch with the WEIGHT GRADIENT OF THE LAYER ABOVE as a side job: that gradient only needs the two fragment images
+// earlier launches have left (dZ_{l+1}, S_{l+1}), and a batch of <= ~6 k rows leaves a third of the CUs without a row tile.  Workgroups [0, n_tiles) are row tiles, workgroups
 // [wg_first, gridDim.x) (wg_first = n_tiles rounded up to 8, so that the weight gradient's block -> XCD map holds) contract one slice of
-// one output block of one of up to two layers each.  A two-layer backward sweep is then TWO launches: the top layer's backward-data
-// (which also leaves the bottom layer's dZ image) and the bottom layer's with both weight gradients riding.
-constexpr int SIDE_MAX = 2;
+// one output block each.  The last launch of the sweep is then the bottom layer's weight gradient alone: 7.5 us instead of 13.0 us for
+// both layers.
+// The weight gradient that rides: ONE layer's, planned for the CUs without a row tile (weight_grad_body of wgrad_common.h, (4 x 3)-tile
+// blocks, XCD-aware slice map).  Measured in round 3 and NOT adopted (profiles/r03_riders_*): both layers' gradients in
+// the bottom layer's launch (the dZ image of the layer below written by the hand-over epilogue) -- 22 us for that launch with (4 x 3)
+// blocks, 19 with (4 x 6), 20.5 with every CU sharing the units, 29 with an LDS-staged rows-form kernel -- against 10.5 + 7.5 us for this
+// launch plus the bottom layer's own: a CU retires ~1 float atomic per clock and a workgroup's fragment stream ~25 B per clock, so a
+// third of the chip cannot take both gradients in the time the row tiles need.
 struct SideWgrads {
-    WgradRowsParams l[SIDE_MAX];
-    int first[SIDE_MAX + 1];            // units [first[i], first[i+1]) belong to l[i]
-    int tile_unit0;                     // units [0, tile_unit0) are dealt round-robin to the passenger workgroups; unit tile_unit0 + t is done by
-                                        // row-tile workgroup t AFTER its tile (the units need nothing this launch computes)
-    int vec[SIDE_MAX], masked[SIDE_MAX];
+    WeightGradParams l;
+    int blocks;                         // passenger workgroups (a multiple of 8)
 };
-
-template <typename CT>
-__device__ __forceinline__ void side_unit(const SideWgrads& sw, const int u, unsigned char* smem_raw) {
-    const int li = u >= sw.first[1] ? 1 : 0;
-    const WgradRowsParams& w = sw.l[li];
-    const int uu = u - sw.first[li];
-    // (workgroup-uniform dispatch; the masked form only ever belongs to the top layer, which is l[0] when it rides)
-    if (sw.masked[li]) { if (sw.vec[li] == 8) wgrad_rows_unit<CT, 8, true>(w, uu, smem_raw); else wgrad_rows_unit<CT, 4, true>(w, uu, smem_raw); }
-    else               { if (sw.vec[li] == 8) wgrad_rows_unit<CT, 8, false>(w, uu, smem_raw); else wgrad_rows_unit<CT, 4, false>(w, uu, smem_raw); }
-}
 
 template <typename CT, typename IT, typename OT, int VEC, int NTW, int KSMAX>
 __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_wgrad_kernel(const RowTileParams p, const SideWgrads sw, const int n_tiles,
                                                                       const int wg_first) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int n_units = sw.first[SIDE_MAX];
-    if ((int)blockIdx.x < n_tiles) {
-        rowtile_body<CT, IT, OT, true, VEC, NTW, KSMAX, true>(p, (int)blockIdx.x, n_tiles, smem_raw);
-        const int u = sw.tile_unit0 + (int)blockIdx.x;
-        if (u < n_units) {                                   // workgroup-uniform
-            __syncthreads();                                 // the tile's LDS is free
-            side_unit<CT>(sw, u, smem_raw);
-        }
-    } else if ((int)blockIdx.x >= wg_first) {
-        const int n_pass = (int)gridDim.x - wg_first;
-        GCNPT_STAMP_REAL(p.stamps);
-        GCNPT_STAMP(p.stamps, 0);
-        for (int u = (int)blockIdx.x - wg_first; u < sw.tile_unit0; u += n_pass) {
-            side_unit<CT>(sw, u, smem_raw);
-            __syncthreads();                                 // every wave has left the stages: the next unit may fill them
-        }
-        GCNPT_STAMP(p.stamps, 10);
-    }
+    if ((int)blockIdx.x < n_tiles) rowtile_body<CT, IT, OT, true, VEC, NTW, KSMAX, true>(p, (int)blockIdx.x, n_tiles, smem_raw);
+    else if ((int)blockIdx.x >= wg_first) weight_grad_body<CT, RT_WAVES, WG_NT, WG_KB>(sw.l, (int)blockIdx.x - wg_first, smem_raw);
 }
 
 }  // namespace gcnpt
@@ -662,7 +636,7 @@ namespace gcnpt {
 
 // Weight gradients the next backward-data launch should carry (layers_bwd_impl sets it around that one call; thread-local because it
 // is only an argument that skips four levels of dispatch templates, not state: it never outlives the call that set it)
-struct SideWgrad { const SideWgrads* sw = nullptr; int passengers = 0; bool carried = false; };
+struct SideWgrad { const SideWgrads* sw = nullptr; bool carried = false; };
 extern thread_local SideWgrad t_side;      // defined in rowtile_kernels.hip
 
 
@@ -684,13 +658,13 @@ static inline int launch_rowtile_cfg(hipStream_t s, const RowTileParams& p) {
     const int n_tiles = ceil_div(p.N, ROWS);
     // the uniform-precision instantiations can carry the layer above's weight gradient on the CUs that have no row tile
     if constexpr (NWV == 8 && BWD && DZIN && std::is_same<IT, OT>::value && sizeof(CT) == sizeof(IT)) {
-        if (t_side.sw && t_side.sw->first[SIDE_MAX] > 0) {
+        if (t_side.sw && t_side.sw->blocks > 0) {
             auto kern = rowtile_wgrad_kernel<CT, IT, OT, VEC, NTW, KSMAX>;
             GCNPT_LDS_ATTR_ONCE(kern, 160 * 1024);
             const int wg_first = round_up(n_tiles, 8);
-            const int grid = wg_first + t_side.passengers;
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(RT_THREADS), std::max(lds, wgrad_rows_lds(sizeof(CT) == 2 ? GCNPT_BF16 : GCNPT_F32)), s, p, *t_side.sw, n_tiles, wg_first);
-            note_launch(grid, RT_THREADS, std::max(lds, wgrad_rows_lds(sizeof(CT) == 2 ? GCNPT_BF16 : GCNPT_F32)), sizeof(p) + sizeof(SideWgrads) + 8);
+            const int grid = wg_first + t_side.sw->blocks;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(RT_THREADS), std::max(lds, weight_grad_lds(RT_WAVES)), s, p, *t_side.sw, n_tiles, wg_first);
+            note_launch(grid, RT_THREADS, std::max(lds, weight_grad_lds(RT_WAVES)), sizeof(p) + sizeof(SideWgrads) + 8);
             GCNPT_HIP_CHECK(hipGetLastError());
             t_side.carried = true;
             return GCNPT_OK;

@@ -22,7 +22,6 @@ struct WeightGradParams {
     float* dW; float* db;
     int H, Din, m_tiles, n_tiles, nks, ks_per_wg;
     int mb, nb, slices;  // block grid; the launch grid is 1-D so that the block -> (m, n, slice) map can follow the XCDs
-    int flat;            // 1: workgroup id = slice * (mb * nb) + block, any number of slices (passengers of a row-tile launch)
     unsigned long long* stamps;   // diagnostic builds only
     int knob;
 };
@@ -67,14 +66,14 @@ __device__ __forceinline__ void weight_grad_body(const WeightGradParams& p, cons
     int slice, blk;
     // Which slices an XCD takes follows the row-tile kernels: XCD x wrote the x-th eighth of the row tiles (contiguous runs, see
     // rowtile_kernels.hip), i.e. of the k-steps, and those lines are still in ITS L2 when the images are read back.
-    if (p.flat)                   { const int nblk = p.mb * p.nb; slice = id / nblk; blk = id - slice * nblk; }
-    else if ((p.slices & 7) == 0) { const int sp = p.slices >> 3; slice = xg * sp + rest % sp; blk = rest / sp; }
+    if ((p.slices & 7) == 0) { const int sp = p.slices >> 3; slice = xg * sp + rest % sp; blk = rest / sp; }
     else                     { const int gp = 8 / p.slices;  slice = xg / gp;             blk = rest * gp + xg % gp; }
-    if (blk >= p.mb * p.nb || slice >= p.slices) return;
+    if (blk >= p.mb * p.nb) return;
     const int bm = blk % p.mb, bn = blk / p.mb;
     const int m0 = bm * WG_MT, n0 = bn * NT;
     const int ks_lo = slice * p.ks_per_wg, ks_hi = min(p.nks, ks_lo + p.ks_per_wg);
     const bool want_db = bn == 0 && p.db != nullptr;
+    GCNPT_STAMP_REAL(p.stamps);
     GCNPT_STAMP(p.stamps, 11);
 
     f32x4_t acc[WG_MT][NT];

@@ -261,10 +261,7 @@ class _GCNLayersFn(torch.autograd.Function):
         dhs = [torch.empty(ctx.lead + (K,), dtype=in_dtypes[l], device=dev) if (l > 0 or ctx.needs_input_grad[0]) else None
                for l, (_, K) in enumerate(dims)]
         if want_w:
-            # a layer whose dZ rows are in the compute type's storage and whose width is a multiple of 4 needs no dZ fragment image: its
-            # weight gradient reads the rows themselves (gcnpt_layer_bwd_weight_rows); the others get the image the kernels then write
-            rows_form = [_lib.dtype_code(outs[l].dtype) == compute and dims[l][0] % 4 == 0 for l in range(L)]
-            z_frag = [None if rows_form[l] else torch.empty((lib.gcnpt_frag_bytes(ctx.rows, H, compute),), **u8) for l, (H, _) in enumerate(dims)]
+            z_frag = [torch.empty((lib.gcnpt_frag_bytes(ctx.rows, H, compute),), **u8) for H, _ in dims]
             dWs = [torch.empty((H, K), dtype=torch.float32, device=dev) for H, K in dims]       # cleared by the sweep's launches
             dbs = [torch.empty((H,), dtype=torch.float32, device=dev) for H, _ in dims]
         ints = lambda v: (ctypes.c_int * L)(*v)  # noqa: E731

@@ -73,8 +73,8 @@ const char* gcnpt_last_error(void);
  *       fixed order (one contraction slice): run-to-run bit-identical weight gradients, as the reference's single-device autograd
  *       gives (model/gcn.py:270-271), at the price of the split contraction's parallelism
  *   GCNPT_OPT_FOUR_WAVES    (env GCNPT_WAVES4, default -1 = by batch size)  0 / 1 forces the 8- / 4-wave form of the layer kernel
- *   GCNPT_OPT_SIDE_TILES    (env GCNPT_SIDE_TILES, default 192)  batches of up to this many 32-row tiles carry their weight gradients
- *       as passengers of the backward-data launches (gcnpt_layers_bwd) */
+ *   GCNPT_OPT_SIDE_TILES    (env GCNPT_SIDE_TILES, default 192)  batches of up to this many 32-row tiles carry the weight gradient of
+ *       layer l+1 as a passenger of layer l's backward-data launch (gcnpt_layers_bwd) */
 #define GCNPT_OPT_DETERMINISTIC 0
 #define GCNPT_OPT_FOUR_WAVES 1
 #define GCNPT_OPT_SIDE_TILES 2
@@ -204,11 +204,9 @@ int gcnpt_layer_bwd_weight_multi(void* stream, int n_layers, const void* const* 
  * gcnpt_layers_bwd:  top layer first, gy = gradient of out[L-1] in y_dtype[L-1]; dh[l] = gradient of layer l's input in
  *   dh_dtype[l] (= y_dtype[l-1] for l > 0; dh[0] may be NULL when the input needs no gradient; dh[l] for l > 0 is scratch for
  *   the caller: it holds dZ of layer l-1, see the hand-over above); scale[l] = 1/(1-p_l) of the
- *   dropout layer l's forward applied.  s_frag == NULL: no weight gradients (dW, db, z_frag unused); otherwise s_frag[l], dW[l],
- *   db[l] for every layer.  z_frag[l] (or z_frag itself) may be NULL for a layer whose dZ rows take the rows form (y_dtype[l] ==
- *   compute_dtype, H[l] % 4 == 0: see gcnpt_layer_bwd_weight_rows) -- no dZ image is written then; other layers need their z_frag[l].
- *   The weight gradients ride in the backward-data launches (small batches, see gcnpt_layer_bwd_data_ex) or follow in one launch
- *   per form. */
+ *   dropout layer l's forward applied.  z_frag == NULL: no weight gradients (dW, db, s_frag unused); otherwise z_frag[l],
+ *   s_frag[l], dW[l], db[l] for every layer; the weight gradient of layer l+1 rides in layer l's backward-data launch (small batches,
+ *   see gcnpt_layer_bwd_data_wgrad) and what is left follows in ONE launch (gcnpt_layer_bwd_weight_multi). */
 int gcnpt_layers_fwd(void* stream, int n_layers, const void* x, int x_dtype, const void* const* w_fwd, const float* const* bias,
                      const int32_t* row_ptr, const int32_t* col_idx, const int32_t* ell, const int32_t* deg_ell, int B, int T,
                      const int* Din, const int* H, void* const* out, const int* out_dtype, int compute_dtype,
@@ -285,30 +283,17 @@ int gcnpt_layers_bwd_dz(void* stream, int n_layers, const void* dz_top, const vo
                         int compute_dtype, const float* scale, void* const* z_frag, const void* const* s_frag, float* const* dW,
                         float* const* db);
 
-/* ---- weight gradient from dZ ROWS (no dZ fragment image), and backward-data launches that carry weight gradients ----------------
- * gcnpt_layer_bwd_weight_rows: the same dW / db as gcnpt_layer_bwd_weight (model/gcn.py:270-271 differentiated; dW, db cleared by the
- * caller or an earlier launch), but the dZ operand is read as it lies in memory and transposed in LDS (csrc/wgrad_rows.h):
- *   dz [dev] [B*T, H] of rows_dtype = the layer's dZ (what the layer above handed down, see relu_src of gcnpt_layer_bwd_data) -- or,
- *   with Y given, the layer's dY, and dZ = dY * 1[Y > 0] * scale / (deg + 1) is formed on the fly (ell = the forward pattern's ELL head);
- *   s_frag = the forward's S image.  Needs rows_dtype == compute_dtype, H % 4 == 0 and 8-byte (bf16) / 16-byte (f32) aligned rows;
- *   GCNPT_E_UNSUPPORTED otherwise (use the image form).
- * gcnpt_layer_bwd_data_ex: gcnpt_layer_bwd_data plus what the backward sweep of a SMALL batch (<= GCNPT_OPT_SIDE_TILES row tiles: a third
- * of the CUs has no row tile) uses to get rid of its weight-gradient launches:
- *   down_zero_dW / down_zero_db / down_Din   NULL / 0, or the accumulators [Din x down_Din], [Din] of the layer BELOW to clear (its
- *       gradient will ride in its own backward-data launch);
- *   n_riders (0..2) rows-form weight gradients, each given like gcnpt_layer_bwd_weight_rows's arguments (r_Y[i] NULL = r_dz[i] is dZ;
- *       accumulators cleared by an EARLIER launch): they ride in this launch on the CUs without a row tile when the launch is a
- *       src_is_dz one in a uniform precision, otherwise they are launched right behind it -- enqueued on return either way.
- * gcnpt_layers_bwd / _bwd_dz use this for every layer: the gradient of layer l rides in layer l's own backward-data launch (its dZ rows
- * are that launch's input), the top layer's in the launch below it: an L >= 2 sweep of a small batch is L launches. */
-int gcnpt_layer_bwd_weight_rows(void* stream, const void* dz, const void* Y, const int32_t* ell, float scale, int rows_dtype,
-                                const void* s_frag, int B, int T, int Din, int H, float* dW, float* db, int compute_dtype);
-int gcnpt_layer_bwd_data_ex(void* stream, const void* dY, const void* Y, int g_dtype, const void* w_bwd, const int32_t* ell,
-                            const int32_t* rowT_ptr, const int32_t* colT_idx, const int32_t* ellT, int B, int T, int Din, int H,
-                            void* dh, int dh_dtype, int compute_dtype, float scale, void* z_frag, float* zero_dW, float* zero_db,
-                            const void* relu_src, float next_scale, int src_is_dz, float* down_zero_dW, float* down_zero_db,
-                            int down_Din, int n_riders, const void* const* r_dz, const void* const* r_Y, const float* r_scale,
-                            const void* const* r_s_frag, const int* r_Din, const int* r_H, float* const* r_dW, float* const* r_db);
+/* gcnpt_layer_bwd_data for layer l that ALSO computes the weight gradient of the layer above it (up_*: that layer's two fragment images,
+ * widths and accumulators, exactly gcnpt_layer_bwd_weight's arguments): for batches of up to GCNPT_OPT_SIDE_TILES row tiles (6 144 token
+ * rows) the gradient rides in the same launch, on the CUs that have no row tile (one launch boundary less on the step's critical path: the
+ * last launch of a backward sweep is then the bottom layer's weight gradient alone); otherwise it is launched right after.
+ * gcnpt_layers_bwd / _bwd_dz do this for every layer but the top one.  (Round 3 measured putting BOTH gradients of a two-layer sweep into
+ * the bottom layer's launch, four ways: slower every time) */
+int gcnpt_layer_bwd_data_wgrad(void* stream, const void* dY, const void* Y, int g_dtype, const void* w_bwd, const int32_t* ell,
+                               const int32_t* rowT_ptr, const int32_t* colT_idx, const int32_t* ellT, int B, int T, int Din, int H,
+                               void* dh, int dh_dtype, int compute_dtype, float scale, void* z_frag, float* zero_dW, float* zero_db,
+                               const void* relu_src, float next_scale, int src_is_dz, const void* up_z_frag, const void* up_s_frag,
+                               int up_Din, int up_H, float* up_dW, float* up_db);
 /* Launches [first_launch, first_launch + n_launches) of the sweep gcnpt_layers_bwd (gy_is_dz = 0) / gcnpt_layers_bwd_dz (1) would
  * enqueue, in its order (measurement aid: bench.py times truncated steps to charge each launch its in-step duration). */
 int gcnpt_layers_bwd_range(void* stream, int n_layers, const void* gy, const void* const* Y, const int* y_dtype,

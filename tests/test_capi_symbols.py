@@ -55,24 +55,11 @@ def test_argument_validation_needs_no_gpu():
     none2 = (ctypes.c_void_p * 2)(None, None)
     assert L.gcnpt_layers_bwd(None, 2, p, ptrs, two(0, 0), ptrs, p, p, p, p, 1, 1, two(8, 8), two(8, 8), none2, two(0, 0), 0, f2, None, None, None, None) == _lib.E_INVALID
     assert b"dh[1] must exist" in L.gcnpt_last_error()
-    assert L.gcnpt_layers_bwd(None, 2, p, ptrs, two(0, 0), ptrs, p, p, p, p, 1, 1, two(8, 8), two(8, 8), ptrs, two(0, 0), 0, f2, None, ptrs, None, None) == _lib.E_INVALID
+    assert L.gcnpt_layers_bwd(None, 2, p, ptrs, two(0, 0), ptrs, p, p, p, p, 1, 1, two(8, 8), two(8, 8), ptrs, two(0, 0), 0, f2, ptrs, None, None, None) == _lib.E_INVALID
     assert b"weight gradients need" in L.gcnpt_last_error()
-    # a layer whose dZ rows cannot take the rows form (width 6) needs its z_frag
-    assert L.gcnpt_layers_bwd(None, 2, p, ptrs, two(0, 0), ptrs, p, p, p, p, 1, 1, two(8, 6), two(6, 6), ptrs, two(0, 0), 0, f2, None, ptrs, ptrs, ptrs) == _lib.E_INVALID
-    assert b"needs z_frag" in L.gcnpt_last_error()
-    # the extended backward-data call: at most two weight gradients ride, each with its dZ rows, S image and accumulators
-    f2b = (ctypes.c_float * 2)(1.0, 1.0)
-    assert L.gcnpt_layer_bwd_data_ex(None, p, p, 0, p, p, p, p, p, 1, 1, 8, 8, p, 0, 0, 1.0, None, None, None, None, 1.0, 1, None, None, 0,
-                                     3, ptrs, none2, f2b, ptrs, two(8, 8), two(8, 8), ptrs, ptrs) == _lib.E_INVALID
-    assert b"can ride" in L.gcnpt_last_error()
-    assert L.gcnpt_layer_bwd_data_ex(None, p, p, 0, p, p, p, p, p, 1, 1, 8, 8, p, 0, 0, 1.0, None, None, None, None, 1.0, 1, None, None, 0,
-                                     1, none2, none2, f2b, ptrs, two(8, 8), two(8, 8), ptrs, ptrs) == _lib.E_INVALID
-    # rows-form riders need rows in the compute dtype's storage with a width that is a multiple of 4
-    assert L.gcnpt_layer_bwd_data_ex(None, p, p, 0, p, p, p, p, p, 1, 1, 8, 8, p, 0, 0, 1.0, None, None, None, None, 1.0, 1, None, None, 0,
-                                     1, ptrs, none2, f2b, ptrs, two(8, 8), two(7, 7), ptrs, ptrs) == _lib.E_INVALID
-    assert b"width % 4" in L.gcnpt_last_error()
-    assert L.gcnpt_layer_bwd_weight_rows(None, p, None, None, 1.0, _lib.BF16, p, 1, 1, 8, 8, p, p, _lib.F32) == _lib.E_UNSUPPORTED
-    assert L.gcnpt_layer_bwd_weight_rows(None, p, p, None, 1.0, _lib.F32, p, 1, 1, 8, 8, p, p, _lib.F32) == _lib.E_INVALID       # Y without ell
+    # the backward-data call that carries the layer above's weight gradient needs that gradient's images and accumulators
+    assert L.gcnpt_layer_bwd_data_wgrad(None, p, p, 0, p, p, p, p, p, 1, 1, 8, 8, p, 0, 0, 1.0, p, p, p, None, 1.0, 1, None, p, 8, 8, p, p) == _lib.E_INVALID
+    assert b"two fragment images" in L.gcnpt_last_error()
     # the option table: the library's one piece of process state, no environment access after load
     assert L.gcnpt_get_option(_lib.OPT_SIDE_TILES) == 192 and L.gcnpt_get_option(_lib.OPT_FOUR_WAVES) == -1
     assert L.gcnpt_set_option(99, 1) == _lib.E_INVALID and L.gcnpt_set_option(_lib.OPT_DETERMINISTIC, 2) == _lib.E_INVALID

@@ -410,8 +410,8 @@ def test_layers_full_size_vs_oracle(api, dev, cfg):
 @pytest.mark.parametrize("compute", [torch.float32, torch.bfloat16])
 def test_one_op_path_full_size_c2_vs_oracle(api, dev, compute):
     """the EXACT launch sequence bench.py times -- gcn.gcn_layers = gcnpt_pack_weights_multi, gcnpt_layers_fwd,
-    gcnpt_layers_bwd: dZ hand-over between the layers, the bottom layer's dZ image from the top layer's epilogue, both weight gradients
-    riding in the bottom layer's launch -- at the full C2 size (B=50, T=100, 360 -> 200 -> 200, K=1), dropout 0.5 between the layers
+    gcnpt_layers_bwd: dZ hand-over between the layers, layer 1's weight gradient riding in layer 0's backward-data launch, layer 0's
+    in the last launch -- at the full C2 size (B=50, T=100, 360 -> 200 -> 200, K=1), dropout 0.5 between the layers
     with the mask recovered from the stored activations, against the oracle: fp32 1e-5 / 1e-4, bf16 2e-2 through the device's own
     activations."""
     from gcn_over_pruned_trees_amd.utils import synthetic
@@ -1737,9 +1737,8 @@ def test_classifier_packs_with_the_tree_launch(api, dev):
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("compute", [torch.float32, torch.bfloat16])
 def test_three_layer_sweep_carries_weight_gradients_vs_oracle(api, dev, compute):
-    """Three layers: the weight gradients of layers 2 and 1 ride in the backward-data launch of layer 1 (layer 1's dZ image comes from
-    layer 2's hand-over epilogue), layer 0's in its own launch: three launches, none at the end.  Every gradient against the oracle
-    (model/gcn.py:266-271, 390-393 and their autograd)."""
+    """Three layers: the weight gradients of layers 2 and 1 ride in the backward-data launches of layers 1 and 0, the last launch is
+    layer 0's alone.  Every gradient against the oracle (model/gcn.py:266-271, 390-393 and their autograd)."""
     from gcn_over_pruned_trees_amd.utils import synthetic
     from oracle import gcn_ref, prune_ref
     gcn, tree = api

@@ -100,13 +100,18 @@ __device__ __forceinline__ void wave_exclusive_scan3(int* a, int* b, int* c, int
 constexpr int PW_SHIFT = 12, PW_MASK = (1 << PW_SHIFT) - 1, PRUNE_MAX_T = PW_MASK - 3;
 __device__ __forceinline__ int pw_par(int w) { return (w & PW_MASK) - 2; }
 
-// wave 0 runs the pruning phases alone, separated by wave_lds_fence() (gcnpt_common.h)
+// Sentences of up to PRUNE_WAVE0_T tokens: wave 0 runs the pruning phases alone, separated by wave_lds_fence() (gcnpt_common.h) -- two
+// tokens per lane and no workgroup barrier.  Longer ones (ALLW): every phase is a loop over the tokens by ALL 1024 threads with a
+// workgroup barrier behind it, so a 300-token sentence is one round per phase instead of five (round 2: 30 us at T = 300).
+constexpr int PRUNE_WAVE0_T = 128;
 
-// Phases of wave 0: lengths, LCA, path, distances, kept tokens, degrees, row offsets, compacted edge rows.
+// Phases: lengths, LCA, path, distances, kept tokens, degrees, row offsets, compacted edge rows.
+// s_red: [0] pad slots, [1] subject tokens, [2] entity tokens, [3] lca (workgroup-wide sums / minimum of the ALLW form)
+template <bool ALLW>
 __device__ void prune_sentence(const int64_t* __restrict__ head, const int64_t* __restrict__ subj_pos,
                                const int64_t* __restrict__ obj_pos, const int64_t* __restrict__ deprel,
                                const uint8_t* __restrict__ pad_mask, const int32_t* __restrict__ len_in, int b, int B, int T,
-                               int prune_k, int cap, int* smem, int* s_err, int* s_status, int* s_nrows,
+                               int prune_k, int cap, int* smem, int* s_err, int* s_status, int* s_nrows, int* s_red,
                                int32_t* __restrict__ row_ptr, int32_t* __restrict__ rowT_ptr, int32_t* __restrict__ ell,
                                int32_t* __restrict__ ellT, uint8_t* __restrict__ pool_mask, int32_t* __restrict__ status,
                                unsigned long long* stamps) {
@@ -118,23 +123,34 @@ __device__ void prune_sentence(const int64_t* __restrict__ head, const int64_t* 
     int* lab = rank + T + 1;       // [T]   deprel id of the token
     int* einfo = lab + T;          // [T]   compacted edge rows: token | (parent+2) << 12 | child/label bits << 24
     const int lane = threadIdx.x & 63;
+    const int t0 = ALLW ? (int)threadIdx.x : lane;            // this thread's first token
+    constexpr int NT = ALLW ? PRUNE_THREADS : WAVE;           // token stride
     const size_t base = (size_t)b * T;
+    auto phase_sync = [&]() { if constexpr (ALLW) __syncthreads(); else wave_lds_fence(); };
+    // sum over the participating threads (ALLW: through s_red[slot], which the kernel cleared; the caller syncs before reading)
+    auto team_sum = [&](int v, int slot) {
+        v = wave_sum(v);
+        if constexpr (ALLW) { if (lane == 0 && v) atomicAdd(&s_red[slot], v); }
+        return v;
+    };
 
-    // ---- stage the parse (tree.py:60-63, 82-83).  Two tokens per lane per round, every load of the round issued before the
-    // first use (clamped addresses, no load behind a condition): a sentence of up to 128 tokens costs ONE memory round trip
+    // ---- stage the parse (tree.py:60-63, 82-83).  Wave-0 form: two tokens per lane per round, every load of the round issued before
+    // the first use (clamped addresses, no load behind a condition): a sentence of up to 128 tokens costs ONE memory round trip.
+    // ALLW: one token per thread, one round for up to 1024 tokens.
     int npad = 0;
-    for (int i0 = 0; i0 < T; i0 += 2 * WAVE) {
-        int64_t h[2], sp[2], op[2], d[2];
-        bool pad[2];
+    constexpr int PER = ALLW ? 1 : 2;
+    for (int i0 = 0; i0 < T; i0 += PER * NT) {
+        int64_t h[PER], sp[PER], op[PER], d[PER];
+        bool pad[PER];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const size_t j = base + min(i0 + u * WAVE + lane, T - 1);
+        for (int u = 0; u < PER; ++u) {
+            const size_t j = base + min(i0 + u * NT + t0, T - 1);
             h[u] = head[j]; sp[u] = subj_pos[j]; op[u] = obj_pos[j]; d[u] = deprel[j];
             pad[u] = pad_mask ? pad_mask[j] != 0 : false;
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int i = i0 + u * WAVE + lane;
+        for (int u = 0; u < PER; ++u) {
+            const int i = i0 + u * NT + t0;
             if (i >= T) continue;
             npad += pad[u] ? 1 : 0;
             int f = 0;
@@ -148,10 +164,18 @@ __device__ void prune_sentence(const int64_t* __restrict__ head, const int64_t* 
         }
     }
     // sentence length = number of non-pad slots (gcn.py:96)
-    const int len = pad_mask ? T - wave_sum(npad) : min(max(len_in[b], 0), T);
-    if (lane == 0 && (long long)B * T > PRUNE_SCAN_MAX) atomicMax(&status[B], len);     // small batches: workgroup 0 scans, see the kernel
+    int len;
+    if (pad_mask) {
+        const int np = team_sum(npad, 0);
+        if constexpr (ALLW) { __syncthreads(); len = T - s_red[0]; } else { len = T - np; }
+    } else {
+        len = min(max(len_in[b], 0), T);
+    }
+    // (the longest sentence: workgroup 0's idle waves scan for it, see the kernel; batches too big for that / sentences that leave no
+    // idle wave: one atomicMax per sentence on a word prune_impl cleared)
+    if (threadIdx.x == 0 && ((long long)B * T > PRUNE_SCAN_MAX || (ALLW && T + WAVE > PRUNE_THREADS))) atomicMax(&status[B], len);
     int nsubj = 0, nent = 0;
-    for (int i = lane; i < T; i += WAVE) {
+    for (int i = t0; i < T; i += NT) {
         const int w = pw[i];
         int f = w >> PW_SHIFT, p = pw_par(w);
         if (i >= len) { f = 0; p = -1; }
@@ -160,13 +184,14 @@ __device__ void prune_sentence(const int64_t* __restrict__ head, const int64_t* 
         nent += ((f & F_SUBJ) ? 1 : 0) + ((f & F_OBJ) ? 1 : 0);
         pw[i] = (p + 2) | (f << PW_SHIFT);
     }
-    nsubj = wave_sum(nsubj);
-    nent = wave_sum(nent);
-    wave_lds_fence();
+    nsubj = team_sum(nsubj, 1);
+    nent = team_sum(nent, 2);
+    phase_sync();
+    if constexpr (ALLW) { nsubj = s_red[1]; nent = s_red[2]; }
     GCNPT_STAMP(stamps, 1);
 
     // ---- every entity token walks to the root, counting visits (tree.py:86-109)
-    for (int i = lane; i < len; i += WAVE) {
+    for (int i = t0; i < len; i += NT) {
         const int f = pw[i] >> PW_SHIFT;
         const int w = ((f & F_SUBJ) ? 1 : 0) + ((f & F_OBJ) ? 1 : 0);
         if (!w) continue;
@@ -178,7 +203,7 @@ __device__ void prune_sentence(const int64_t* __restrict__ head, const int64_t* 
         }
         if (a == -2) atomicOr(s_err, ERR_CHAIN_BADHEAD);
     }
-    wave_lds_fence();
+    phase_sync();
     int err = 0;
     if (*s_err & ERR_CHAIN_BADHEAD) err = GCNPT_E_BAD_HEAD;
     else if (*s_err & ERR_CHAIN_CYCLE) err = GCNPT_E_CYCLE;
@@ -187,28 +212,33 @@ __device__ void prune_sentence(const int64_t* __restrict__ head, const int64_t* 
 
     // ---- common ancestors and the lowest of them (tree.py:112-124)
     int lca = 0x7fffffff;
-    if (!err) {
-        for (int i = lane; i < len; i += WAVE)
+    if (!err) {                                          // (err is the same in every thread: the syncs below are uniform)
+        for (int i = t0; i < len; i += NT)
             if (cnt[i] == nent) pw[i] |= F_CA << PW_SHIFT;
-        wave_lds_fence();
-        for (int i = lane; i < len; i += WAVE) {
+        phase_sync();
+        for (int i = t0; i < len; i += NT) {
             const int w = pw[i], p = pw_par(w);
             if ((w & (F_CA << PW_SHIFT)) && p >= 0 && (pw[p] & (F_CA << PW_SHIFT))) atomicOr(&pw[p], F_CA_HASCHILD << PW_SHIFT);
         }
-        wave_lds_fence();
-        for (int i = lane; i < len; i += WAVE)
+        phase_sync();
+        for (int i = t0; i < len; i += NT)
             if (((pw[i] >> PW_SHIFT) & (F_CA | F_CA_HASCHILD)) == F_CA) lca = min(lca, i);
         lca = wave_min(lca);
+        if constexpr (ALLW) {
+            if (lane == 0 && lca != 0x7fffffff) atomicMin(&s_red[3], lca);
+            __syncthreads();
+            lca = s_red[3];
+        }
         if (lca == 0x7fffffff) err = GCNPT_E_NO_LCA;
     }
     GCNPT_STAMP(stamps, 3);
 
     // ---- path nodes, distance to the path, kept tokens (tree.py:126-147)
     if (!err) {
-        for (int i = lane; i < len; i += WAVE)
+        for (int i = t0; i < len; i += NT)
             if ((cnt[i] > 0 && !(pw[i] & (F_CA << PW_SHIFT))) || i == lca) pw[i] |= F_PATH << PW_SHIFT;
-        wave_lds_fence();
-        for (int i = lane; i < len; i += WAVE) {
+        phase_sync();
+        for (int i = t0; i < len; i += NT) {
             int a = i, d = 0, w = pw[i];
             while (a >= 0 && !(w & (F_PATH << PW_SHIFT))) {          // one LDS read per step
                 a = pw_par(w);
@@ -220,7 +250,7 @@ __device__ void prune_sentence(const int64_t* __restrict__ head, const int64_t* 
             const bool child = keep && i != lca && pw_par(pw[i]) >= 0;
             cnt[i] = (keep ? K_KEEP : 0) | (child ? K_CHILD : 0);   // cnt is free from here on
         }
-        wave_lds_fence();
+        phase_sync();
         if (*s_err & ERR_BADHEAD) err = GCNPT_E_BAD_HEAD;
         else if (*s_err & ERR_CYCLE) err = GCNPT_E_CYCLE;
     }
@@ -228,7 +258,7 @@ __device__ void prune_sentence(const int64_t* __restrict__ head, const int64_t* 
 
     // ---- degrees of the labelled adjacency tree_to_adj would write (tree.py:182-192)
     if (!err) {
-        for (int i = lane; i < len; i += WAVE) {
+        for (int i = t0; i < len; i += NT) {
             if (!(cnt[i] & K_CHILD)) continue;
             const int w = pw[i], p = pw_par(w), f = w >> PW_SHIFT;
             if (!(cnt[p] & K_KEEP)) atomicOr(s_err, ERR_ASSERT);   // tree.py:159
@@ -237,49 +267,52 @@ __device__ void prune_sentence(const int64_t* __restrict__ head, const int64_t* 
             atomicOr(&pw[p], F_HASEDGE << PW_SHIFT);
             atomicOr(&pw[i], F_HASEDGE << PW_SHIFT);
         }
-        wave_lds_fence();
+        phase_sync();
         if (*s_err & ERR_ASSERT) err = GCNPT_E_ASSERT;
     }
     int n_edge_rows = 0;
     if (!err) {
-        for (int i = lane; i < T; i += WAVE) {
+        for (int i = t0; i < T; i += NT) {
             const int he = (i < len && (pw[i] & (F_HASEDGE << PW_SHIFT))) ? 1 : 0;
             deg[i] += he; degT[i] += he;                             // the 84 on the diagonal
             rank[i] = he;
             if (pool_mask) pool_mask[base + i] = (deg[i] + degT[i]) == 0;   // gcn.py:262
         }
-        wave_lds_fence();
-        int tot, totT;
-        wave_exclusive_scan3(deg, degT, rank, T, lane, tot, totT, n_edge_rows);
-        if (lane == 0) { deg[T] = tot; degT[T] = totT; }
-        wave_lds_fence();
-        if (tot > cap || totT > cap) err = GCNPT_E_CAPACITY;
+        phase_sync();
+        if (!ALLW || threadIdx.x < WAVE) {                           // the three scans: one wave (lane l owns a contiguous segment)
+            int tot, totT;
+            wave_exclusive_scan3(deg, degT, rank, T, lane, tot, totT, n_edge_rows);
+            if (lane == 0) { deg[T] = tot; degT[T] = totT; rank[T] = n_edge_rows; }
+        }
+        phase_sync();
+        n_edge_rows = rank[T];
+        if (deg[T] > cap || degT[T] > cap) err = GCNPT_E_CAPACITY;
     }
     GCNPT_STAMP(stamps, 5);
 
     if (err) {   // the sentence contributes no edges; every row is empty and masked
-        for (int i = lane; i <= T; i += WAVE) {
+        for (int i = t0; i <= T; i += NT) {
             row_ptr[(size_t)b * (T + 1) + i] = b * cap;
             if (rowT_ptr) rowT_ptr[(size_t)b * (T + 1) + i] = b * cap;
         }
-        for (int i = lane; i < T; i += WAVE)
+        for (int i = t0; i < T; i += NT)
             if (pool_mask) pool_mask[base + i] = 1;
-        for (int i = lane; i < T * 8; i += WAVE) {
+        for (int i = t0; i < T * 8; i += NT) {
             ell[base * 8 + i] = 0;
             if (ellT) ellT[base * 8 + i] = 0;
         }
-        if (lane == 0) { status[b] = err; *s_status = err; }
+        if (threadIdx.x == 0) { status[b] = err; *s_status = err; }
         return;
     }
 
     // ---- emit both patterns, columns ascending (same order a dense -> CSR conversion gives).
     // Only rows that carry an edge have entries, and only such rows appear as columns: compact them (ascending)
     // with everything the inner loop needs in ONE word, so that loop is a stream of broadcast LDS reads.
-    for (int i = lane; i <= T; i += WAVE) {
+    for (int i = t0; i <= T; i += NT) {
         row_ptr[(size_t)b * (T + 1) + i] = b * cap + deg[i];
         if (rowT_ptr) rowT_ptr[(size_t)b * (T + 1) + i] = b * cap + degT[i];
     }
-    for (int i = lane; i < T; i += WAVE) {
+    for (int i = t0; i < T; i += NT) {
         const int w = i < len ? pw[i] : 0;
         if (w & (F_HASEDGE << PW_SHIFT)) {
             const int f = w >> PW_SHIFT;
@@ -294,69 +327,160 @@ __device__ void prune_sentence(const int64_t* __restrict__ head, const int64_t* 
             }
         }
     }
-    wave_lds_fence();
+    if constexpr (!ALLW) wave_lds_fence();                          // (ALLW: the kernel's barrier in front of emit_rows)
     GCNPT_STAMP(stamps, 6);
-    if (lane == 0) { *s_nrows = n_edge_rows; status[b] = 0; }
+    if (threadIdx.x == 0) { *s_nrows = n_edge_rows; status[b] = 0; }
 }
 
-// All 4 waves: the CSR entries and ELL heads of the rows that carry an edge.  One row at a time per wave, one
-// candidate column per lane: ballot + prefix popcount give every entry its slot, no inner loop, no LDS traffic
-// (row info comes from the other lanes' registers with v_readlane).
-__device__ void emit_rows(int b, int T, int cap, int* smem, int err, int n_edge_rows, int lane, int wave,
+// One row of both patterns by ONE WAVE: one candidate column per lane (the edge rows, ascending), ballot + prefix popcount give every
+// entry its slot -- no sorting, any number of entries.  rw / rdeg / rdegT / rlab: the chunk's row info in the lanes' registers (row qq of
+// the chunk is read with v_readlane).
+__device__ __forceinline__ void emit_row_scan(int b, int T, int cap, const int* lab, const int* einfo, int n_edge_rows, int lane, int me, int labr_raw,
+                                              int o_rel, int oT_rel, int32_t* __restrict__ col_idx, int32_t* __restrict__ label,
+                                              int32_t* __restrict__ colT_idx, int32_t* __restrict__ ell, int32_t* __restrict__ ellT) {
+    const size_t base = (size_t)b * T;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int r = me & 0xfff, rp = ((me >> 12) & 0xfff) - 2;
+    const bool rchild = me & (1 << 24), rfwd = me & (1 << 25), rrev = me & (1 << 26);
+    const int labr = labr_raw + FWD_BOUND;
+    const int o = b * cap + o_rel, oT = b * cap + oT_rel;
+    int32_t* hd = ell + (base + r) * 8;                       // ELL head: [0] = count, [1..7] = first 7 columns
+    int32_t* hdT = ellT ? ellT + (base + r) * 8 : nullptr;
+    int n_e = 0, n_eT = 0;
+    for (int k0 = 0; k0 < n_edge_rows; k0 += WAVE) {          // candidate columns: the edge rows, ascending
+        const bool valid = k0 + lane < n_edge_rows;
+        const int w = valid ? einfo[k0 + lane] : 0;
+        const int j = w & 0xfff, jp = ((w >> 12) & 0xfff) - 2;
+        const bool is_child = valid && (w & (1 << 24)) && jp == r;      // j is a kept child of r
+        const bool is_self = valid && j == r;
+        const bool is_par = valid && rchild && j == rp;
+        const bool e = (is_child && (w & (1 << 25))) || is_self || (is_par && rrev);      // adj[r,j] != 0
+        const bool eT = (is_child && (w & (1 << 26))) || is_self || (is_par && rfwd);     // adj[j,r] != 0
+        const unsigned long long m = __ballot(e), mT = __ballot(eT);
+        if (e) {
+            const int pos = n_e + __popcll(m & lt);
+            col_idx[o + pos] = j;
+            if (label) label[o + pos] = is_self ? SELF_LOOP_ID : (is_child ? lab[j] : labr);
+            if (pos < 7) hd[1 + pos] = j;
+        }
+        if (eT) {
+            const int pos = n_eT + __popcll(mT & lt);
+            if (colT_idx) colT_idx[oT + pos] = j;
+            if (hdT && pos < 7) hdT[1 + pos] = j;
+        }
+        n_e += __popcll(m);
+        n_eT += __popcll(mT);
+    }
+    if (lane < 8) {                                           // count, and zeros in the unused slots
+        if (lane == 0) hd[0] = n_e; else if (lane > n_e) hd[lane] = 0;
+        if (hdT) { if (lane == 0) hdT[0] = n_eT; else if (lane > n_eT) hdT[lane] = 0; }
+    }
+}
+
+// All 16 waves: the CSR entries and ELL heads of the rows that carry an edge.
+// STAGED (sentences whose entry lists fit LDS beside the pruning arrays): every edge row is a THREAD.  It appends its own entries
+// (diagonal; for a kept child also the pair with its parent) to the rows' LDS segments through per-row fill counters, and after one
+// barrier sorts its row's segment by column (an insertion sort: a row of a pruned tree has 2-4 entries) and writes it out with its
+// ELL head.  Rows with more than EMIT_SORT_MAX entries (a star-shaped parse) go to the scan form below, one wave each.
+// Otherwise: one row at a time per wave, one candidate column per lane (emit_row_scan) -- O(rows^2 / 64) wave iterations, which at
+// T = 300, K = 2 was 11-25 k cycles of the sentence's 29-43 k.
+constexpr int EMIT_SORT_MAX = 12;
+__device__ void emit_rows(int b, int T, int cap, int* smem, int err, int n_edge_rows, int lane, int wave, bool staged,
                           int32_t* __restrict__ col_idx, int32_t* __restrict__ label, int32_t* __restrict__ colT_idx,
                           int32_t* __restrict__ ell, int32_t* __restrict__ ellT, unsigned long long* stamps) {
     if (err) return;
     GCNPT_STAMP(stamps, 8);
+    int* cnt = smem + T;               // free after the pruning phases: fill counter of the forward rows
     int* deg = smem + 2 * T;
     int* degT = deg + T + 1;
-    int* lab = degT + 2 * (T + 1);
+    int* rank = degT + T + 1;          // free as well: fill counter of the transposed rows
+    int* lab = rank + T + 1;
     int* einfo = lab + T;
     const size_t base = (size_t)b * T;
-    const unsigned long long lt = (1ull << lane) - 1ull;
+    if (staged && n_edge_rows > WAVE) {          // (up to 64 edge rows the scan form is as fast: 4.7 k against 5.3 k cycles at T = 100, K = 1)
+        int* entF = einfo + T;         // [nnz]  forward entries: column (the label follows from the pair, see below)
+        int* entT = entF + 3 * T;      // [nnzT] transposed entries: column
+        int* longrows = entT + 3 * T;  // [<= T / EMIT_SORT_MAX + 1] edge rows left to the scan form; [T-1] (end of the region) = their count
+        int* n_long = longrows + T - 1;
+        for (int i = threadIdx.x; i < T; i += PRUNE_THREADS) { cnt[i] = 0; rank[i] = 0; }
+        if (threadIdx.x == 0) *n_long = 0;
+        __syncthreads();
+        for (int q = threadIdx.x; q < n_edge_rows; q += PRUNE_THREADS) {
+            const int me = einfo[q];
+            const int r = me & 0xfff, rp = ((me >> 12) & 0xfff) - 2;
+            entF[deg[r] + atomicAdd(&cnt[r], 1)] = r;                                               // adj[r,r] = 84 (tree.py:186-187)
+            entT[degT[r] + atomicAdd(&rank[r], 1)] = r;
+            if (me & (1 << 24)) {                                                                   // r is a kept child of rp
+                if (me & (1 << 25)) {                                                               // adj[rp,r] = deprel[r]
+                    entF[deg[rp] + atomicAdd(&cnt[rp], 1)] = r;
+                    entT[degT[r] + atomicAdd(&rank[r], 1)] = rp;
+                }
+                if (me & (1 << 26)) {                                                               // adj[r,rp] = deprel[r] + 42
+                    entF[deg[r] + atomicAdd(&cnt[r], 1)] = rp;
+                    entT[degT[rp] + atomicAdd(&rank[rp], 1)] = r;
+                }
+            }
+        }
+        __syncthreads();
+        for (int q = threadIdx.x; q < n_edge_rows; q += PRUNE_THREADS) {
+            const int r = einfo[q] & 0xfff;
+            const int o = deg[r], n = deg[r + 1] - o, oT = degT[r], nT = degT[r + 1] - oT;
+            if (n > EMIT_SORT_MAX || nT > EMIT_SORT_MAX) { longrows[atomicAdd(n_long, 1)] = q; continue; }
+            int v[EMIT_SORT_MAX], vT[EMIT_SORT_MAX];
+#pragma unroll
+            for (int k = 0; k < EMIT_SORT_MAX; ++k) {
+                v[k] = k < n ? entF[o + k] : 0x7fffffff;
+                vT[k] = k < nT ? entT[oT + k] : 0x7fffffff;
+            }
+            // (a fixed odd-even transposition network keeps the arrays in registers; unused slots hold INT_MAX and stay behind)
+#pragma unroll
+            for (int pass = 0; pass < EMIT_SORT_MAX; ++pass)
+#pragma unroll
+                for (int k = pass & 1; k + 1 < EMIT_SORT_MAX; k += 2) {
+                    const bool sw = v[k] > v[k + 1];
+                    const int lo = sw ? v[k + 1] : v[k], hi = sw ? v[k] : v[k + 1];
+                    v[k] = lo; v[k + 1] = hi;
+                    const bool swT = vT[k] > vT[k + 1];
+                    const int loT = swT ? vT[k + 1] : vT[k], hiT = swT ? vT[k] : vT[k + 1];
+                    vT[k] = loT; vT[k + 1] = hiT;
+                }
+            int hd[8], hdT[8];
+            hd[0] = n; hdT[0] = nT;
+#pragma unroll
+            for (int k = 0; k < EMIT_SORT_MAX; ++k) {
+                if (k < n) {
+                    const int j = v[k];
+                    col_idx[b * cap + o + k] = j;
+                    // the value tree_to_adj wrote there (tree.py:184-192): 84 on the diagonal, deprel[j] for a child j, deprel[r] + 42 for the parent
+                    if (label) label[b * cap + o + k] = j == r ? SELF_LOOP_ID : (pw_par(smem[j]) == r ? lab[j] : lab[r] + FWD_BOUND);
+                }
+                if (k < nT && colT_idx) colT_idx[b * cap + oT + k] = vT[k];
+                if (k < 7) { hd[1 + k] = k < n ? v[k] : 0; hdT[1 + k] = k < nT ? vT[k] : 0; }
+            }
+            int4* e = reinterpret_cast<int4*>(ell + (base + r) * 8);
+            e[0] = make_int4(hd[0], hd[1], hd[2], hd[3]); e[1] = make_int4(hd[4], hd[5], hd[6], hd[7]);
+            if (ellT) {
+                int4* eT = reinterpret_cast<int4*>(ellT + (base + r) * 8);
+                eT[0] = make_int4(hdT[0], hdT[1], hdT[2], hdT[3]); eT[1] = make_int4(hdT[4], hdT[5], hdT[6], hdT[7]);
+            }
+        }
+        __syncthreads();
+        const int nl = *n_long;
+        for (int x = wave; x < nl; x += PRUNE_THREADS / WAVE) {           // the few long rows: one wave each, scan form
+            const int me = einfo[longrows[x]];
+            const int r = me & 0xfff;
+            emit_row_scan(b, T, cap, lab, einfo, n_edge_rows, lane, me, lab[r], deg[r], degT[r], col_idx, label, colT_idx, ell, ellT);
+        }
+        GCNPT_STAMP(stamps, 7);
+        return;
+    }
     for (int q0 = 0; q0 < n_edge_rows; q0 += WAVE) {                  // rows, a chunk of 64 at a time (registers)
         const int rw = q0 + lane < n_edge_rows ? einfo[q0 + lane] : 0;
         const int rdeg = deg[rw & 0xfff], rdegT = degT[rw & 0xfff], rlab = lab[rw & 0xfff];
         const int nq = min(WAVE, n_edge_rows - q0);
         for (int qq = wave; qq < nq; qq += PRUNE_THREADS / WAVE) {    // this wave's rows of the chunk
-            const int me = __builtin_amdgcn_readlane(rw, qq);
-            const int r = me & 0xfff, rp = ((me >> 12) & 0xfff) - 2;
-            const bool rchild = me & (1 << 24), rfwd = me & (1 << 25), rrev = me & (1 << 26);
-            const int labr = __builtin_amdgcn_readlane(rlab, qq) + FWD_BOUND;
-            int o = b * cap + __builtin_amdgcn_readlane(rdeg, qq), oT = b * cap + __builtin_amdgcn_readlane(rdegT, qq);
-            int32_t* hd = ell + (base + r) * 8;                       // ELL head: [0] = count, [1..7] = first 7 columns
-            int32_t* hdT = ellT ? ellT + (base + r) * 8 : nullptr;
-            int n_e = 0, n_eT = 0;
-            for (int k0 = 0; k0 < n_edge_rows; k0 += WAVE) {          // candidate columns: the edge rows, ascending
-                const bool valid = k0 + lane < n_edge_rows;
-                const int w = valid ? einfo[k0 + lane] : 0;
-                const int j = w & 0xfff, jp = ((w >> 12) & 0xfff) - 2;
-                const bool is_child = valid && (w & (1 << 24)) && jp == r;      // j is a kept child of r
-                const bool is_self = valid && j == r;
-                const bool is_par = valid && rchild && j == rp;
-                const bool e = (is_child && (w & (1 << 25))) || is_self || (is_par && rrev);      // adj[r,j] != 0
-                const bool eT = (is_child && (w & (1 << 26))) || is_self || (is_par && rfwd);     // adj[j,r] != 0
-                const unsigned long long m = __ballot(e), mT = __ballot(eT);
-                if (e) {
-                    const int pos = n_e + __popcll(m & lt);
-                    col_idx[o + pos] = j;
-                    if (label) label[o + pos] = is_self ? SELF_LOOP_ID : (is_child ? lab[j] : labr);
-                    if (pos < 7) hd[1 + pos] = j;
-                }
-                if (eT) {
-                    const int pos = n_eT + __popcll(mT & lt);
-                    if (colT_idx) colT_idx[oT + pos] = j;
-                    if (hdT && pos < 7) hdT[1 + pos] = j;
-                }
-                n_e += __popcll(m);
-                n_eT += __popcll(mT);
-            }
-            if (lane < 8) {                                           // count, and zeros in the unused slots
-                if (lane == 0) hd[0] = n_e; else if (lane > n_e) hd[lane] = 0;
-                if (hdT) { if (lane == 0) hdT[0] = n_eT; else if (lane > n_eT) hdT[lane] = 0; }
-            }
-#ifdef GCNPT_STAMPS
-            if (qq < 12) GCNPT_STAMP(stamps, 9 + qq / 4);            // diagnostic: wave 0's rows 0, 4, 8 of the chunk
-#endif
+            emit_row_scan(b, T, cap, lab, einfo, n_edge_rows, lane, __builtin_amdgcn_readlane(rw, qq), __builtin_amdgcn_readlane(rlab, qq),
+                          __builtin_amdgcn_readlane(rdeg, qq), __builtin_amdgcn_readlane(rdegT, qq), col_idx, label, colT_idx, ell, ellT);
         }
     }
     GCNPT_STAMP(stamps, 7);
@@ -368,29 +492,31 @@ __global__ __launch_bounds__(PRUNE_THREADS) void prune_to_csr_kernel(
     int B, int T, int prune_k, int cap, int32_t* __restrict__ row_ptr, int32_t* __restrict__ col_idx,
     int32_t* __restrict__ label, int32_t* __restrict__ rowT_ptr, int32_t* __restrict__ colT_idx,
     int32_t* __restrict__ ell, int32_t* __restrict__ ellT, uint8_t* __restrict__ pool_mask,
-    int32_t* __restrict__ status, unsigned long long* stamps, const PackParams pk, int pk_dtype) {
-    extern __shared__ int smem[];  // carved in prune_sentence()
+    int32_t* __restrict__ status, unsigned long long* stamps, const PackParams pk, int pk_dtype, int staged) {
+    extern __shared__ int smem[];  // carved in prune_sentence() (+ the entry lists of emit_rows when staged)
     __shared__ int s_err;
     if ((int)blockIdx.x >= B) {    // side job of gcnpt_prune_to_csr_pack: the launch leaves most CUs idle, these workgroups pack the weights
         pack_side_job(pk, pk_dtype, B);
         return;
     }
 
-    __shared__ int s_status, s_nrows;
+    __shared__ int s_status, s_nrows, s_red[4];
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) { s_err = 0; s_status = 0; s_nrows = 0; }
+    if (threadIdx.x == 0) { s_err = 0; s_status = 0; s_nrows = 0; s_red[0] = s_red[1] = s_red[2] = 0; s_red[3] = 0x7fffffff; }
     GCNPT_STAMP_REAL(stamps);
     GCNPT_STAMP(stamps, 0);
     __shared__ int s_maxlen;
     if (threadIdx.x == 0) s_maxlen = 0;
     __syncthreads();
-    if (wave == 0) prune_sentence(head, subj_pos, obj_pos, deprel, pad_mask, len_in, b, B, T, prune_k, cap, smem, &s_err, &s_status,
-                                  &s_nrows, row_ptr, rowT_ptr, ell, ellT, pool_mask, status, stamps);
-    else if (b == 0 && (long long)B * T <= PRUNE_SCAN_MAX) {
-        // status[B] = longest sentence of the batch (gcn.py:97): the idle waves of workgroup 0 count every sentence's non-pad
-        // slots while wave 0 prunes, so the launch needs neither a memset of that word nor one atomic per sentence
+    const bool allw = T > PRUNE_WAVE0_T;
+    // status[B] = longest sentence of the batch (gcn.py:97): waves of workgroup 0 that have no token to prune count every sentence's
+    // non-pad slots while the others prune (wave 0 alone, or the waves holding the T tokens), so the launch needs neither a memset
+    // of that word nor one atomic per sentence.  (Big batches, or sentences that occupy every wave: atomicMax, see prune_impl.)
+    const int first_idle = allw ? (T + WAVE - 1) / WAVE : 1;
+    if (b == 0 && (long long)B * T <= PRUNE_SCAN_MAX && first_idle < PRUNE_THREADS / WAVE && wave >= first_idle) {
+        const int n_idle = PRUNE_THREADS / WAVE - first_idle;
         int m = 0;
-        for (int sidx = wave - 1; sidx < B; sidx += PRUNE_THREADS / WAVE - 1) {
+        for (int sidx = wave - first_idle; sidx < B; sidx += n_idle) {
             int n;
             if (pad_mask) {
                 n = 0;
@@ -405,9 +531,13 @@ __global__ __launch_bounds__(PRUNE_THREADS) void prune_to_csr_kernel(
         }
         if (lane == 0) atomicMax(&s_maxlen, m);
     }
+    if (allw) prune_sentence<true>(head, subj_pos, obj_pos, deprel, pad_mask, len_in, b, B, T, prune_k, cap, smem, &s_err, &s_status,
+                                   &s_nrows, s_red, row_ptr, rowT_ptr, ell, ellT, pool_mask, status, stamps);
+    else if (wave == 0) prune_sentence<false>(head, subj_pos, obj_pos, deprel, pad_mask, len_in, b, B, T, prune_k, cap, smem, &s_err, &s_status,
+                                              &s_nrows, s_red, row_ptr, rowT_ptr, ell, ellT, pool_mask, status, stamps);
     __syncthreads();
-    if (b == 0 && threadIdx.x == 0 && (long long)B * T <= PRUNE_SCAN_MAX) status[B] = s_maxlen;
-    emit_rows(b, T, cap, smem, s_status, s_nrows, lane, wave, col_idx, label, colT_idx, ell, ellT, stamps);
+    if (b == 0 && threadIdx.x == 0 && (long long)B * T <= PRUNE_SCAN_MAX && first_idle < PRUNE_THREADS / WAVE) status[B] = s_maxlen;
+    emit_rows(b, T, cap, smem, s_status, s_nrows, lane, wave, staged != 0, col_idx, label, colT_idx, ell, ellT, stamps);
 }
 
 // ---- dense float adjacency -> CSR of (adj != 0) and of its transpose (gcn.py:260-262) -----------------
@@ -675,15 +805,21 @@ static int prune_impl(void* stream, const int64_t* head, const int64_t* subj_pos
         return fail(GCNPT_E_PRUNE_NEGATIVE, "prune_k=%d: the reference fork only works with prune_k >= 0 "
                     "(model/tree.py:194 reads Tree.head, which the unpruned branch never sets)", prune_k);
     if ((long long)B * cap > 0x7fffffffLL) return fail(GCNPT_E_UNSUPPORTED, "prune_to_csr: B*cap overflows int32");
-    const size_t lds = sizeof(int) * ((size_t)7 * T + 4);
+    // 7 words per token for the pruning phases; + 7 more for the staged row emission (3T forward + 3T transposed entries, T for the
+    // long-row list) when that still fits LDS (T <= ~2800)
+    const size_t lds_base = sizeof(int) * ((size_t)7 * T + 4), lds_staged = sizeof(int) * ((size_t)14 * T + 4);
+    const int staged = lds_staged <= 160 * 1024 - 256 ? 1 : 0;
+    const size_t lds = staged ? lds_staged : lds_base;
     if (T > PRUNE_MAX_T) return fail(GCNPT_E_UNSUPPORTED, "prune_to_csr: T=%d exceeds the %d tokens a sentence may have", T, PRUNE_MAX_T);
     hipStream_t s = (hipStream_t)stream;
     // sentences beyond ~2300 tokens need more than the default 64 KB of LDS (7 words per token); minus the kernel's few static words
     if (lds > 64 * 1024) GCNPT_LDS_ATTR_ONCE(prune_to_csr_kernel, 160 * 1024 - 256);
-    if ((long long)B * T > PRUNE_SCAN_MAX) GCNPT_HIP_CHECK(hipMemsetAsync(status + B, 0, sizeof(int32_t), s));   // big batches: atomicMax per sentence
+    // big batches, and sentences that occupy every wave of their workgroup: atomicMax per sentence (see the kernel)
+    if ((long long)B * T > PRUNE_SCAN_MAX || (T > PRUNE_WAVE0_T && T + WAVE > PRUNE_THREADS))
+        GCNPT_HIP_CHECK(hipMemsetAsync(status + B, 0, sizeof(int32_t), s));
     hipLaunchKernelGGL(prune_to_csr_kernel, dim3(B + pack_blocks), dim3(PRUNE_THREADS), lds, s, head, subj_pos, obj_pos, deprel,
                        pad_mask, len, B, T, prune_k, cap, row_ptr, col_idx, label, rowT_ptr, colT_idx, ell, ellT, pool_mask, status,
-                       static_cast<unsigned long long*>(g_debug_stamps), pk, pk_dtype);
+                       static_cast<unsigned long long*>(g_debug_stamps), pk, pk_dtype, staged);
     GCNPT_HIP_CHECK(hipGetLastError());
     return GCNPT_OK;
 }

@@ -61,6 +61,18 @@ def main():
     for _ in range(5):
         stack.step_native()
     torch.cuda.synchronize()
+    # the tree build (slots: 0 entry, 1 parse staged, 2 entity chains, 3 LCA, 4 distances, 5 degrees + scans, 6 row info, 8 -> 7 rows emitted)
+    for _ in range(3):
+        stack.prune()
+    torch.cuda.synchronize()
+    buf.zero_()
+    L.gcnpt_debug_set_stamps(buf.data_ptr())
+    stack.prune()
+    torch.cuda.synchronize()
+    L.gcnpt_debug_set_stamps(None)
+    report("prune", buf.cpu().numpy().reshape(-1, 16).astype(np.int64))
+    if os.environ.get("GCNPT_STAMPS_PRUNE_ONLY"):
+        return
     for k in range(2, len(names) + 1):              # (the pack kernel has no stamps)
         L.gcnpt_debug_set_stamps(None)
         for _ in range(3):

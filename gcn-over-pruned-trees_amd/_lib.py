@@ -54,16 +54,16 @@ SIGNATURES = {
     "gcnpt_gather_trees": (_i, [_p] * 11 + [_i, _i, _i, _p, _i, _i, _i] + [_p] * 9),
     "gcnpt_gather_trees_pack": (_i, [_p] * 11 + [_i, _i, _i, _p, _i, _i, _i] + [_p] * 9 + [_i, _p, _p, _p, _i, _p, _p]),
     "gcnpt_compact_trees": (_i, [_p] * 10 + [_i] * 5 + [_p] * 11),
-    "gcnpt_bilinear_packed_bytes": (_sz, [_i, _i, _i]),
-    "gcnpt_bilinear_supported": (_i, [_i, _i, _i]),
-    "gcnpt_bilinear_planes": (_i, [_i, _i, _i, _i]),
-    "gcnpt_bilinear_pack": (_i, [_p, _p, _i, _i, _i, _p, _i]),
-    "gcnpt_rows_image_bytes": (_sz, [_i, _i]),
-    "gcnpt_rows_pack": (_i, [_p, _p, _i, _i, _p]),
-    "gcnpt_bilinear_bwd_w": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
-    "gcnpt_bilinear_de_planes": (_i, [_i, _i, _i, _i]),
-    "gcnpt_bilinear_bwd_e": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
-    "gcnpt_bilinear_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "gcnpt_bilinear_packed_bytes": (_sz, [_i, _i, _i, _i]),
+    "gcnpt_bilinear_supported": (_i, [_i, _i, _i, _i]),
+    "gcnpt_bilinear_planes": (_i, [_i, _i, _i, _i, _i]),
+    "gcnpt_bilinear_pack": (_i, [_p, _p, _i, _i, _i, _p, _i, _i]),
+    "gcnpt_rows_image_bytes": (_sz, [_i, _i, _i]),
+    "gcnpt_rows_pack": (_i, [_p, _p, _i, _i, _p, _i]),
+    "gcnpt_bilinear_bwd_w": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _i]),
+    "gcnpt_bilinear_de_planes": (_i, [_i, _i, _i, _i, _i]),
+    "gcnpt_bilinear_bwd_e": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _i]),
+    "gcnpt_bilinear_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _i]),
 }
 
 

@@ -366,26 +366,359 @@ __global__ __launch_bounds__(BL_THREADS, 1) void bilinear_dw_kernel(const Biline
     }
 }
 
+
+// ===========================================================================================================================
+// The same traversal in EXACT fp32 (v_mfma_f32_16x16x4_f32): the module's default precision (opt['gcn_dtype'] = 'fp32'), the mode the
+// reference-recorded gradient goldens are checked in.  Reference model/gcn.py:400-415 (+ 417-434 through the caller).
+// fp32 MFMA runs at 1/16 of the bf16 rate (32 cycles per 16x16x4 MFMA), so these kernels are MFMA-bound by a wide margin and need none
+// of the bf16 kernel's machinery: a relation's weight fragments are prefetched through registers one relation ahead into a two-stage
+// LDS buffer (a relation's MFMAs take ~10 k cycles per wave), the token fragments stay in registers.
+// Fragment = 16 bytes per lane = 4 floats X[k = 16 kstep + 4 (lane >> 4) + s][n = 16 tile + (lane & 15)], s = 0..3 (the layer kernels'
+// fp32 image order, include/gcnpt.h); MFMA s of a k-step multiplies the s-th values.
+// ===========================================================================================================================
+constexpr int BF_MT = 2, BF_NT = 3;          // token tiles per wave, output tiles per workgroup (one workgroup per CU: ~250 registers)
+constexpr int BF_TSMAX = 16;                 // 16-wide k-steps per relation the registers are sized for: Tin <= 256
+constexpr int BF_ROWS = 16 * BF_MT * BL_WAVES;       // 128 token rows per workgroup
+
+__global__ void bilinear_pack_f32_kernel(const float* __restrict__ W, int D, int Tin, int H, int TS, long long n_frag_lanes,
+                                         uint4* __restrict__ img, int transposed) {
+    for (long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x; gid < n_frag_lanes; gid += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(gid & 63);
+        const long long f = gid >> 6;
+        const int ks = (int)(f % ((long long)D * TS)), tl = (int)(f / ((long long)D * TS));
+        const int d = ks / TS, ts = ks - d * TS;
+        const int n = tl * 16 + (lane & 15), k0 = ts * 16 + 4 * (lane >> 4);
+        const int Kd = transposed ? H : Tin, Nd = transposed ? Tin : H;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                       // unconditional clamped loads, dropped with a select
+            const int kc = min(k0 + j, Kd - 1), nc = min(n, Nd - 1);
+            const float x = transposed ? W[((size_t)d * Tin + nc) * H + kc] : W[((size_t)d * Tin + kc) * H + nc];
+            v[j] = (k0 + j < Kd && n < Nd) ? x : 0.0f;
+        }
+        img[gid] = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+    }
+}
+
+struct BilinearF32Params {
+    const float* x;         // [M, TS*16] fp32, zero padded
+    const float* e;         // [M, D]
+    const uint4* img;       // packed W3 (fp32 fragments)
+    float* y;               // MODE 0: [slices][M, H]; MODE 1: [nb][M, D]
+    const float* gy;        // MODE 1: [M, H]
+    int M, D, H, TS, n_tiles, mb, nb, slices, d_per_slice;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(BL_THREADS, 1) void bilinear_f32_kernel(const BilinearF32Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char bf_smem[];              // [2][BF_NT * BF_TSMAX][64] uint4 | e tile
+    const int TS = p.TS, Tpad = TS * 16;
+    const int n_frag = BF_NT * TS;
+    constexpr int STAGE = BF_NT * BF_TSMAX * 64;                                         // uint4 per stage (all slots: the stores are unconditional)
+    uint4* wl = reinterpret_cast<uint4*>(bf_smem);
+    float* es = reinterpret_cast<float*>(wl + (size_t)2 * STAGE);                        // [d_per_slice][BF_ROWS + 1]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int id = blockIdx.x;
+    const int slice = id % p.slices, rest = id / p.slices;
+    const int bm = rest % p.mb, bn = rest / p.mb;
+    const int m0 = bm * BF_ROWS + wave * 16 * BF_MT, nt0 = bn * BF_NT;
+    const int d_lo = slice * p.d_per_slice, d_hi = min(p.D, d_lo + p.d_per_slice);
+    const int nd = d_hi - d_lo;
+    const size_t d_stride = (size_t)p.D * TS;
+
+    // this wave's x fragments: lane (l & 15) = token row, 4 consecutive k per lane -- registers for the whole kernel
+    uint4 xf[BF_MT][BF_TSMAX];
+#pragma unroll
+    for (int mt = 0; mt < BF_MT; ++mt) {
+        const size_t row = (size_t)min(m0 + 16 * mt + (lane & 15), p.M - 1);
+#pragma unroll
+        for (int ts = 0; ts < BF_TSMAX; ++ts)
+            xf[mt][ts] = *reinterpret_cast<const uint4*>(p.x + row * Tpad + min(ts, TS - 1) * 16 + 4 * (lane >> 4));
+    }
+    // a relation's fragments: thread t fetches fragment-lanes t, t + 256, ... (<= BF_NT * BF_TSMAX * 64 / 256 = 12 per thread)
+    constexpr int WPT = BF_NT * BF_TSMAX * 64 / BL_THREADS;
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));      // a first-class vector: hipcc kept an array of uint4 STRUCTS in scratch memory
+    u32x4_t wr[WPT];
+    auto fetch_w = [&](int dd) {
+        const int d = d_lo + min(dd, nd - 1);
+#pragma unroll
+        for (int u = 0; u < WPT; ++u) {
+            const int q = min(tid + u * BL_THREADS, n_frag * 64 - 1);
+            const int f = q >> 6, l = q & 63;
+            const int j = f / TS, ts = f - j * TS;
+            wr[u] = *reinterpret_cast<const u32x4_t*>(p.img + ((size_t)min(nt0 + j, p.n_tiles - 1) * d_stride + (size_t)d * TS + ts) * 64 + l);
+        }
+    };
+    // (unconditional stores into a stage sized for BF_TSMAX k-steps: a prefetched register whose only use is a CONDITIONAL store gets
+    // parked in scratch memory by hipcc right behind its load, i.e. the prefetch becomes a blocking load -- seen in the ISA)
+    auto store_w = [&](int dd) {
+        uint4* dst = wl + (size_t)(dd & 1) * STAGE;
+#pragma unroll
+        for (int u = 0; u < WPT; ++u) *reinterpret_cast<u32x4_t*>(dst + tid + u * BL_THREADS) = wr[u];
+    };
+    fetch_w(0);
+    // e of the workgroup's rows -> LDS, relation-major
+    const int rows0 = bm * BF_ROWS;
+    constexpr int EU = 8;
+    for (int q0 = tid; MODE == 0 && q0 < nd * BF_ROWS; q0 += BL_THREADS * EU) {
+        float v[EU];
+#pragma unroll
+        for (int u = 0; u < EU; ++u) {
+            const int q = min(q0 + u * BL_THREADS, nd * BF_ROWS - 1);
+            const int row = q / nd, dl = q - row * nd;
+            v[u] = p.e[(size_t)min(rows0 + row, p.M - 1) * p.D + d_lo + dl];
+        }
+#pragma unroll
+        for (int u = 0; u < EU; ++u) {
+            const int q = q0 + u * BL_THREADS;
+            const int row = q / nd, dl = q - row * nd;
+            if (q < nd * BF_ROWS) es[dl * (BF_ROWS + 1) + row] = v[u];
+        }
+    }
+    store_w(0);
+    __syncthreads();
+
+    f32x4_t acc[BF_MT][BF_NT];             // MODE 0: the result tile; MODE 1: the upstream gradient's values at the tile's positions
+#pragma unroll
+    for (int mt = 0; mt < BF_MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < BF_NT; ++j) {
+            acc[mt][j] = (f32x4_t){0, 0, 0, 0};
+            if constexpr (MODE == 1) {
+                const size_t row = (size_t)min(m0 + 16 * mt + (lane & 15), p.M - 1);
+                const int n = (nt0 + j) * 16 + 4 * (lane >> 4);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float v = p.gy[row * p.H + min(n + g, p.H - 1)];
+                    acc[mt][j][g] = (n + g < p.H && nt0 + j < p.n_tiles) ? v : 0.0f;
+                }
+            }
+        }
+
+    for (int dd = 0; dd < nd; ++dd) {
+        fetch_w(dd + 1);                                     // the next relation's fragments, in flight during this one's MFMAs
+        const uint4* ring = wl + (size_t)(dd & 1) * STAGE;
+        float ev[BF_MT];
+#pragma unroll
+        for (int mt = 0; mt < BF_MT; ++mt) ev[mt] = MODE == 0 ? es[dd * (BF_ROWS + 1) + wave * 16 * BF_MT + 16 * mt + (lane & 15)] : 0.0f;
+        f32x4_t P[BF_MT][BF_NT];
+#pragma unroll
+        for (int mt = 0; mt < BF_MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < BF_NT; ++j) P[mt][j] = (f32x4_t){0, 0, 0, 0};
+#pragma unroll
+        for (int ts = 0; ts < BF_TSMAX; ++ts) {
+            if (ts < TS) {                                   // workgroup-uniform, no global load inside
+                // the 4 MFMAs of a k-step that share an accumulator are kept BF_NT * BF_MT instructions apart (a dependent MFMA right
+                // behind its producer waits for the 8 passes to drain)
+                f32x4_t wq[BF_NT];
+#pragma unroll
+                for (int j = 0; j < BF_NT; ++j) wq[j] = __builtin_bit_cast(f32x4_t, ring[(size_t)(j * TS + ts) * 64 + lane]);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                    for (int j = 0; j < BF_NT; ++j)
+#pragma unroll
+                        for (int mt = 0; mt < BF_MT; ++mt) {
+                            const f32x4_t xq = __builtin_bit_cast(f32x4_t, xf[mt][ts]);
+                            P[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[j][s4], xq[s4], P[mt][j], 0, 0, 0);
+                        }
+            }
+        }
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int mt = 0; mt < BF_MT; ++mt)
+#pragma unroll
+                for (int j = 0; j < BF_NT; ++j) acc[mt][j] += ev[mt] * P[mt][j];
+        } else {
+            float* plane = p.y + (size_t)bn * p.M * p.D;
+#pragma unroll
+            for (int mt = 0; mt < BF_MT; ++mt) {
+                float sdot = 0.0f;
+#pragma unroll
+                for (int j = 0; j < BF_NT; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) sdot += P[mt][j][g] * acc[mt][j][g];
+                sdot += __shfl_xor(sdot, 16);
+                sdot += __shfl_xor(sdot, 32);
+                const int m = m0 + 16 * mt + (lane & 15);
+                if (lane < 16 && m < p.M) plane[(size_t)m * p.D + d_lo + dd] = sdot;
+            }
+        }
+        store_w(dd + 1);                                     // into the stage relation dd-1 left (everybody passed the barrier since)
+        __syncthreads();
+    }
+
+    if constexpr (MODE == 1) return;
+    float* plane = p.y + (size_t)slice * p.M * p.H;
+    const bool vec = (p.H & 3) == 0;
+#pragma unroll
+    for (int mt = 0; mt < BF_MT; ++mt) {
+        const int m = m0 + 16 * mt + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < BF_NT; ++j) {
+            const int n = (nt0 + j) * 16 + 4 * (lane >> 4);
+            if (m < p.M && nt0 + j < p.n_tiles) {
+                float* dst = plane + (size_t)m * p.H + n;
+                if (vec && n + 4 <= p.H) {
+                    *reinterpret_cast<float4*>(dst) = make_float4(acc[mt][j][0], acc[mt][j][1], acc[mt][j][2], acc[mt][j][3]);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        if (n + g < p.H) dst[g] = acc[mt][j][g];
+                }
+            }
+        }
+    }
+}
+
+// rows -> fp32 row-contraction fragment image: img[w_tile][m16 step][lane] = 4 floats src[16 ms + 4 (lane >> 4) + s][16 wt + (lane & 15)]
+__global__ void rows_pack_f32_kernel(const float* __restrict__ src, int M, int W, int m_steps, long long n_lanes, uint4* __restrict__ img) {
+    for (long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x; gid < n_lanes; gid += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(gid & 63);
+        const long long f = gid >> 6;
+        const int ms = (int)(f % m_steps), wt = (int)(f / m_steps);
+        const int c = wt * 16 + (lane & 15), m0 = ms * 16 + 4 * (lane >> 4);
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x = src[(size_t)min(m0 + j, M - 1) * W + min(c, W - 1)];
+            v[j] = (m0 + j < M && c < W) ? x : 0.0f;
+        }
+        img[gid] = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+    }
+}
+
+// dW3[d][t][h] = sum_m e[m,d] x[m,t] gy[m,h] in exact fp32: (4 x 3)-tile blocks x 2 relations per workgroup; per 16-token step the gy
+// fragments are scaled by e[., d] (one fp32 multiply per value) and meet the x fragments on the matrix cores; the 4 waves take every
+// 4th step and meet in LDS; every element of dW3 is written once (no atomics).
+constexpr int BWF_MT = 4, BWF_NT = 3, BWF_ND = 2;
+
+__global__ __launch_bounds__(BL_THREADS, 1) void bilinear_dw_f32_kernel(const BilinearDwParams p) {
+    __shared__ f32x4_t red[BL_WAVES][BWF_MT * BWF_NT][WAVE];                // 48 KiB: one relation's tiles at a time
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int id = blockIdx.x;
+    const int bt = id % p.tb, rest = id / p.tb;
+    const int bh = rest % p.hb, dg = rest / p.hb;
+    const int t0 = bt * BWF_MT, h0 = bh * BWF_NT, d0 = dg * BWF_ND;
+    f32x4_t acc[BWF_ND][BWF_MT][BWF_NT];
+#pragma unroll
+    for (int q = 0; q < BWF_ND; ++q)
+#pragma unroll
+        for (int i = 0; i < BWF_MT; ++i)
+#pragma unroll
+            for (int j = 0; j < BWF_NT; ++j) acc[q][i][j] = (f32x4_t){0, 0, 0, 0};
+    const size_t Mpad = (size_t)p.m_steps * 16;
+    struct Operands { uint4 xa[BWF_MT], gb[BWF_NT]; float4 ea[BWF_ND]; };
+    auto fetch = [&](int ms_raw, Operands& o) {              // clamped: the step past the end re-reads the last one and is not used
+        const int ms = min(ms_raw, p.m_steps - 1);
+#pragma unroll
+        for (int i = 0; i < BWF_MT; ++i) o.xa[i] = p.xI[((size_t)min(t0 + i, p.t_tiles - 1) * p.m_steps + ms) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < BWF_NT; ++j) o.gb[j] = p.gI[((size_t)min(h0 + j, p.h_tiles - 1) * p.m_steps + ms) * 64 + lane];
+#pragma unroll
+        for (int q = 0; q < BWF_ND; ++q)
+            o.ea[q] = *reinterpret_cast<const float4*>(p.eT + (size_t)min(d0 + q, p.D - 1) * Mpad + (size_t)ms * 16 + 4 * (lane >> 4));
+    };
+    auto consume = [&](const Operands& o) {
+#pragma unroll
+        for (int q = 0; q < BWF_ND; ++q) {
+            const float ev[4] = {o.ea[q].x, o.ea[q].y, o.ea[q].z, o.ea[q].w};
+            // swapped operands: rows = h (scaled gy), columns = t (x): a lane ends with 4 consecutive h of one t.  MFMAs that share an
+            // accumulator are 12 instructions apart
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int j = 0; j < BWF_NT; ++j) {
+                    const float sg = __builtin_bit_cast(f32x4_t, o.gb[j])[s4] * ev[s4];
+#pragma unroll
+                    for (int i = 0; i < BWF_MT; ++i)
+                        acc[q][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(sg, __builtin_bit_cast(f32x4_t, o.xa[i])[s4], acc[q][i][j], 0, 0, 0);
+                }
+        }
+    };
+    Operands oa, ob;
+    fetch(wave, oa);
+    for (int ms = wave; ms < p.m_steps; ms += 2 * BL_WAVES) {
+        fetch(ms + BL_WAVES, ob);
+        consume(oa);
+        fetch(ms + 2 * BL_WAVES, oa);
+        if (ms + BL_WAVES < p.m_steps) consume(ob);          // wave-uniform, no load inside
+    }
+    for (int q = 0; q < BWF_ND; ++q) {
+        __syncthreads();
+#pragma unroll
+        for (int q2 = 0; q2 < BWF_ND; ++q2)
+#pragma unroll
+            for (int i = 0; i < BWF_MT; ++i)
+#pragma unroll
+                for (int j = 0; j < BWF_NT; ++j)
+                    if (q2 == q) red[wave][i * BWF_NT + j][lane] = acc[q2][i][j];      // static register indices
+        __syncthreads();
+        const int d = d0 + q;
+        for (int tt = wave; tt < BWF_MT * BWF_NT; tt += BL_WAVES) {
+            const int i = tt / BWF_NT, j = tt % BWF_NT;
+            f32x4_t v = red[0][tt][lane];
+#pragma unroll
+            for (int w = 1; w < BL_WAVES; ++w) v += red[w][tt][lane];
+            const int t = (t0 + i) * 16 + (lane & 15);
+            const int h = (h0 + j) * 16 + 4 * (lane >> 4);
+            if (d < p.D && t < p.Tin && t0 + i < p.t_tiles && h0 + j < p.h_tiles) {
+                float* dst = p.dW + ((size_t)d * p.Tin + t) * p.H + h;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (h + g < p.H) dst[g] = v[g];
+            }
+        }
+    }
+}
+
 }  // namespace gcnpt
 
 using namespace gcnpt;
 
-extern "C" size_t gcnpt_bilinear_packed_bytes(int D, int Tin, int H) {
-    if (D <= 0 || Tin <= 0 || H <= 0) return 0;
-    return (size_t)ceil_div(H, 16) * D * ceil_div(Tin, 32) * 64 * 16;
+// k-step width of the traversal's fragments: 32 values per lane group of bf16, 16 of fp32
+static int bl_kstep(int dtype) { return dtype == GCNPT_BF16 ? 32 : 16; }
+
+extern "C" size_t gcnpt_bilinear_packed_bytes(int D, int Tin, int H, int dtype) {
+    if (D <= 0 || Tin <= 0 || H <= 0 || !dtype_ok(dtype)) return 0;
+    return (size_t)ceil_div(H, 16) * D * ceil_div(Tin, bl_kstep(dtype)) * 64 * 16;
 }
 
-extern "C" int gcnpt_bilinear_supported(int D, int Tin, int H) {
-    return D > 0 && H > 0 && Tin > 0 && ceil_div(Tin, 32) <= BL_TSMAX;
+extern "C" int gcnpt_bilinear_supported(int D, int Tin, int H, int dtype) {
+    if (!dtype_ok(dtype)) return 0;
+    return D > 0 && H > 0 && Tin > 0 && ceil_div(Tin, bl_kstep(dtype)) <= (dtype == GCNPT_BF16 ? BL_TSMAX : BF_TSMAX);
 }
 
-extern "C" int gcnpt_bilinear_pack(void* stream, const float* W, int D, int Tin, int H, void* w_img, int transposed) {
+extern "C" int gcnpt_bilinear_pack(void* stream, const float* W, int D, int Tin, int H, void* w_img, int transposed, int dtype) {
     GCNPT_REQUIRE(W && w_img, "bilinear_pack: null pointer");
-    GCNPT_REQUIRE(D > 0 && Tin > 0 && H > 0, "bilinear_pack: sizes must be positive");
-    const int TS = ceil_div(transposed ? H : Tin, 32);
+    GCNPT_REQUIRE(D > 0 && Tin > 0 && H > 0 && dtype_ok(dtype), "bilinear_pack: sizes must be positive, dtype f32 or bf16");
+    const int TS = ceil_div(transposed ? H : Tin, bl_kstep(dtype));
     const long long n = (long long)ceil_div(transposed ? Tin : H, 16) * D * TS * 64;
     const int grid = (int)std::min<long long>((n + 255) / 256, 1 << 16);
-    hipLaunchKernelGGL(bilinear_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, D, Tin, H, TS, n, static_cast<uint4*>(w_img), transposed);
+    if (dtype == GCNPT_BF16)
+        hipLaunchKernelGGL(bilinear_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, D, Tin, H, TS, n, static_cast<uint4*>(w_img), transposed);
+    else
+        hipLaunchKernelGGL(bilinear_pack_f32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, D, Tin, H, TS, n, static_cast<uint4*>(w_img), transposed);
+    GCNPT_HIP_CHECK(hipGetLastError());
+    return GCNPT_OK;
+}
+
+static void bilinear_f32_plan(BilinearF32Params& p, int M, int D, int Tin, int H) {
+    p.M = M; p.D = D; p.H = H; p.TS = ceil_div(Tin, 16); p.n_tiles = ceil_div(H, 16);
+    p.mb = ceil_div(M, BF_ROWS); p.nb = ceil_div(p.n_tiles, BF_NT);
+    int slices = std::max(1, std::min(256 / std::max(1, p.mb * p.nb), D / 4));       // one workgroup per CU, one round
+    slices = std::max(slices, ceil_div(D, 64));                 // the e tile of a slice must fit LDS beside the two weight stages
+    p.d_per_slice = ceil_div(D, slices);
+    p.slices = ceil_div(D, p.d_per_slice);
+}
+
+template <int MODE>
+static int bilinear_f32_launch(hipStream_t s, BilinearF32Params& p) {
+    const size_t lds = (size_t)2 * BF_NT * BF_TSMAX * 64 * sizeof(uint4) + sizeof(float) * (BF_ROWS + 1) * (size_t)p.d_per_slice;
+    if (lds > 160 * 1024) return fail(GCNPT_E_UNSUPPORTED, "bilinear (fp32): %zu B of LDS", lds);
+    GCNPT_LDS_ATTR_ONCE(bilinear_f32_kernel<MODE>, 160 * 1024);
+    hipLaunchKernelGGL(bilinear_f32_kernel<MODE>, dim3(p.mb * p.nb * p.slices), dim3(BL_THREADS), lds, s, p);
     GCNPT_HIP_CHECK(hipGetLastError());
     return GCNPT_OK;
 }
@@ -395,12 +728,18 @@ static void bilinear_plan(BilinearParams& p, int M, int D, int Tin, int H) {
     p.mb = ceil_div(M, BL_ROWS); p.nb = ceil_div(p.n_tiles, BL_NT);
     // relation slices: about one workgroup per CU (each holds ~120 KB of LDS and all registers), at least 4 relations each
     int slices = std::max(1, std::min(256 / std::max(1, p.mb * p.nb), D / 4));
+    slices = std::max(slices, ceil_div(D, 48));                 // the e tile of a slice must fit LDS beside the ring (48 x 257 words)
     p.d_per_slice = ceil_div(D, slices);
     p.slices = ceil_div(D, p.d_per_slice);
 }
 
-extern "C" int gcnpt_bilinear_planes(int M, int D, int Tin, int H) {
-    if (M <= 0 || !gcnpt_bilinear_supported(D, Tin, H)) return 0;
+extern "C" int gcnpt_bilinear_planes(int M, int D, int Tin, int H, int dtype) {
+    if (M <= 0 || !gcnpt_bilinear_supported(D, Tin, H, dtype)) return 0;
+    if (dtype == GCNPT_F32) {
+        BilinearF32Params q{};
+        bilinear_f32_plan(q, M, D, Tin, H);
+        return q.slices;
+    }
     BilinearParams p{};
     bilinear_plan(p, M, D, Tin, H);
     return p.slices;
@@ -417,30 +756,42 @@ static int bilinear_launch(hipStream_t s, BilinearParams& p) {
 }
 
 extern "C" int gcnpt_bilinear_fwd(void* stream, const void* x, const float* e, const void* w_img, int M, int D, int Tin, int H,
-                                  float* y_planes) {
+                                  float* y_planes, int dtype) {
     GCNPT_REQUIRE(x && e && w_img && y_planes, "bilinear_fwd: null pointer");
     GCNPT_REQUIRE(M > 0 && D > 0 && Tin > 0 && H > 0, "bilinear_fwd: sizes must be positive");
     GCNPT_REQUIRE(aligned16(x) && aligned16(w_img) && aligned16(y_planes), "bilinear_fwd: x, w_img and y_planes must be 16-byte aligned");
-    if (!gcnpt_bilinear_supported(D, Tin, H))
-        return fail(GCNPT_E_UNSUPPORTED, "bilinear_fwd: Tin=%d needs more than %d k-steps per relation", Tin, BL_TSMAX);
+    if (!gcnpt_bilinear_supported(D, Tin, H, dtype))
+        return fail(GCNPT_E_UNSUPPORTED, "bilinear_fwd: Tin=%d needs more k-steps per relation than the kernel keeps in registers (Tin <= 256)", Tin);
+    if (dtype == GCNPT_F32) {
+        BilinearF32Params q{};
+        q.x = static_cast<const float*>(x); q.e = e; q.img = static_cast<const uint4*>(w_img); q.y = y_planes;
+        bilinear_f32_plan(q, M, D, Tin, H);
+        return bilinear_f32_launch<0>((hipStream_t)stream, q);
+    }
     BilinearParams p{};
     p.x = static_cast<const bf16_t*>(x); p.e = e; p.img = static_cast<const uint4*>(w_img); p.y = y_planes;
     bilinear_plan(p, M, D, Tin, H);
     return bilinear_launch<0>((hipStream_t)stream, p);
 }
 
-extern "C" int gcnpt_bilinear_de_planes(int M, int D, int Tin, int H) {
-    if (M <= 0 || !gcnpt_bilinear_supported(D, Tin, H)) return 0;
-    return ceil_div(ceil_div(H, 16), BL_NT);
+extern "C" int gcnpt_bilinear_de_planes(int M, int D, int Tin, int H, int dtype) {
+    if (M <= 0 || !gcnpt_bilinear_supported(D, Tin, H, dtype)) return 0;
+    return ceil_div(ceil_div(H, 16), dtype == GCNPT_BF16 ? BL_NT : BF_NT);
 }
 
 extern "C" int gcnpt_bilinear_bwd_e(void* stream, const void* x, const float* gy, const void* w_img, int M, int D, int Tin, int H,
-                                    float* de_planes) {
+                                    float* de_planes, int dtype) {
     GCNPT_REQUIRE(x && gy && w_img && de_planes, "bilinear_bwd_e: null pointer");
     GCNPT_REQUIRE(M > 0 && D > 0 && Tin > 0 && H > 0, "bilinear_bwd_e: sizes must be positive");
     GCNPT_REQUIRE(aligned16(x) && aligned16(w_img), "bilinear_bwd_e: x and w_img must be 16-byte aligned");
-    if (!gcnpt_bilinear_supported(D, Tin, H))
-        return fail(GCNPT_E_UNSUPPORTED, "bilinear_bwd_e: Tin=%d needs more than %d k-steps per relation", Tin, BL_TSMAX);
+    if (!gcnpt_bilinear_supported(D, Tin, H, dtype))
+        return fail(GCNPT_E_UNSUPPORTED, "bilinear_bwd_e: Tin=%d needs more k-steps per relation than the kernel keeps in registers (Tin <= 256)", Tin);
+    if (dtype == GCNPT_F32) {
+        BilinearF32Params q{};
+        q.x = static_cast<const float*>(x); q.e = nullptr; q.gy = gy; q.img = static_cast<const uint4*>(w_img); q.y = de_planes;
+        bilinear_f32_plan(q, M, D, Tin, H);
+        return bilinear_f32_launch<1>((hipStream_t)stream, q);
+    }
     BilinearParams p{};
     p.x = static_cast<const bf16_t*>(x); p.e = nullptr; p.gy = gy;
     p.img = static_cast<const uint4*>(w_img); p.y = de_planes;
@@ -448,34 +799,37 @@ extern "C" int gcnpt_bilinear_bwd_e(void* stream, const void* x, const float* gy
     return bilinear_launch<1>((hipStream_t)stream, p);
 }
 
-extern "C" size_t gcnpt_rows_image_bytes(int M, int W) {
-    if (M <= 0 || W <= 0) return 0;
-    return (size_t)ceil_div(W, 16) * ceil_div(M, 32) * 64 * 16;
+extern "C" size_t gcnpt_rows_image_bytes(int M, int W, int dtype) {
+    if (M <= 0 || W <= 0 || !dtype_ok(dtype)) return 0;
+    return (size_t)ceil_div(W, 16) * ceil_div(M, bl_kstep(dtype)) * 64 * 16;
 }
 
-extern "C" int gcnpt_rows_pack(void* stream, const float* src, int M, int W, void* img) {
+extern "C" int gcnpt_rows_pack(void* stream, const float* src, int M, int W, void* img, int dtype) {
     GCNPT_REQUIRE(src && img, "rows_pack: null pointer");
-    GCNPT_REQUIRE(M > 0 && W > 0, "rows_pack: sizes must be positive");
-    const int m_steps = ceil_div(M, 32);
+    GCNPT_REQUIRE(M > 0 && W > 0 && dtype_ok(dtype), "rows_pack: sizes must be positive, dtype f32 or bf16");
+    const int m_steps = ceil_div(M, bl_kstep(dtype));
     const long long n = (long long)ceil_div(W, 16) * m_steps * 64;
     const int grid = (int)std::min<long long>((n + 255) / 256, 1 << 16);
-    hipLaunchKernelGGL(rows_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, M, W, m_steps, n, static_cast<uint4*>(img));
+    if (dtype == GCNPT_BF16) hipLaunchKernelGGL(rows_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, M, W, m_steps, n, static_cast<uint4*>(img));
+    else hipLaunchKernelGGL(rows_pack_f32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, M, W, m_steps, n, static_cast<uint4*>(img));
     GCNPT_HIP_CHECK(hipGetLastError());
     return GCNPT_OK;
 }
 
 extern "C" int gcnpt_bilinear_bwd_w(void* stream, const void* x_img, const void* gy_img, const float* eT, int M, int D, int Tin, int H,
-                                    float* dW) {
+                                    float* dW, int dtype) {
     GCNPT_REQUIRE(x_img && gy_img && eT && dW, "bilinear_bwd_w: null pointer");
-    GCNPT_REQUIRE(M > 0 && D > 0 && Tin > 0 && H > 0, "bilinear_bwd_w: sizes must be positive");
+    GCNPT_REQUIRE(M > 0 && D > 0 && Tin > 0 && H > 0 && dtype_ok(dtype), "bilinear_bwd_w: sizes must be positive, dtype f32 or bf16");
     GCNPT_REQUIRE(aligned16(x_img) && aligned16(gy_img) && aligned16(eT), "bilinear_bwd_w: images and eT must be 16-byte aligned");
     BilinearDwParams p{};
     p.xI = static_cast<const uint4*>(x_img); p.gI = static_cast<const uint4*>(gy_img); p.eT = eT; p.dW = dW;
-    p.D = D; p.Tin = Tin; p.H = H; p.t_tiles = ceil_div(Tin, 16); p.h_tiles = ceil_div(H, 16); p.m_steps = ceil_div(M, 32);
-    p.tb = ceil_div(p.t_tiles, BW_MT); p.hb = ceil_div(p.h_tiles, BW_NT); p.dgroups = ceil_div(D, BW_ND);
+    p.D = D; p.Tin = Tin; p.H = H; p.t_tiles = ceil_div(Tin, 16); p.h_tiles = ceil_div(H, 16); p.m_steps = ceil_div(M, bl_kstep(dtype));
+    const bool bf = dtype == GCNPT_BF16;
+    p.tb = ceil_div(p.t_tiles, bf ? BW_MT : BWF_MT); p.hb = ceil_div(p.h_tiles, bf ? BW_NT : BWF_NT); p.dgroups = ceil_div(D, bf ? BW_ND : BWF_ND);
     const long long blocks = (long long)p.tb * p.hb * p.dgroups;
     if (blocks > 0x7fffffffLL) return fail(GCNPT_E_UNSUPPORTED, "bilinear_bwd_w: too many blocks");
-    hipLaunchKernelGGL(bilinear_dw_kernel, dim3((unsigned)blocks), dim3(BL_THREADS), 0, (hipStream_t)stream, p);
+    if (bf) hipLaunchKernelGGL(bilinear_dw_kernel, dim3((unsigned)blocks), dim3(BL_THREADS), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(bilinear_dw_f32_kernel, dim3((unsigned)blocks), dim3(BL_THREADS), 0, (hipStream_t)stream, p);
     GCNPT_HIP_CHECK(hipGetLastError());
     return GCNPT_OK;
 }

@@ -611,13 +611,12 @@ class GCN(nn.Module):
         return x.float(), trees.pool_mask
 
     def _forward_full(self, adj, gcn_inputs, deprel, all_tokens=False):
-        """adj_type='full_deprel', gcn.py:296-388 + traverse_deprel / traverse_self_loop 400-434; fp32, or with
-        opt['gcn_dtype']='bf16' the traversal's contraction on csrc/bilinear_kernels.hip (bf16 MFMA operands, fp32 accumulate).
+        """adj_type='full_deprel', gcn.py:296-388 + traverse_deprel / traverse_self_loop 400-434; the traversal's contraction runs on
+        csrc/bilinear_kernels.hip in the module's precision: exact fp32 MFMA (default) or, with opt['gcn_dtype']='bf16', bf16 operands.
         trav(x, e)[n] = sum_d e[n,d] (x[n] W3[d] + b3[d]) is only needed for tokens that sit in a pruned tree, so those are
         compacted (their number is read back together with the tree check's status word; with opt['gcn_check_trees']=False or
-        CompactTrees, whose rows are those tokens already, every row is traversed and there is no host sync at all).  In bf16 mode the
-        contraction runs on the hand-written kernels; in fp32 mode the outer products e (x) x meet W3 as [D*Tin, H] in ONE plain
-        library GEMM per direction.  Everything around it -- aggregation of the traversed rows over the forward / reverse entries of the
+        CompactTrees, whose rows are those tokens already, every row is traversed and there is no host sync at all).  The
+        contraction runs on the hand-written kernels in both precisions (a library GEMM only when Tin > 256).  Everything around it -- aggregation of the traversed rows over the forward / reverse entries of the
         device pruner's CSR (picked by label range), edge dropout, the self-loop term, /(deg+1), ReLU, dropout -- is ONE kernel
         (csrc/full_kernels.hip, gcnpt_full_agg_fwd / _bwd).  The reference materialises [B,T,D,Tin] for all tokens and multiplies
         dense [B,T,T] matrices instead."""
@@ -663,9 +662,10 @@ class GCN(nn.Module):
                     e = torch.where(kept, e, torch.ones_like(e))
                 if plain:
                     e = torch.ones_like(e)
-                if self.compute_dtype == torch.bfloat16 and bilinear_supported(D, Tin, H):
-                    ys[k] = bilinear_traverse(xt, e, self.W.weight, self.W.bias)                  # hand-written MFMA contraction
-                else:                                                                             # one plain library GEMM, gcn.py:408-414
+                if bilinear_supported(D, Tin, H, self.compute_dtype):
+                    # hand-written MFMA contraction in the module's precision (exact fp32 MFMA by default): e (x) x never exists
+                    ys[k] = bilinear_traverse(xt, e, self.W.weight, self.W.bias, self.compute_dtype)
+                else:                                                                             # Tin > 256: one library GEMM, gcn.py:408-414
                     ys[k] = torch.mm((e.unsqueeze(2) * xt.unsqueeze(1)).reshape(-1, D * Tin), Wk) + torch.mm(e, b3)
                 edge_keep = opt.get('edge_keep_prob', 1.0)
                 if self.training and edge_keep < 1.0:                                             # maybe_drop_edges, gcn.py:436-449
@@ -779,86 +779,93 @@ class _FullAggFn(torch.autograd.Function):
 
 
 class _BilinearFn(torch.autograd.Function):
-    """y = sum_d e[:,d] * (x @ W3[d]) + e @ b3 (reference traverse_deprel, model/gcn.py:400-415) with the forward contraction on
-    csrc/bilinear_kernels.hip (bf16 MFMA operands, fp32 accumulate).  The op is linear in each argument: dx is the same kernel on
+    """y = sum_d e[:,d] * (x @ W3[d]) + e @ b3 (reference traverse_deprel, model/gcn.py:400-415) with the contraction on
+    csrc/bilinear_kernels.hip in either precision: exact fp32 MFMA (the module's default) or bf16 operands with fp32 accumulation.
+    The outer product e (x) x the reference materialises never exists.  The op is linear in each argument: dx is the same kernel on
     the transposed weight image, de the same per-relation products dotted with the upstream gradient, dW the token contraction
     of row-contraction fragment images with the gy fragments scaled by e in registers (gcnpt_bilinear_bwd_w)."""
 
     @staticmethod
-    def forward(ctx, xt, e, weight, bias):
+    def forward(ctx, xt, e, weight, bias, compute):
         M, Tin = xt.shape
         D = e.shape[1]
         H = weight.shape[0] // D
         lib, st, dev = _lib.lib(), _lib.stream(), xt.device
+        k = 32 if compute == _lib.BF16 else 16
+        op_dtype = torch.bfloat16 if compute == _lib.BF16 else torch.float32
         w32 = weight.detach().to(torch.float32).contiguous()
-        img = torch.empty((lib.gcnpt_bilinear_packed_bytes(D, Tin, H),), dtype=torch.uint8, device=dev)
-        _lib.check(lib.gcnpt_bilinear_pack(st, _lib.ptr(w32), D, Tin, H, _lib.ptr(img), 0))
-        Tpad = (Tin + 31) // 32 * 32
-        xb = torch.zeros((M, Tpad), dtype=torch.bfloat16, device=dev)
+        img = torch.empty((lib.gcnpt_bilinear_packed_bytes(D, Tin, H, compute),), dtype=torch.uint8, device=dev)
+        _lib.check(lib.gcnpt_bilinear_pack(st, _lib.ptr(w32), D, Tin, H, _lib.ptr(img), 0, compute))
+        xb = torch.zeros((M, (Tin + k - 1) // k * k), dtype=op_dtype, device=dev)
         xb[:, :Tin] = xt.detach()
         e32 = e.detach().to(torch.float32).contiguous()
-        planes = torch.empty((lib.gcnpt_bilinear_planes(M, D, Tin, H), M, H), dtype=torch.float32, device=dev)
-        _lib.check(lib.gcnpt_bilinear_fwd(st, _lib.ptr(xb), _lib.ptr(e32), _lib.ptr(img), M, D, Tin, H, _lib.ptr(planes)))
+        planes = torch.empty((lib.gcnpt_bilinear_planes(M, D, Tin, H, compute), M, H), dtype=torch.float32, device=dev)
+        _lib.check(lib.gcnpt_bilinear_fwd(st, _lib.ptr(xb), _lib.ptr(e32), _lib.ptr(img), M, D, Tin, H, _lib.ptr(planes), compute))
         y = torch.addmm(planes.sum(0), e32, bias.detach().to(torch.float32).reshape(D, H))      # + e @ b3, gcn.py:413
         ctx.save_for_backward(xt, e, weight, bias, xb, img)
+        ctx.compute = compute
         return y
 
     @staticmethod
     def backward(ctx, gy):
         xt, e, weight, bias, xb, img = ctx.saved_tensors
+        compute = ctx.compute
         M, Tin = xt.shape
         D = e.shape[1]
         H = weight.shape[0] // D
         lib, st, dev = _lib.lib(), _lib.stream(), xt.device
+        k = 32 if compute == _lib.BF16 else 16
+        op_dtype = torch.bfloat16 if compute == _lib.BF16 else torch.float32
         gy = gy.to(torch.float32).contiguous()
         x32, e32 = xt.to(torch.float32), e.to(torch.float32).contiguous()
         w32 = weight.detach().to(torch.float32).contiguous()
         b3 = bias.to(torch.float32).reshape(D, H)
         dx = de = dW = db = None
-        on_kernel = bool(lib.gcnpt_bilinear_supported(D, H, Tin))         # the transposed problem contracts over H
+        on_kernel = bool(lib.gcnpt_bilinear_supported(D, H, Tin, compute))         # the transposed problem contracts over H
         if ctx.needs_input_grad[0]:
             if on_kernel:       # dx = sum_d e_d (gy @ W3[d]^T): the forward kernel on the transposed weight image
-                imgT = torch.empty((lib.gcnpt_bilinear_packed_bytes(D, H, Tin),), dtype=torch.uint8, device=dev)
-                _lib.check(lib.gcnpt_bilinear_pack(st, _lib.ptr(w32), D, Tin, H, _lib.ptr(imgT), 1))
-                gyb = torch.zeros((M, (H + 31) // 32 * 32), dtype=torch.bfloat16, device=dev)
+                imgT = torch.empty((lib.gcnpt_bilinear_packed_bytes(D, H, Tin, compute),), dtype=torch.uint8, device=dev)
+                _lib.check(lib.gcnpt_bilinear_pack(st, _lib.ptr(w32), D, Tin, H, _lib.ptr(imgT), 1, compute))
+                gyb = torch.zeros((M, (H + k - 1) // k * k), dtype=op_dtype, device=dev)
                 gyb[:, :H] = gy
-                planes = torch.empty((lib.gcnpt_bilinear_planes(M, D, H, Tin), M, Tin), dtype=torch.float32, device=dev)
-                _lib.check(lib.gcnpt_bilinear_fwd(st, _lib.ptr(gyb), _lib.ptr(e32), _lib.ptr(imgT), M, D, H, Tin, _lib.ptr(planes)))
+                planes = torch.empty((lib.gcnpt_bilinear_planes(M, D, H, Tin, compute), M, Tin), dtype=torch.float32, device=dev)
+                _lib.check(lib.gcnpt_bilinear_fwd(st, _lib.ptr(gyb), _lib.ptr(e32), _lib.ptr(imgT), M, D, H, Tin, _lib.ptr(planes), compute))
                 dx = planes.sum(0)
             else:
                 dx = (torch.mm(gy, w32.reshape(D * Tin, H).t()).view(M, D, Tin) * e32.unsqueeze(2)).sum(1)
         if ctx.needs_input_grad[1]:
             # de[m,d] = (x[m] @ W3[d]) . gy[m] + gy[m] . b3[d]: the forward's per-relation products, dotted instead of summed
-            planes = torch.empty((lib.gcnpt_bilinear_de_planes(M, D, Tin, H), M, D), dtype=torch.float32, device=dev)
-            _lib.check(lib.gcnpt_bilinear_bwd_e(st, _lib.ptr(xb), _lib.ptr(gy), _lib.ptr(img), M, D, Tin, H, _lib.ptr(planes)))
+            planes = torch.empty((lib.gcnpt_bilinear_de_planes(M, D, Tin, H, compute), M, D), dtype=torch.float32, device=dev)
+            _lib.check(lib.gcnpt_bilinear_bwd_e(st, _lib.ptr(xb), _lib.ptr(gy), _lib.ptr(img), M, D, Tin, H, _lib.ptr(planes), compute))
             de = torch.addmm(planes.sum(0), gy, b3.t())
         if ctx.needs_input_grad[2]:                                       # dW3[d] = (e_d * x)^T gy without the [M, D*Tin] outer product
             u8 = dict(dtype=torch.uint8, device=dev)
-            xI = torch.empty((lib.gcnpt_rows_image_bytes(M, Tin),), **u8)
-            gI = torch.empty((lib.gcnpt_rows_image_bytes(M, H),), **u8)
+            xI = torch.empty((lib.gcnpt_rows_image_bytes(M, Tin, compute),), **u8)
+            gI = torch.empty((lib.gcnpt_rows_image_bytes(M, H, compute),), **u8)
             x32c = x32.contiguous()
-            _lib.check(lib.gcnpt_rows_pack(st, _lib.ptr(x32c), M, Tin, _lib.ptr(xI)))
-            _lib.check(lib.gcnpt_rows_pack(st, _lib.ptr(gy), M, H, _lib.ptr(gI)))
-            eT = torch.zeros((D, (M + 31) // 32 * 32), dtype=torch.float32, device=dev)
+            _lib.check(lib.gcnpt_rows_pack(st, _lib.ptr(x32c), M, Tin, _lib.ptr(xI), compute))
+            _lib.check(lib.gcnpt_rows_pack(st, _lib.ptr(gy), M, H, _lib.ptr(gI), compute))
+            eT = torch.zeros((D, (M + k - 1) // k * k), dtype=torch.float32, device=dev)
             eT[:, :M] = e32.t()
             dW32 = torch.empty(weight.shape, dtype=torch.float32, device=dev)
-            _lib.check(lib.gcnpt_bilinear_bwd_w(st, _lib.ptr(xI), _lib.ptr(gI), _lib.ptr(eT), M, D, Tin, H, _lib.ptr(dW32)))
+            _lib.check(lib.gcnpt_bilinear_bwd_w(st, _lib.ptr(xI), _lib.ptr(gI), _lib.ptr(eT), M, D, Tin, H, _lib.ptr(dW32), compute))
             dW = dW32.to(weight.dtype)
         if ctx.needs_input_grad[3]:
             db = torch.mm(e32.t(), gy).reshape(-1).to(bias.dtype)
-        return dx, de, dW, db
+        return dx, de, dW, db, None
 
 
-def bilinear_traverse(xt, e, weight, bias):
+def bilinear_traverse(xt, e, weight, bias, compute_dtype=torch.bfloat16):
     """traverse_deprel of the reference for M compacted token rows: xt [M,Tin], e [M,D] relation vectors, weight [D*H,Tin] and
-    bias [D*H] of the shared nn.Linear (read as W3 [D,Tin,H] / b3 [D,H], gcn.py:301-303).  float32 [M,H]."""
+    bias [D*H] of the shared nn.Linear (read as W3 [D,Tin,H] / b3 [D,H], gcn.py:301-303).  float32 [M,H].  compute_dtype: float32 =
+    exact fp32 MFMA, bfloat16 = bf16 operands with fp32 accumulation."""
     for t in (xt, e, weight, bias):
         _lib.require_gpu(t)
-    return _BilinearFn.apply(xt, e, weight, bias)
+    return _BilinearFn.apply(xt, e, weight, bias, _lib.dtype_code(compute_dtype))
 
 
-def bilinear_supported(D, Tin, H):
-    return bool(_lib.lib().gcnpt_bilinear_supported(int(D), int(Tin), int(H)))
+def bilinear_supported(D, Tin, H, compute_dtype=torch.bfloat16):
+    return bool(_lib.lib().gcnpt_bilinear_supported(int(D), int(Tin), int(H), _lib.dtype_code(compute_dtype)))
 
 
 def _zero_pad_row(grad):

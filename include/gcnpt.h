@@ -354,37 +354,40 @@ int gcnpt_compact_trees(void* stream, const int32_t* src_row_ptr, const int32_t*
 /* ---- N3: the relation-conditioned traversal of adj_type == 'full_deprel', model/gcn.py:400-415 (traverse_deprel) ------------
  *   y[m,:] = sum_d e[m,d] * (x[m,:] @ W3[d]),   W3 = Linear.weight.reshape(D, Tin, H) (gcn.py:301: a reinterpretation of the
  *   [D*H, Tin] weight's memory, no transpose), for M token rows (the caller compacts the tokens that sit in a pruned tree).
- * bf16 MFMA operands, fp32 accumulation.  gcnpt_bilinear_pack: W [dev] float32, the Linear weight as it lies in memory ->
- * w_img, gcnpt_bilinear_packed_bytes(D, Tin, H) bytes of MFMA fragment order (once per optimizer step).
- * gcnpt_bilinear_fwd: x [dev] bf16 [M, 32*ceil(Tin/32)] zero padded, 16-byte aligned; e [dev] float32 [M, D] (relation vectors:
- * embeddings, or ones past deprel_max_depth); y_planes [dev] float32 [gcnpt_bilinear_planes(M,D,Tin,H)][M, H], written
+ * Every entry point takes the MFMA operand type `dtype`: GCNPT_BF16 (bf16 operands, fp32 accumulation) or GCNPT_F32 (exact fp32 MFMA,
+ * v_mfma_f32_16x16x4_f32: the module's default precision, the mode the reference-recorded goldens are checked in).  k = 32 (bf16) or
+ * 16 (f32) below is the fragments' k-step.
+ * gcnpt_bilinear_pack: W [dev] float32, the Linear weight as it lies in memory -> w_img, gcnpt_bilinear_packed_bytes(D, Tin, H, dtype)
+ * bytes of MFMA fragment order (once per optimizer step).
+ * gcnpt_bilinear_fwd: x [dev] [M, k*ceil(Tin/k)] of dtype, zero padded, 16-byte aligned; e [dev] float32 [M, D] (relation vectors:
+ * embeddings, or ones past deprel_max_depth); y_planes [dev] float32 [gcnpt_bilinear_planes(M,D,Tin,H,dtype)][M, H], written
  * completely: the relations are split into that many slices (so that ~256 workgroups exist) and each slice leaves its partial
  * sums in its own plane -- the result is the sum of the planes (plus the bias term e @ b3, gcn.py:413).  No float atomics.
  * gcnpt_bilinear_supported: 0 when Tin needs more k-steps than the kernel keeps in registers (Tin > 256). */
-size_t gcnpt_bilinear_packed_bytes(int D, int Tin, int H);
-int gcnpt_bilinear_supported(int D, int Tin, int H);
-int gcnpt_bilinear_pack(void* stream, const float* W, int D, int Tin, int H, void* w_img, int transposed);
-int gcnpt_bilinear_planes(int M, int D, int Tin, int H);
+size_t gcnpt_bilinear_packed_bytes(int D, int Tin, int H, int dtype);
+int gcnpt_bilinear_supported(int D, int Tin, int H, int dtype);
+int gcnpt_bilinear_pack(void* stream, const float* W, int D, int Tin, int H, void* w_img, int transposed, int dtype);
+int gcnpt_bilinear_planes(int M, int D, int Tin, int H, int dtype);
 int gcnpt_bilinear_fwd(void* stream, const void* x, const float* e, const void* w_img, int M, int D, int Tin, int H,
-                       float* y_planes);
+                       float* y_planes, int dtype);
 /* Gradients of the traversal that reuse the same kernel (the op is linear in each argument):
  *   dx = sum_d e_d * (gy @ W3[d]^T)        -> gcnpt_bilinear_fwd on (gy as x, the image packed with transposed = 1, widths swapped:
- *                                             gcnpt_bilinear_pack(.., transposed=1) fills gcnpt_bilinear_packed_bytes(D, H, Tin) bytes;
- *                                             gcnpt_bilinear_fwd(stream, gy_bf16 [M, 32*ceil(H/32)], e, imgT, M, D, H, Tin, dx_planes))
+ *                                             gcnpt_bilinear_pack(.., transposed=1, dtype) fills gcnpt_bilinear_packed_bytes(D, H, Tin, dtype) bytes;
+ *                                             gcnpt_bilinear_fwd(stream, gy [M, k*ceil(H/k)] of dtype, e, imgT, M, D, H, Tin, dx_planes, dtype))
  *   de[m,d] = (x[m] @ W3[d]) . gy[m]       -> gcnpt_bilinear_bwd_e: gy [dev] float32 [M,H]; de_planes [dev] float32
- *                                             [gcnpt_bilinear_de_planes(M,D,Tin,H)][M, D] written completely, summed by the caller. */
+ *                                             [gcnpt_bilinear_de_planes(M,D,Tin,H,dtype)][M, D] written completely, summed by the caller. */
 /*   dW3[d][t][h] = sum_m e[m,d] x[m,t] gy[m,h] -> gcnpt_bilinear_bwd_w: x_img / gy_img = gcnpt_rows_pack of x [M,Tin] / gy [M,H]
- *                                             (float32 in, bf16 fragment images out, gcnpt_rows_image_bytes(M, width) bytes: lane =
- *                                             column, 8 consecutive rows per lane); eT [dev] float32 [D, 32*ceil(M/32)] = e
+ *                                             (float32 in, fragment images of dtype out, gcnpt_rows_image_bytes(M, width, dtype) bytes:
+ *                                             lane = column, k/4 consecutive rows per lane); eT [dev] float32 [D, k*ceil(M/k)] = e
  *                                             transposed, zero padded; dW [dev] float32 in the Linear weight's own layout
  *                                             ([D*H, Tin] memory read as [D,Tin,H]), written completely, no atomics. */
-size_t gcnpt_rows_image_bytes(int M, int W);
-int gcnpt_rows_pack(void* stream, const float* src, int M, int W, void* img);
+size_t gcnpt_rows_image_bytes(int M, int W, int dtype);
+int gcnpt_rows_pack(void* stream, const float* src, int M, int W, void* img, int dtype);
 int gcnpt_bilinear_bwd_w(void* stream, const void* x_img, const void* gy_img, const float* eT, int M, int D, int Tin, int H,
-                         float* dW);
-int gcnpt_bilinear_de_planes(int M, int D, int Tin, int H);
+                         float* dW, int dtype);
+int gcnpt_bilinear_de_planes(int M, int D, int Tin, int H, int dtype);
 int gcnpt_bilinear_bwd_e(void* stream, const void* x, const float* gy, const void* w_img, int M, int D, int Tin, int H,
-                         float* de_planes);
+                         float* de_planes, int dtype);
 
 /* ---- N3, the layer AROUND the traversal: model/gcn.py:308-311 + 331, 340-344 + 362 (aggregation of the traversed encodings over the
  * forward / reverse edges, picked by value ranges of the labelled adjacency), 366-385 (self loop), 390-393 (normalise, ReLU, dropout) ----

@@ -973,7 +973,7 @@ def test_diag_deprel_classifier_end_to_end_golden(api, dev):
 
 
 # ---------------------------------------------------------------------------------------------------
-# N3: adj_type == 'full_deprel' (library GEMMs for the bilinear contraction, the device pruner's CSR for the edges)
+# N3: adj_type == 'full_deprel' (hand-written MFMA contraction in both precisions, the device pruner's CSR for the edges)
 # ---------------------------------------------------------------------------------------------------
 def _full_gcn(api, dev, D, hidden, layers, **kw):
     gcn, _ = api
@@ -1026,7 +1026,7 @@ def test_bilinear_traverse_kernel(api, dev, M, D, Tin, H):
     grads = [t.grad.clone() for t in (x, e, W, b)]
     for t in (x, e, W, b):
         t.grad = None
-    got = gcn.bilinear_traverse(x, e, W, b)
+    got = gcn.bilinear_traverse(x, e, W, b, torch.bfloat16)
     got.backward(gy)
     assert max_rel(got.detach().cpu().numpy(), want.detach().cpu().numpy()) <= 1e-2          # bf16 operands
     # the same against the fp32 einsum of bf16-rounded operands: only the accumulation order is left
@@ -1048,8 +1048,74 @@ def test_bilinear_traverse_kernel(api, dev, M, D, Tin, H):
     assert max_rel(e.grad.cpu().numpy(), er.grad.cpu().numpy()) <= 2e-5
 
 
+@pytest.mark.parametrize("M,D,Tin,H", [(1000, 50, 200, 200), (37, 6, 24, 24), (130, 16, 64, 72), (65, 9, 250, 40), (300, 200, 96, 200)])
+def test_bilinear_traverse_kernel_fp32(api, dev, M, D, Tin, H):
+    """the traversal contraction (gcn.py:400-415) in EXACT fp32 MFMA (v_mfma_f32_16x16x4_f32), forward and the three
+    gradients on the kernels, against the fp32 einsum of the reference's traverse_deprel and its autograd: 1e-5 forward, 1e-4 gradients
+    (the stated fp32 tolerances) -- nothing rounded to bf16 anywhere, no [M, D*Tin] outer product materialised."""
+    gcn, _ = api
+    rng = np.random.RandomState(M + D + 1)
+    mk = lambda *shape: torch.from_numpy(rng.uniform(-1, 1, size=shape).astype(np.float32)).to(dev).requires_grad_()  # noqa: E731
+    x, e, W, b = mk(M, Tin), mk(M, D), mk(D * H, Tin), mk(D * H)
+    gy = torch.from_numpy(rng.standard_normal((M, H)).astype(np.float32)).to(dev)
+
+    def ref(x, e, W, b):
+        W3, b3 = W.double().reshape(D, Tin, H), b.double().reshape(D, H)
+        return torch.einsum("md,mt,dth->mh", e.double(), x.double(), W3) + e.double() @ b3
+    want = ref(x, e, W, b)                                      # float64: the yardstick for both fp32 evaluations
+    want.backward(gy.double())
+    grads = [t.grad.clone() for t in (x, e, W, b)]
+    for t in (x, e, W, b):
+        t.grad = None
+    assert gcn.bilinear_supported(D, Tin, H, torch.float32)
+    got = gcn.bilinear_traverse(x, e, W, b, torch.float32)
+    got.backward(gy)
+    assert max_rel(got.detach().cpu().numpy(), want.detach().cpu().numpy()) <= FWD_RTOL
+    for t, gref, name in zip((x, e, W, b), grads, ("dx", "de", "dW", "db")):
+        assert max_rel(t.grad.cpu().numpy(), gref.cpu().numpy()) <= GRAD_RTOL, name
+
+
+def test_full_deprel_bf16_backward_vs_oracle(api, dev):
+    """The bf16 traversal kernels inside the whole full_deprel layer stack against oracle/gcn_ref.py::full_backward (fp32 NumPy
+    restatement of gcn.py:296-388, 400-434 and its autograd): normwise 1e-1 like every bf16-vs-fp32-reference gradient check, forward 3e-2."""
+    from gcn_over_pruned_trees_amd.utils import synthetic
+    from oracle import gcn_ref, prune_ref
+    gcn, tree = api
+    B, T, hidden, D, K, L = 12, 70, 64, 16, 1, 2
+    tb = synthetic.random_tree_batch(93, B, T, "tacred")
+    adj = prune_ref.batch_adj(tb["head"], tb["subj_pos"], tb["obj_pos"], tb["deprel"], tb["lens"], K)["adj"]
+    rng = np.random.RandomState(7)
+    g = dict(tb, B=B, T=T, hidden=hidden, D=D, prune_k=K, x=synthetic.normal(8, (B, T, hidden)), gy=synthetic.normal(9, (B, T, hidden)),
+             E=rng.uniform(-1, 1, size=(85, D)).astype(np.float32),
+             W=(rng.uniform(-1, 1, size=(D * hidden, hidden)) / np.sqrt(hidden * D)).astype(np.float32),
+             b=(rng.uniform(-1, 1, size=(D * hidden,)) / np.sqrt(hidden)).astype(np.float32))
+    kw = dict(max_depth=2, directed=False, self_loop=True)
+    net, demb = _full_gcn(api, dev, D, hidden, L, deprel_max_depth=2, deprel_directed=False, deprel_self_loop=True, gcn_dtype="bf16")
+    with torch.no_grad():
+        demb.weight.copy_(torch.from_numpy(g["E"]))
+        net.W.weight.copy_(torch.from_numpy(g["W"]))
+        net.W.bias.copy_(torch.from_numpy(g["b"]))
+    net.to(dev).eval()
+    demb.to(dev)
+    x = _t(g["x"], dev).requires_grad_()
+    masks = np.arange(T)[None, :] >= tb["lens"][:, None]
+    inputs = (x, _t(masks, dev), None, None, _t(tb["deprel"], dev), _t(tb["head"], dev), _t(tb["subj_pos"], dev), _t(tb["obj_pos"], dev))
+    trees = tree.prune_to_csr(inputs[5], inputs[6], inputs[7], inputs[4], K, masks=inputs[1], want_label=True)
+    h, _ = net(trees, inputs)
+    h.backward(_t(g["gy"], dev))
+    href, _ = gcn_ref.full_forward(adj, g["x"], g["deprel"], g["W"], g["b"], g["E"], L, **kw)
+    dx, dW, db, dE = gcn_ref.full_backward(adj, g["x"], g["deprel"], g["W"], g["b"], g["E"], L, g["gy"], **kw)
+    f = lambda t: t.detach().float().cpu().numpy()  # noqa: E731
+    assert max_rel(f(h), href) <= 3e-2
+    dEg = f(demb.weight.grad).copy()
+    dEg[0] = 0
+    for got, want, key in ((f(x.grad), dx, "dx"), (f(net.W.weight.grad), dW, "dW"), (f(net.W.bias.grad), db, "db"), (dEg, dE, "dE")):
+        assert fro_rel(got, want) <= BF16_FRO, key
+
+
 def test_full_deprel_golden(api, dev):
-    """fp32 against outputs and gradients recorded from the reference's GCN(adj_type='full_deprel'), four option sets."""
+    """fp32 (the traversal on the exact-fp32 MFMA kernels: no library GEMM on the path) against outputs and gradients recorded from the
+    reference's GCN(adj_type='full_deprel'), four option sets."""
     import json
     g = dict(load_golden("layers_full_deprel.npz"))
     g["adj"] = dense_from_coo(g["coo"], int(g["B"]), int(g["T"]))

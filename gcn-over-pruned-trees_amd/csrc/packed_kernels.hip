@@ -113,7 +113,8 @@ __global__ __launch_bounds__(PK_THREADS) void move_rows_kernel(const unsigned ch
     const int b = blockIdx.y, i0 = blockIdx.x * 8;
     const int base = cu[b], len = cu[b + 1] - base;
     const size_t pieces = row_bytes / VB;
-    typedef typename std::conditional<VB == 16, uint4, typename std::conditional<VB == 4, unsigned, unsigned short>::type>::type V;
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));  // (first-class vector: a select between uint4 structs went through scratch memory)
+    typedef typename std::conditional<VB == 16, u32x4_t, typename std::conditional<VB == 4, unsigned, unsigned short>::type>::type V;
     for (int i = i0; i < min(i0 + 8, T); ++i) {
         const size_t padded = ((size_t)b * T + i) * row_bytes, packed = ((size_t)base + i) * row_bytes;
         if (UNPACK) {

@@ -53,9 +53,14 @@ static int vec_bytes(int width, size_t es, const void* a, const void* b) {
 }
 
 
+namespace gcnpt { int rowgemm_try(hipStream_t s, const RowTileParams& p, int mode, int in_dtype, int out_dtype, int compute_dtype); }
+
 template <bool BWD, bool DZIN = false>
 static int dispatch_rowtile(hipStream_t s, const RowTileParams& p, int in_dtype, int out_dtype, int compute) {
     const int mode = BWD ? (DZIN ? 2 : 1) : 0;
+    // big batches in bf16: the k-step-pipelined 128-row form (rowgemm_kernels.hip), same bits
+    const int rg = rowgemm_try(s, p, mode, in_dtype, out_dtype, compute);
+    if (rg != 0) return rg < 0 ? rg : GCNPT_OK;
     if (compute == GCNPT_F32) {
         if (in_dtype != GCNPT_F32 || out_dtype != GCNPT_F32)
             return fail(GCNPT_E_UNSUPPORTED, "compute_dtype f32 needs f32 activations");
@@ -159,11 +164,12 @@ static int launch_wgrads(void* stream, const WgradReq* req, int n, int B, int T,
     return n ? gcnpt_layer_bwd_weight_multi(stream, n, zf, sf, B, T, Din, H, dW, db, compute_dtype) : GCNPT_OK;
 }
 
-// backward-data of one layer; the weight gradient `ride` (of the layer above) rides in the launch when it can, else follows it
+// backward-data of one layer; the weight gradient `ride` (of the layer above) rides in the launch when it can (*carried says whether it
+// did); launch_behind: a gradient that could not ride is launched right after, else it is left to the caller
 static int bwd_data_with_rider(void* stream, const void* dY, const void* Y, int g_dtype, const void* w_bwd, const int32_t* ell,
                                const int32_t* rowT_ptr, const int32_t* colT_idx, const int32_t* ellT, int B, int T, int Din, int H, void* dh,
                                int dh_dtype, int compute_dtype, float scale, void* z_frag, float* zero_dW, float* zero_db, const void* relu_src,
-                               float next_scale, int src_is_dz, const WgradReq* ride) {
+                               float next_scale, int src_is_dz, const WgradReq* ride, bool launch_behind, bool* carried_out) {
     SideWgrads sw;
     t_side = SideWgrad{};
     if (ride && plan_side_wgrad(sw, *ride, B, T, compute_dtype)) t_side.sw = &sw;
@@ -171,8 +177,9 @@ static int bwd_data_with_rider(void* stream, const void* dY, const void* Y, int 
                                        z_frag, zero_dW, zero_db, relu_src, next_scale, src_is_dz);
     const bool carried = t_side.carried;
     t_side = SideWgrad{};
+    if (carried_out) *carried_out = carried;
     if (rc != GCNPT_OK) return rc;
-    return (carried || !ride) ? GCNPT_OK : launch_wgrads(stream, ride, 1, B, T, compute_dtype);
+    return (carried || !ride || !launch_behind) ? GCNPT_OK : launch_wgrads(stream, ride, 1, B, T, compute_dtype);
 }
 
 extern "C" int gcnpt_layer_bwd_data_wgrad(void* stream, const void* dY, const void* Y, int g_dtype, const void* w_bwd,
@@ -185,7 +192,7 @@ extern "C" int gcnpt_layer_bwd_data_wgrad(void* stream, const void* dY, const vo
                   "its two fragment images, dW and db");
     const WgradReq ride{up_z_frag, up_s_frag, up_Din, up_H, up_dW, up_db};
     return bwd_data_with_rider(stream, dY, Y, g_dtype, w_bwd, ell, rowT_ptr, colT_idx, ellT, B, T, Din, H, dh, dh_dtype, compute_dtype, scale, z_frag,
-                               zero_dW, zero_db, relu_src, next_scale, src_is_dz, &ride);
+                               zero_dW, zero_db, relu_src, next_scale, src_is_dz, &ride, true, nullptr);
 }
 
 // ---- the whole layer loop / its autograd in one host call: the launches above, back to back (no kernel of their own) ----
@@ -239,14 +246,19 @@ static int layers_bwd_impl(void* stream, int n_layers, const void* gy, const voi
             WgradReq ride{};
             const bool offer = z_frag && l + 1 < n_layers;           // carry layer l+1's gradient?
             if (offer) ride = WgradReq{z_frag[l + 1], s_frag[l + 1], Din[l + 1], H[l + 1], dW[l + 1], db[l + 1]};
+            bool carried = false;
             if (wanted()) {
                 const int rc = bwd_data_with_rider(stream, g, Y[l], y_dtype[l], w_bwd[l], ell, rowT_ptr, colT_idx, ellT, B, T, Din[l], H[l], dh[l],
                                                    dh_dtype[l], compute_dtype, scale[l], z_frag ? z_frag[l] : nullptr, z_frag ? dW[l] : nullptr,
                                                    z_frag ? db[l] : nullptr, hand_down ? Y[l - 1] : nullptr, hand_down ? scale[l - 1] : 1.0f,
-                                                   handed ? 1 : 0, offer ? &ride : nullptr);
+                                                   handed ? 1 : 0, offer ? &ride : nullptr, false, &carried);
                 if (rc != GCNPT_OK) return rc;
+            } else if (offer) {                                      // (a launch outside the requested range: would it have carried?)
+                SideWgrads sw;
+                carried = handed && y_dtype[l] == dh_dtype[l] && esize(y_dtype[l]) == esize(compute_dtype) && option(GCNPT_OPT_FOUR_WAVES) != 1 &&
+                          plan_side_wgrad(sw, ride, B, T, compute_dtype);
             }
-            if (offer) wg_done[l + 1] = true;                        // carried, or launched right behind
+            if (carried) wg_done[l + 1] = true;                      // what no launch carried goes into the launch at the end of the sweep
         }
         g = dh[l];
     }

@@ -668,13 +668,14 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_trees_kernel(const Tree
         if (dst.colT_idx)
             for (int k = t; k < nnzT; k += GATHER_THREADS) dst.colT_idx[(size_t)b * cap + k] = src.colT_idx[s * cap_s + k];
     }
-    const int4 z = make_int4(0, 0, 0, 0);
+    typedef int i32x4_t __attribute__((ext_vector_type(4)));       // (a first-class vector: a select between int4 STRUCTS went through scratch memory)
+    const i32x4_t z = {0, 0, 0, 0};
     for (int q = t; q < 2 * T; q += GATHER_THREADS) {    // ELL heads, 16 bytes at a time
         const int i = q >> 1;
         const bool have = ok && i < Ts;
         const size_t o = (s * Ts + min(i, Ts - 1)) * 2 + (q & 1);
-        reinterpret_cast<int4*>(dst.ell)[(size_t)b * T * 2 + q] = have ? reinterpret_cast<const int4*>(src.ell)[o] : z;
-        if (dst.ellT) reinterpret_cast<int4*>(dst.ellT)[(size_t)b * T * 2 + q] = have ? reinterpret_cast<const int4*>(src.ellT)[o] : z;
+        reinterpret_cast<i32x4_t*>(dst.ell)[(size_t)b * T * 2 + q] = have ? reinterpret_cast<const i32x4_t*>(src.ell)[o] : z;
+        if (dst.ellT) reinterpret_cast<i32x4_t*>(dst.ellT)[(size_t)b * T * 2 + q] = have ? reinterpret_cast<const i32x4_t*>(src.ellT)[o] : z;
     }
     if (dst.pool_mask)
         for (int i = t; i < T; i += GATHER_THREADS)

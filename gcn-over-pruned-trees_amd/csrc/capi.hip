@@ -72,7 +72,7 @@ extern "C" const char* gcnpt_last_error(void) { return gcnpt::err_buf(); }
 extern "C" int gcnpt_set_option(int option, int value) {
     if (option < 0 || option >= GCNPT_OPT_COUNT) return gcnpt::fail(GCNPT_E_INVALID, "set_option: unknown option %d", option);
     if (option == GCNPT_OPT_DETERMINISTIC && value != 0 && value != 1) return gcnpt::fail(GCNPT_E_INVALID, "set_option: deterministic is 0 or 1");
-    if (option == GCNPT_OPT_FOUR_WAVES && (value < -1 || value > 2)) return gcnpt::fail(GCNPT_E_INVALID, "set_option: layer form is -1 (auto), 0, 1 or 2");
+    if (option == GCNPT_OPT_FOUR_WAVES && (value < -1 || value > 1)) return gcnpt::fail(GCNPT_E_INVALID, "set_option: four_waves is -1 (auto), 0 or 1");
     if (option == GCNPT_OPT_SIDE_TILES && value < 0) return gcnpt::fail(GCNPT_E_INVALID, "set_option: side_tiles must be >= 0");
     gcnpt::g_options[option].store(value, std::memory_order_relaxed);
     return GCNPT_OK;

@@ -53,14 +53,9 @@ static int vec_bytes(int width, size_t es, const void* a, const void* b) {
 }
 
 
-namespace gcnpt { int rowgemm_try(hipStream_t s, const RowTileParams& p, int mode, int in_dtype, int out_dtype, int compute_dtype); }
-
 template <bool BWD, bool DZIN = false>
 static int dispatch_rowtile(hipStream_t s, const RowTileParams& p, int in_dtype, int out_dtype, int compute) {
     const int mode = BWD ? (DZIN ? 2 : 1) : 0;
-    // big batches in bf16: the k-step-pipelined 128-row form (rowgemm_kernels.hip), same bits
-    const int rg = rowgemm_try(s, p, mode, in_dtype, out_dtype, compute);
-    if (rg != 0) return rg < 0 ? rg : GCNPT_OK;
     if (compute == GCNPT_F32) {
         if (in_dtype != GCNPT_F32 || out_dtype != GCNPT_F32)
             return fail(GCNPT_E_UNSUPPORTED, "compute_dtype f32 needs f32 activations");

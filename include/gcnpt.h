@@ -72,9 +72,7 @@ const char* gcnpt_last_error(void);
  *   GCNPT_OPT_DETERMINISTIC (env GCNPT_DETERMINISTIC, default 0)  1: every element of dW / db is summed by exactly ONE workgroup in a
  *       fixed order (one contraction slice): run-to-run bit-identical weight gradients, as the reference's single-device autograd
  *       gives (model/gcn.py:270-271), at the price of the split contraction's parallelism
- *   GCNPT_OPT_FOUR_WAVES    (env GCNPT_WAVES4, default -1 = by batch size)  which form of the layer kernel runs: 0 = 32-row tiles, 8 waves
- *       (small batches: one workgroup per CU, the shortest latency chain); 1 = 32-row tiles, 4 waves (two or three workgroups per CU);
- *       2 = the k-step-pipelined 128 / 64-row form of big bf16 batches wherever it applies (csrc/rowgemm_kernels.hip).  Same bits.
+ *   GCNPT_OPT_FOUR_WAVES    (env GCNPT_WAVES4, default -1 = by batch size)  0 / 1 forces the 8- / 4-wave form of the layer kernel
  *   GCNPT_OPT_SIDE_TILES    (env GCNPT_SIDE_TILES, default 192)  batches of up to this many 32-row tiles carry the weight gradient of
  *       layer l+1 as a passenger of layer l's backward-data launch (gcnpt_layers_bwd) */
 #define GCNPT_OPT_DETERMINISTIC 0

@@ -1911,55 +1911,3 @@ def test_four_wave_workgroups_match_eight(api, dev, compute, dims):
     for l in range(2):
         assert max_rel(b[2][l].cpu().numpy(), a[2][l].cpu().numpy()) <= 1e-5 and max_rel(b[3][l].cpu().numpy(), a[3][l].cpu().numpy()) <= 1e-5
 
-
-# ---------------------------------------------------------------------------------------------------
-# the k-step-pipelined form of big bf16 batches (csrc/rowgemm_kernels.hip: 128 / 64-row workgroups) against the row-tile form
-# ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("dims", [(72, 100, 96), (200, 180, 200), (360, 200, 200), (600, 300, 300), (200, 360, 600), (300, 600, 300), (44, 36, 52)],
-                         ids=["100_96", "180_200", "c2_widths", "c5_widths", "360_600", "600_300", "widths_mod_4"])
-@pytest.mark.parametrize("layout", ["padded", "packed"])
-def test_pipelined_big_batch_form_matches_row_tiles(api, dev, dims, layout):
-    """gcnpt_set_option(GCNPT_OPT_FOUR_WAVES, 2) forces the big-batch form on a small batch: same gather order, same k-step order per
-    output tile, so every bf16 row -- all three layers' outputs and the input gradient (hand-over between the layers included) -- is
-    BIT-identical to the 32-row-tile form's, and so are the fragment images, i.e. the weight gradients agree up to the order of the
-    float atomics.  Three layers: forward x3 and the two lower backward-data launches take the form (the top layer's backward starts
-    from dY and Y and keeps the row-tile kernel).  Ragged lengths, K = 2 (rows with up to 7 entries and more), a tile count that is
-    not a multiple of the tile size, dropout on."""
-    from gcn_over_pruned_trees_amd import _lib
-    from gcn_over_pruned_trees_amd.utils import synthetic
-    gcn, tree = api
-    din, h0, h1 = dims
-    B, T, K = 9, 61, 2
-    tb = synthetic.random_tree_batch(29, B, T, "tacred")
-    trees = _prune(tree, tb, K, dev)
-    Wn, bn = synthetic.layer_params(30, [din, h0, h1, h0])
-    xn, gyn = synthetic.normal(31, (B, T, din)), synthetic.normal(32, (B, T, h0))
-    keep = ~_t(tb["masks"], dev)
-    if layout == "packed":
-        trees = trees.pack(tb["lens"].tolist())
-    res = []
-    old = _lib.lib().gcnpt_get_option(_lib.OPT_FOUR_WAVES)
-    try:
-        for form in (0, 2):
-            _lib.set_option(_lib.OPT_FOUR_WAVES, form)
-            x = _t(xn, dev).to(torch.bfloat16)
-            gy = _t(gyn, dev).to(torch.bfloat16)
-            if layout == "packed":
-                x, gy = x[keep].contiguous(), gy[keep].contiguous()
-            x.requires_grad_()
-            Ws = [_t(w, dev).requires_grad_() for w in Wn]
-            bs = [_t(b, dev).requires_grad_() for b in bn]
-            h, acts = gcn.gcn_layers_with_acts(x, Ws, bs, trees, drop_p=[0.3, 0.2, 0.0], seeds=[5, 6, 0], compute_dtype=torch.bfloat16,
-                                               out_dtype=torch.bfloat16)
-            h.backward(gy)
-            torch.cuda.synchronize()
-            res.append((acts, x.grad, [w.grad for w in Ws], [b.grad for b in bs]))
-    finally:
-        _lib.set_option(_lib.OPT_FOUR_WAVES, old)
-    a, b = res
-    assert float(a[0][2].float().abs().max()) > 0
-    for l in range(3):
-        assert torch.equal(a[0][l], b[0][l]), "layer %d output rows differ" % l
-    assert torch.equal(a[1], b[1]), "input gradient rows differ"
-    for l in range(3):
-        assert max_rel(b[2][l].cpu().numpy(), a[2][l].cpu().numpy()) <= 1e-5 and max_rel(b[3][l].cpu().numpy(), a[3][l].cpu().numpy()) <= 1e-5, l

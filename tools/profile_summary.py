@@ -18,7 +18,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
 def short(name):
@@ -97,8 +97,11 @@ traffic = {k: int(2 * cs.get("FETCH_SIZE", 0) * 1024 + cs.get("WRITE_SIZE", 0) *
            for k, cs in merged.items() if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs}
 # bench.py quotes these bytes only for the workload they were recorded on (tools/profile_round.sh profiles the default bench command)
 sha = os.popen("git -C %s rev-parse --short HEAD 2>/dev/null" % ROOT).read().strip() or "?"
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (source_hash: the recording is only quoted for the kernel sources it was made with)
 meta = dict(batch=50, seq=100, din=360, hidden=200, prune_k=1, dtype="bf16", lengths="full",
-            kernels=["pack", "fwd0", "fwd1", "bwd_data1", "bwd_data0+wgrad1", "bwd_weight0"], git_sha="%s (%s)" % (sha, tag))
+            kernels=["pack", "fwd0", "fwd1", "bwd_data1", "bwd_data0+wgrad1", "bwd_weight0"], git_sha="%s (%s)" % (sha, tag),
+            source_hash=bench.source_hash())
 json.dump(dict(meta=meta, traffic=traffic), open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(traffic))
 for k in sorted(merged):

@@ -21,7 +21,8 @@ raise on malformed trees the way the reference does; False keeps the step free o
 layer loop runs on token-packed rows, sum(len) instead of B*T, padding only at the module boundary), `gcn_graph_rng` = False
 (True: dropout seeds that survive hipGraph capture), `gcn_pool_handover` = True (layer stack + poolings as one op whose backward
 hands the top layer its dZ), `gcn_pack_with_trees` = True (the tree launch also packs the weights in a training step),
-`gcn_reuse_packed_weights` = False (True: a TRAINING forward may reuse the packed weight images of the previous one while the weights'
+`gcn_sparse_emb_grad` = False (True: the word-embedding table's gradient is a row-sparse tensor of the batch's token rows, for
+shard.SparseRowExchange in a data-parallel loop), `gcn_reuse_packed_weights` = False (True: a TRAINING forward may reuse the packed weight images of the previous one while the weights'
 version counters stand still -- gradient accumulation; off by default because `p.data` updates do not bump them) -- with `gcn_check_trees=False` a whole training step of the no-LSTM
 model can be captured with torch.cuda.graph and replayed, see tests/test_gpu_parity.py::test_training_step_graph_capture).
 """
@@ -322,28 +323,40 @@ class _EmbedFn(torch.autograd.Function):
     """nn.Embedding lookup (model/gcn.py:235-239) whose backward is ONE index_add_ of float atomics.  PyTorch-ROCm 2.10's own
     embedding backward takes ~140 us per table at the 1.5-5 k indices of a batch (embedding_backward_feature_kernel: three
     tables = half of the no-LSTM training step) and above 3072 indices a rocPRIM sort path that faults when replayed in a
-    hipGraph; same sums, same zero row for padding_idx."""
+    hipGraph; same sums, same zero row for padding_idx.
+    sparse = True: the gradient is a ROW-SPARSE tensor instead (indices = the batch's token ids, values = their gradient rows; rows
+    >= topn and the padding row zeroed, gcn.py:84-88): a data-parallel loop then exchanges (row ids, rows) with
+    shard.SparseRowExchange instead of all-reducing the dense [V, E] table."""
 
     @staticmethod
-    def forward(ctx, weight, idx, padding_idx):
+    def forward(ctx, weight, idx, padding_idx, sparse=False, topn=None):
         ctx.save_for_backward(idx)
-        ctx.table, ctx.pad = tuple(weight.shape), padding_idx
+        ctx.table, ctx.pad, ctx.sparse, ctx.topn = tuple(weight.shape), padding_idx, sparse, topn
         return torch.nn.functional.embedding(idx, weight)
 
     @staticmethod
     def backward(ctx, g):
         (idx,) = ctx.saved_tensors
+        flat, rows = idx.reshape(-1), g.reshape(-1, g.shape[-1])
+        if ctx.sparse:
+            keep = torch.ones_like(flat, dtype=torch.bool)
+            if ctx.pad is not None:
+                keep &= flat != ctx.pad
+            if ctx.topn is not None:
+                keep &= flat < ctx.topn
+            rows = rows * keep.unsqueeze(1).to(rows.dtype)
+            return torch.sparse_coo_tensor(flat.unsqueeze(0), rows, size=ctx.table), None, None, None, None
         gw = torch.zeros(ctx.table, dtype=g.dtype, device=g.device)
-        gw.index_add_(0, idx.reshape(-1), g.reshape(-1, g.shape[-1]))
+        gw.index_add_(0, flat, rows)
         if ctx.pad is not None:
             gw[ctx.pad].zero_()
-        return gw, None, None
+        return gw, None, None, None, None
 
 
-def _embed(table, idx):
+def _embed(table, idx, sparse=False, topn=None):
     """table: nn.Embedding.  Same result as table(idx)."""
     if idx.is_cuda and table.weight.requires_grad and torch.is_grad_enabled():
-        return _EmbedFn.apply(table.weight, idx, table.padding_idx)
+        return _EmbedFn.apply(table.weight, idx, table.padding_idx, sparse, topn)
     return table(idx)
 
 
@@ -414,7 +427,7 @@ class GCNRelationModel(nn.Module):
         topn = self.opt.get('topn', self.opt['vocab_size'])
         if topn <= 0:
             self.emb.weight.requires_grad = False
-        elif topn < self.opt['vocab_size']:
+        elif topn < self.opt['vocab_size'] and not self.opt.get('gcn_sparse_emb_grad', False):
             def keep_top(grad, n=topn):
                 grad = grad.clone()
                 grad[n:].zero_()
@@ -535,7 +548,11 @@ class GCN(nn.Module):
     def _word_embeddings(self, words):
         """EmbeddingDropout of the reference (model/dropouts.py:23-39): in training, every word TYPE of a
         sentence is dropped with probability emb_dropout and the rest is scaled by 1/(1-p)."""
-        embs = _embed(self.emb, words)
+        # opt['gcn_sparse_emb_grad']: the word table's gradient as (token ids, rows) -- what a data-parallel loop exchanges with
+        # shard.SparseRowExchange instead of the dense [V, 300] all-reduce; topn is then applied to the rows here, not by the hook
+        sparse = bool(self.opt.get('gcn_sparse_emb_grad', False))
+        topn = self.opt.get('topn', self.opt['vocab_size'])
+        embs = _embed(self.emb, words, sparse, topn if (sparse and 0 < topn < self.opt['vocab_size']) else None)
         p = self.emb_dropout
         if not self.training or p <= 0.0:
             return embs

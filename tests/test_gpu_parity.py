@@ -1585,6 +1585,34 @@ def test_packed_weight_cache_follows_weight_versions(api, dev):
         assert torch.equal(c, d)                                              # = a model that never had a cache
 
 
+def test_sparse_embedding_gradient_equals_dense(api, dev):
+    """opt['gcn_sparse_emb_grad']: the word table's gradient as a row-sparse tensor (what shard.SparseRowExchange exchanges between
+    ranks instead of the dense [V, E] all-reduce) holds exactly the dense gradient, topn (gcn.py:84-88) and the padding row included."""
+    from gcn_over_pruned_trees_amd.utils import synthetic
+    gcn, tree = api
+    B, T, K = 6, 40, 1
+    base = dict(vocab_size=60, emb_dim=24, pos_dim=4, ner_dim=4, hidden_dim=32, num_layers=2, input_dropout=0.0, gcn_dropout=0.0,
+                prune_k=K, pooling="max", mlp_layers=1, rnn=False, dataset="tacred", num_class=5, topn=30, cuda=True, adj_type="regular")
+    tb = synthetic.random_tree_batch(83, B, T, "tacred")
+    rng = np.random.RandomState(84)
+    ids = lambda hi: _t(rng.randint(1, hi, size=(B, T)) * ~tb["masks"], dev)  # noqa: E731
+    inputs = (ids(60), _t(tb["masks"], dev), ids(40), ids(8), _t(tb["deprel"], dev), _t(tb["head"], dev), _t(tb["subj_pos"], dev), _t(tb["obj_pos"], dev))
+    grads = []
+    for sparse in (False, True):
+        torch.manual_seed(5)
+        model = gcn.GCNClassifier(dict(base, gcn_sparse_emb_grad=sparse)).to(dev).train()
+        logits, _ = model(inputs)
+        logits.logsumexp(1).mean().backward()
+        g = model.gcn_model.emb.weight.grad
+        assert g.is_sparse == sparse
+        grads.append(g.to_dense() if sparse else g)
+        if sparse:
+            ids_touched = g.coalesce().indices()[0]
+            assert ids_touched.numel() <= B * T and int(ids_touched.max()) < 60
+    assert float(grads[0].abs().max()) > 0 and float(grads[0][30:].abs().max()) == 0 and float(grads[0][0].abs().max()) == 0
+    assert max_rel(grads[1].cpu().numpy(), grads[0].cpu().numpy()) <= 1e-6
+
+
 def test_training_forward_repacks_after_p_data_updates(api, dev):
     """an optimizer that updates through `p.data` -- the reference's own MyAdagrad does (utils/torch_utils.py:84-88:
     `p.data.addcdiv_`), so do EMA / clipping code -- changes the weights WITHOUT bumping their version counters.  A training forward

@@ -22,7 +22,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
 def short(name):
-    m = re.search(r"(rowtile_wgrad_kernel<[^>]*>|rowtile_kernel<[^>]*>|weight_grad_kernel<[^>]*>|pack_weights_kernel<[^>]*>|prune_to_csr_kernel|fused_fwd_kernel<[^>]*>|rowprep_kernel<[^>]*>|rowgemm_kernel<[^>]*>|dz_rows_kernel<[^>]*>)", name)
+    m = re.search(r"(rowtile_wgrad_kernel<[^>]*>|rowtile_kernel<[^>]*>|weight_grad_kernel<[^>]*>|pack_weights_kernel<[^>]*>|prune_to_csr_kernel)", name)
     return (m.group(1) if m else name[:50]).replace("unsigned short", "bf16")
 
 

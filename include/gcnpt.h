@@ -74,16 +74,11 @@ const char* gcnpt_last_error(void);
  *       gives (model/gcn.py:270-271), at the price of the split contraction's parallelism
  *   GCNPT_OPT_FOUR_WAVES    (env GCNPT_WAVES4, default -1 = by batch size)  0 / 1 forces the 8- / 4-wave form of the layer kernel
  *   GCNPT_OPT_SIDE_TILES    (env GCNPT_SIDE_TILES, default 192)  batches of up to this many 32-row tiles carry the weight gradient of
- *       layer l+1 as a passenger of layer l's backward-data launch (gcnpt_layers_bwd)
- *   GCNPT_OPT_PERSIST       (env GCNPT_PERSIST, default -1 = by batch size)  the persistent form of the layer kernel (bf16 MFMA operands:
- *       one workgroup per CU keeps its weight fragments in registers and walks over its share of the row tiles; what big batches run).
- *       0: never;  n > 0: always, on n workgroups (rounded up to a multiple of 8; tests force it on small batches this way).
- *       Same values bit for bit as the one-tile-per-workgroup forms */
+ *       layer l+1 as a passenger of layer l's backward-data launch (gcnpt_layers_bwd) */
 #define GCNPT_OPT_DETERMINISTIC 0
 #define GCNPT_OPT_FOUR_WAVES 1
 #define GCNPT_OPT_SIDE_TILES 2
-#define GCNPT_OPT_PERSIST 3
-#define GCNPT_OPT_COUNT 4
+#define GCNPT_OPT_COUNT 3
 int gcnpt_set_option(int option, int value);
 int gcnpt_get_option(int option);
 

@@ -1901,55 +1901,6 @@ def test_deterministic_weight_gradients(api, dev):
 
 
 # ---------------------------------------------------------------------------------------------------
-# the persistent big-batch form (csrc/rowpersist_body.h) against the one-tile-per-workgroup form
-# ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("dims", [(360, 200, 200), (600, 300, 300), (200, 360, 96), (304, 520, 72), (64, 40, 640)],
-                         ids=["c2_widths", "c5_widths_col_split", "23_tiles", "33_tiles_col_split", "wide_out"])
-@pytest.mark.parametrize("x_dtype", [torch.bfloat16, torch.float32], ids=["x_bf16", "x_fp32"])
-@pytest.mark.parametrize("grid", [8, 40], ids=["8_workgroups", "40_workgroups"])
-@pytest.mark.parametrize("layout", ["padded", "packed"])
-def test_persistent_form_matches_one_shot(api, dev, dims, x_dtype, grid, layout):
-    """gcnpt_set_option(GCNPT_OPT_PERSIST, n) forces the big-batch form of the layer kernel (n persistent workgroups, weight fragments resident
-    in registers, rows of the next tile prefetched across the matrix phase, wide layers split by output columns over several workgroups per
-    row tile) on a batch of a few dozen row tiles, so that every workgroup walks over several tiles and the last ones run out early.  Same
-    gather order, k order and epilogue as the one-shot form: outputs of all layers, the input gradient and (the dZ hand-over included) every
-    fragment image are bit-identical; the weight gradients differ by the order of their float atomics only."""
-    from gcn_over_pruned_trees_amd.utils import synthetic
-    from gcn_over_pruned_trees_amd import _lib
-    gcn, tree = api
-    B, T, K = 23, 61, 2
-    tb = synthetic.random_tree_batch(31, B, T, "tacred")
-    trees = _prune(tree, tb, K, dev)
-    Wn, bn = synthetic.layer_params(32, list(dims))
-    xn, gyn = synthetic.normal(33, (B, T, dims[0])), synthetic.normal(34, (B, T, dims[-1]))
-    x0, g0 = _t(xn, dev).to(x_dtype), _t(gyn, dev)
-    if layout == "packed":
-        keep = ~_t(tb["masks"], dev)
-        trees = trees.pack(tb["lens"].tolist())
-        x0, g0 = x0[keep].contiguous(), g0[keep].contiguous()
-    res = []
-    old = _lib.lib().gcnpt_get_option(_lib.OPT_PERSIST)
-    try:
-        for persist in (0, grid):
-            _lib.set_option(_lib.OPT_PERSIST, persist)
-            x = x0.clone().requires_grad_()
-            Ws = [_t(w, dev).requires_grad_() for w in Wn]
-            bs = [_t(b, dev).requires_grad_() for b in bn]
-            h, acts = gcn.gcn_layers_with_acts(x, Ws, bs, trees, drop_p=[0.3, 0.0], seeds=[5, 0], compute_dtype=torch.bfloat16)
-            h.backward(g0)
-            torch.cuda.synchronize()
-            res.append((h.detach(), x.grad, [w.grad for w in Ws], [b.grad for b in bs], acts))
-    finally:
-        _lib.set_option(_lib.OPT_PERSIST, old)
-    a, b = res
-    assert float(a[0].abs().max()) > 0 and float(a[1].abs().max()) > 0
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-    assert all(torch.equal(u, v) for u, v in zip(a[4], b[4]))
-    for l in range(2):
-        assert max_rel(b[2][l].cpu().numpy(), a[2][l].cpu().numpy()) <= 1e-5 and max_rel(b[3][l].cpu().numpy(), a[3][l].cpu().numpy()) <= 1e-5
-
-
-# ---------------------------------------------------------------------------------------------------
 # 4-wave workgroups (big batches: two or three workgroups per CU) against the 8-wave form
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dims", [(72, 100), (200, 180), (360, 250), (600, 300), (200, 360), (300, 600)],

@@ -21,6 +21,8 @@ import bench  # noqa: E402
 
 
 def report(name, s):
+    if os.environ.get("GCNPT_STAMPS_DUMP"):                 # raw stamps per launch, for offline analysis
+        np.save(os.path.join(os.environ["GCNPT_STAMPS_DUMP"], "stamps_%s.npy" % name.replace("+", "_")), s)
     s = s[(s != 0).any(1)]
     print("== %s: %d workgroups stamped" % (name, len(s)))
     groups = {}

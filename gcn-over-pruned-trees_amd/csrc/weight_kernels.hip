@@ -3,7 +3,6 @@
 #include "layer_common.h"
 #include "pack_common.h"
 #include "wgrad_common.h"
-#include "wgrad_block.h"
 
 namespace gcnpt {
 
@@ -76,14 +75,14 @@ extern "C" size_t gcnpt_frag_bytes(int rows, int width, int dtype) {
 // fills p for one layer; returns the number of workgroups it takes (a multiple of 8)
 namespace gcnpt {
 int plan_weight_grad(WeightGradParams& p, const void* z_frag, const void* s_frag, int nks, int Din, int H, float* dW, float* db,
-                            int blocks_in_launch, int waves, int wg_budget, int nt, int mt) {
+                            int blocks_in_launch, int waves, int wg_budget, int nt) {
     p = WeightGradParams{};
     p.stamps = static_cast<unsigned long long*>(g_debug_stamps); p.knob = g_debug_knob;
     p.zf = static_cast<const uint4*>(z_frag); p.sf = static_cast<const uint4*>(s_frag);
     p.dW = dW; p.db = db; p.H = H; p.Din = Din;
     p.m_tiles = ceil_div(H, 16); p.n_tiles = ceil_div(Din, 16);
     p.nks = nks;
-    const int mb = ceil_div(p.m_tiles, mt), nb = ceil_div(p.n_tiles, nt);
+    const int mb = ceil_div(p.m_tiles, WG_MT), nb = ceil_div(p.n_tiles, nt);
     // split the contraction so that the launch as a whole has ~256 workgroups, one per CU (the layers of a launch share
     // them: measured 2 us faster per step than letting each layer bring 256 of its own), with at least one k-step per wave;
     // slices is 1, 2, 4 or a multiple of 8 so that each slice maps onto whole XCD groups (rounded DOWN: one more
@@ -134,48 +133,6 @@ static int launch_weight_grad(hipStream_t s, const WeightGradMulti& mp, int comp
     return waves == 8 ? launch_weight_grad_cfg<float, 8, WG_NT, WG_KB>(s, mp) : launch_weight_grad_cfg<float, 4, WG_NT, WG_KB>(s, mp);
 }
 
-// ---- big batches: the workgroup-shared form (wgrad_block.h) -----------------------------------------------------------------------
-// block shapes (WM, MBW, NBW): (4,2,4) = 8 x 8 tiles, (2,5,2) = 10 x 8, (4,4,4) = 16 x 8.  The launch takes the one with the smallest
-// estimated time: fragment bytes through the CUs' L1 paths (~28 B per clock and CU) plus the float atomics of 256 blocks (~250 per clock).
-struct BlockShape { int wm, mbw, nbw; };
-static const BlockShape kBlockShapes[3] = {{4, 2, 4}, {2, 5, 2}, {4, 4, 4}};
-
-template <typename CT, int WM, int MBW, int NBW>
-static int launch_weight_grad_block_cfg(hipStream_t s, const WeightGradMulti& mp) {
-    const size_t lds = weight_grad_block_lds(WM, MBW, NBW);
-    GCNPT_LDS_ATTR_ONCE((weight_grad_block_kernel<CT, WM, MBW, NBW>), 160 * 1024);
-    hipLaunchKernelGGL((weight_grad_block_kernel<CT, WM, MBW, NBW>), dim3(mp.first[mp.n]), dim3(512), lds, s, mp);
-    note_launch(mp.first[mp.n], 512, lds, sizeof(mp));
-    GCNPT_HIP_CHECK(hipGetLastError());
-    return GCNPT_OK;
-}
-
-static int launch_weight_grad_block(hipStream_t s, int n_layers, const void* const* z_frag, const void* const* s_frag, int nks, const int* Din,
-                                    const int* H, float* const* dW, float* const* db, int compute_dtype) {
-    int best = 0;
-    double best_cost = 1e300;
-    for (int v = 0; v < 3; ++v) {
-        const int bm = kBlockShapes[v].wm * kBlockShapes[v].mbw, bn = (8 / kBlockShapes[v].wm) * kBlockShapes[v].nbw;
-        double frags = 0;
-        for (int l = 0; l < n_layers; ++l) frags += (double)ceil_div(ceil_div(H[l], 16), bm) * ceil_div(ceil_div(Din[l], 16), bn) * (bm + bn);
-        const double cost = frags * nks * (1024.0 / 28.0) / 256.0 + 256.0 * bm * bn * 256.0 / 250.0;
-        if (cost < best_cost) { best = v; best_cost = cost; }
-    }
-    const int bm = kBlockShapes[best].wm * kBlockShapes[best].mbw, bn = (8 / kBlockShapes[best].wm) * kBlockShapes[best].nbw;
-    int blocks = 0;
-    for (int l = 0; l < n_layers; ++l) blocks += ceil_div(ceil_div(H[l], 16), bm) * ceil_div(ceil_div(Din[l], 16), bn);
-    WeightGradMulti mp{};
-    mp.n = n_layers;
-    for (int l = 0; l < n_layers; ++l)
-        mp.first[l + 1] = mp.first[l] + plan_weight_grad(mp.l[l], z_frag[l], s_frag[l], nks, Din[l], H[l], dW[l], db[l], blocks, 8, 256, bn, bm);
-    const bool bf = compute_dtype == GCNPT_BF16;
-    switch (best) {
-        case 0: return bf ? launch_weight_grad_block_cfg<bf16_t, 4, 2, 4>(s, mp) : launch_weight_grad_block_cfg<float, 4, 2, 4>(s, mp);
-        case 1: return bf ? launch_weight_grad_block_cfg<bf16_t, 2, 5, 2>(s, mp) : launch_weight_grad_block_cfg<float, 2, 5, 2>(s, mp);
-        default: return bf ? launch_weight_grad_block_cfg<bf16_t, 4, 4, 4>(s, mp) : launch_weight_grad_block_cfg<float, 4, 4, 4>(s, mp);
-    }
-}
-
 extern "C" int gcnpt_layer_bwd_weight_multi(void* stream, int n_layers, const void* const* z_frag, const void* const* s_frag,
                                             int B, int T, const int* Din, const int* H, float* const* dW, float* const* db,
                                             int compute_dtype) {
@@ -184,16 +141,11 @@ extern "C" int gcnpt_layer_bwd_weight_multi(void* stream, int n_layers, const vo
     GCNPT_REQUIRE(B > 0 && T >= 0, "layer_bwd_weight: sizes must be positive");
     GCNPT_REQUIRE(dtype_ok(compute_dtype), "layer_bwd_weight: bad dtype");
     const int nks = ceil_div((int)rows_of(B, T), 32) * (compute_dtype == GCNPT_BF16 ? 1 : 2);
-    for (int l = 0; l < n_layers; ++l) {
-        GCNPT_REQUIRE(z_frag[l] && s_frag[l] && dW[l] && db[l], "layer_bwd_weight: null pointer (layer %d)", l);
-        GCNPT_REQUIRE(Din[l] > 0 && H[l] > 0, "layer_bwd_weight: sizes must be positive (layer %d)", l);
-    }
-    const int form = option(GCNPT_OPT_WGRAD_BLOCK);          // -1: by batch size, 0 / 1: never / always the workgroup-shared form
-    if (option(GCNPT_OPT_DETERMINISTIC) != 1 && (form == 1 || (form < 0 && nks >= 512)))
-        return launch_weight_grad_block((hipStream_t)stream, n_layers, z_frag, s_frag, nks, Din, H, dW, db, compute_dtype);
     WeightGradMulti mp{};
     mp.n = n_layers;
     for (int l = 0; l < n_layers; ++l) {
+        GCNPT_REQUIRE(z_frag[l] && s_frag[l] && dW[l] && db[l], "layer_bwd_weight: null pointer (layer %d)", l);
+        GCNPT_REQUIRE(Din[l] > 0 && H[l] > 0, "layer_bwd_weight: sizes must be positive (layer %d)", l);
         mp.first[l + 1] = mp.first[l] + plan_weight_grad(mp.l[l], z_frag[l], s_frag[l], nks, Din[l], H[l], dW[l], db[l],
                                                          wg_blocks(n_layers, Din, H, wg_nt(nks)), wg_waves(n_layers, nks), wg_budget(nks), wg_nt(nks));
     }

@@ -194,9 +194,8 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 2) void weight_grad_kernel(const W
 }
 
 // host side (weight_kernels.hip): fills p for one layer; returns the number of workgroups it takes (a multiple of 8)
-// (mt x nt: output tiles of a workgroup's block)
 int plan_weight_grad(WeightGradParams& p, const void* z_frag, const void* s_frag, int nks, int Din, int H, float* dW, float* db,
-                     int blocks_in_launch, int waves, int wg_budget, int nt, int mt = WG_MT);
+                     int blocks_in_launch, int waves, int wg_budget, int nt);
 // dynamic LDS of a weight-gradient workgroup of NW waves
 inline size_t weight_grad_lds(int nw) { return (sizeof(f32x4_t) * 12 * WAVE + sizeof(float) * WG_MT * 16) * (size_t)nw; }
 

@@ -1901,56 +1901,6 @@ def test_deterministic_weight_gradients(api, dev):
 
 
 # ---------------------------------------------------------------------------------------------------
-# the workgroup-shared weight-gradient kernel of big batches (csrc/wgrad_block.h) against the per-wave form and the oracle
-# ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("dims", [(360, 200, 200), (600, 300, 300), (72, 40, 130), (200, 360, 24)],
-                         ids=["c2_widths", "c5_widths", "narrow", "wide_hidden"])
-@pytest.mark.parametrize("compute", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("shape", [(23, 61), (9, 100)], ids=["44_ksteps", "29_ksteps"])
-def test_block_weight_gradient_matches_per_wave_form(api, dev, dims, compute, shape):
-    """gcnpt_set_option(GCNPT_OPT_WGRAD_BLOCK, 1) forces the big-batch form of the weight gradient (a workgroup shares a k-step's fragments
-    through a two-slot LDS ring, register-staged two k-steps ahead; 8x8 / 10x8 / 16x8-tile blocks; odd and even k-step counts per slice) on
-    a batch of ~1 k rows.  Same products, another summation order: dW / db within 1e-5 (fp32) / 2e-5 (bf16 products are exact in fp32, the
-    order of the fp32 sums differs) of the per-wave form, and within GRAD_RTOL / BF16_GRAD of the oracle differentiated through the device's
-    activations."""
-    from gcn_over_pruned_trees_amd.utils import synthetic
-    from gcn_over_pruned_trees_amd import _lib
-    from oracle import gcn_ref, prune_ref
-    gcn, tree = api
-    B, T = shape
-    K = 1
-    tb = synthetic.random_tree_batch(41, B, T, "tacred")
-    trees = _prune(tree, tb, K, dev)
-    Wn, bn = synthetic.layer_params(42, list(dims))
-    xn, gyn = synthetic.normal(43, (B, T, dims[0])), synthetic.normal(44, (B, T, dims[-1]))
-    res = []
-    old = _lib.lib().gcnpt_get_option(_lib.OPT_WGRAD_BLOCK)
-    try:
-        for form in (0, 1):
-            _lib.set_option(_lib.OPT_WGRAD_BLOCK, form)
-            x = _t(xn, dev).requires_grad_()
-            Ws = [_t(w, dev).requires_grad_() for w in Wn]
-            bs = [_t(b, dev).requires_grad_() for b in bn]
-            h, acts = gcn.gcn_layers_with_acts(x, Ws, bs, trees, compute_dtype=compute)
-            h.backward(_t(gyn, dev))
-            torch.cuda.synchronize()
-            res.append(([w.grad.cpu().numpy() for w in Ws], [b.grad.cpu().numpy() for b in bs], [a_.float().cpu().numpy() for a_ in acts]))
-    finally:
-        _lib.set_option(_lib.OPT_WGRAD_BLOCK, old)
-    a, b = res
-    tol = 1e-5 if compute == torch.float32 else 2e-5
-    for l in range(2):
-        assert float(np.abs(b[0][l]).max()) > 0 and float(np.abs(b[1][l]).max()) > 0
-        assert max_rel(b[0][l], a[0][l]) <= tol and max_rel(b[1][l], a[1][l]) <= tol
-    # the oracle, differentiated through the device's own activations (a pre-activation within rounding of zero may be cut either way)
-    adj = prune_ref.batch_adj(tb["head"], tb["subj_pos"], tb["obj_pos"], tb["deprel"], tb["lens"], K)["adj"]
-    _, dWs, dbs = gcn_ref.gcn_backward(adj, xn, Wn, bn, gyn, acts=b[2])
-    for l in range(2):
-        lim = GRAD_RTOL if compute == torch.float32 else BF16_GRAD
-        assert max_rel(b[0][l], dWs[l]) <= lim and max_rel(b[1][l], dbs[l]) <= lim
-
-
-# ---------------------------------------------------------------------------------------------------
 # 4-wave workgroups (big batches: two or three workgroups per CU) against the 8-wave form
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dims", [(72, 100), (200, 180), (360, 250), (600, 300), (200, 360), (300, 600)],

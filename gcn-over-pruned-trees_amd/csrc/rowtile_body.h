@@ -71,14 +71,9 @@ struct RowTileParams {
 // n_blocks: this workgroup's tile number and the number of tiles, which that launch does not read off blockIdx / gridDim)
 // NWV: waves per workgroup.  8 for the headline batches (one workgroup per CU, the shortest chain); 4 for big batches, where two
 // workgroups share a CU (same registers per wave, half the waves each) and one's memory waits overlap the other's arithmetic.
-// RW: token rows per workgroup.  32 for everything up to a few hundred row tiles; 64 for big batches, where a launch runs at the rate the
-// CUs take the weight fragments in (~20 B per clock and CU through the L1 path: 360 KB of fragments per 32 rows at the C5 input layer):
-// a 64-row workgroup feeds each fragment to four MFMAs instead of two, i.e. halves the weight bytes per row.
-template <typename CT, typename IT, typename OT, bool BWD, int VEC, int NTW, int KSMAX, bool DZIN = false, int NWV = 8, int RW = ROWS>
+template <typename CT, typename IT, typename OT, bool BWD, int VEC, int NTW, int KSMAX, bool DZIN = false, int NWV = 8>
 __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int block_id, const int n_blocks, unsigned char* smem_raw) {
     constexpr int RTT = NWV * WAVE, RTW = NWV;                  // threads and waves of this workgroup
-    constexpr int MT = RW / 16, HV = RW / ROWS;                 // 16-row MFMA tiles and 32-row halves (= k-steps of the bf16 fragment images) of the tile
-    static_assert(RW == 32 || RW == 64, "32- or 64-row workgroups");
     static_assert(BWD || !DZIN, "DZIN is a backward mode");
     constexpr bool MASKED = BWD && !DZIN;                       // the loader computes dZ = dY * 1[Y>0] * scale / (deg+1) itself
     constexpr int KSTEP = sizeof(CT) == 2 ? 32 : 16;            // K consumed per fragment
@@ -88,22 +83,22 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
     const int stride = lds_stride_dw(p.Kpad * (int)sizeof(CT) / 4) * 4 / (int)sizeof(CT);     // S row stride, CT elements
     const int ncols_pass = RTW * NTW * 16;
     const int ostride = out_stride_dw(min(round_up(p.NOUT, 16), ncols_pass) * (int)sizeof(OT) / 4) * 4 / (int)sizeof(OT);
-    const size_t s_bytes = (size_t)RW * stride * sizeof(CT);
+    const size_t s_bytes = (size_t)ROWS * stride * sizeof(CT);
     CT* S = reinterpret_cast<CT*>(smem_raw);
     // bwd: Z (the tile's own dZ rows, before aggregation) is only read by the fragment-image emission, the out tile O only
     // written from the epilogue on: they share one region, with a barrier between the two uses
-    const size_t o_bytes = (size_t)RW * ostride * sizeof(OT);
+    const size_t o_bytes = (size_t)ROWS * ostride * sizeof(OT);
     const size_t zo_bytes = BWD ? (s_bytes > o_bytes ? s_bytes : o_bytes) : o_bytes;
     CT* Z = reinterpret_cast<CT*>(smem_raw + s_bytes);
     OT* O = reinterpret_cast<OT*>(smem_raw + s_bytes);
     int* meta = reinterpret_cast<int*>(smem_raw + s_bytes + zo_bytes);
-    int* rell = meta;                         // [RW][8] ELL heads of the tile's rows (count, 7 sentence-local columns)
-    float* rinv = reinterpret_cast<float*>(meta + 8 * RW);   // [RW] fwd: 1/(deg+1)   bwd: scale/(deg+1)
-    float* rden = reinterpret_cast<float*>(meta + 9 * RW);   // [RW] deg+1
-    int* glist = meta + 10 * RW;              // [RW] tile rows that aggregate at least one entry, compacted
-    int* rsb = meta + 11 * RW;                // [RW] first row of the row's sentence (b * T)
-    int* gcount = meta + 12 * RW;             // [1] the number of entries of glist
-    float* sbias = reinterpret_cast<float*>(meta + 13 * RW);   // [max(RTT, columns of a pass)] fwd: the bias of this pass's columns
+    int* rell = meta;                         // [ROWS][8] ELL heads of the tile's rows (count, 7 sentence-local columns)
+    float* rinv = reinterpret_cast<float*>(meta + 8 * ROWS);   // [ROWS] fwd: 1/(deg+1)   bwd: scale/(deg+1)
+    float* rden = reinterpret_cast<float*>(meta + 9 * ROWS);   // [ROWS] deg+1
+    int* glist = meta + 10 * ROWS;            // [ROWS] tile rows that aggregate at least one entry, compacted
+    int* rsb = meta + 11 * ROWS;              // [ROWS] first row of the row's sentence (b * T)
+    int* gcount = meta + 12 * ROWS;           // [1] the number of entries of glist
+    float* sbias = reinterpret_cast<float*>(meta + 13 * ROWS);   // [max(RTT, columns of a pass)] fwd: the bias of this pass's columns
 
     // `wave` through readfirstlane: the compiler then knows it is uniform and does every wave-dependent address in SALU
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -112,7 +107,7 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
     // gathers are rows the same L2 serves to the tiles next to it (speed only; any placement gives the same values)
     const int xg = block_id & 7, xq = n_blocks >> 3, xr = n_blocks & 7;
     const int tile_id = xg * xq + min(xg, xr) + (block_id >> 3);
-    const int r0 = tile_id * RW;
+    const int r0 = tile_id * ROWS;
     const IT* src = static_cast<const IT*>(p.src);
     const IT* yref = static_cast<const IT*>(p.yref);
     const uint4* wfrag = static_cast<const uint4*>(p.wfrag);
@@ -127,15 +122,10 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
     //     them (64 lanes x 16 bytes; waves 1..7 hit wave 0's lines) and keeps its own copy of the derived tables: the load
     //     is unconditional and first in the queue, and no wave waits for another one before it can start gathering.
     const int erow = lane >> 1, ehalf = lane & 1;
-    int4 ell_v[HV];
-    int deg_v[HV], sb_v[HV];
-#pragma unroll
-    for (int h = 0; h < HV; ++h) {
-        const size_t er = (size_t)min(r0 + ROWS * h + erow, p.N - 1);
-        ell_v[h] = reinterpret_cast<const int4*>(p.g_ell)[er * 2 + ehalf];
-        deg_v[h] = p.d_ell[er * 8];                                                      // gcn.py:261
-        sb_v[h] = p.T ? (int)er / p.T * p.T : 0;   // the one division by T, done while the loads are on their way (T = 0: packed rows, columns are absolute)
-    }
+    const size_t er = (size_t)min(r0 + erow, p.N - 1);
+    const int4 ell_v = reinterpret_cast<const int4*>(p.g_ell)[er * 2 + ehalf];
+    const int deg_v = p.d_ell[er * 8];                                                   // gcn.py:261
+    const int sb_v = p.T ? (int)er / p.T * p.T : 0;   // the one division by T, done while the loads are on their way (T = 0: packed rows, columns are absolute)
     float bias_v = 0.0f;                           // fwd: one bias element per thread, parked in LDS with the heads (registers are
     if constexpr (!BWD) bias_v = p.bias[min(tid, p.NOUT - 1)];      // too scarce to carry 4 per tile through the whole kernel)
     float bias_w = 0.0f;                           // (4 waves x 5 tiles: 320 columns per pass, a second element for the first 64 threads)
@@ -144,7 +134,7 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
     // own rows of the first batch (everyone)
     const int nchunk = p.Kpad / 8;
     auto div_chunk = [&](int x) { return (int)__umulhi((unsigned)x, p.chunk_magic); };    // x / nchunk, exact for x * nchunk < 2^32
-    const int n_items = RW * nchunk;
+    const int n_items = ROWS * nchunk;
     // VEC: 8 = rows read 16 bytes at a time (K % 8 == 0), 4 = in 8-byte (bf16) / 16-byte (f32) halves (K % 4 == 0), 0 = element loads
     const int kmax8 = VEC == 8 ? p.K - 8 : (VEC == 4 ? p.K - 4 : p.K - 1);
     auto ld8 = [&](const IT* base, size_t row, int k0c, raw8<IT>& dst) {
@@ -199,26 +189,20 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
     // waves write the same values to the same places; each reads back only after its own writes (wave_lds_fence).
     {
         const bool first = ehalf == 0;
+        const int e0 = (first && r0 + erow >= p.N) ? 0 : ell_v.x;                    // rows past the end aggregate nothing
+        reinterpret_cast<int4*>(rell)[erow * 2 + ehalf] = make_int4(e0, ell_v.y, ell_v.z, ell_v.w);
+        const float dn = (float)(deg_v + 1);
+        rsb[erow] = sb_v;
         if constexpr (!BWD) {
             sbias[tid] = bias_v;
             if constexpr (RTW * NTW * 16 > RTT) { if (tid < RTW * NTW * 16 - RTT) sbias[RTT + tid] = bias_w; }
         }
-        int n_agg = 0;
-#pragma unroll
-        for (int h = 0; h < HV; ++h) {
-            const int row = ROWS * h + erow;
-            const int e0 = (first && r0 + row >= p.N) ? 0 : ell_v[h].x;               // rows past the end aggregate nothing
-            reinterpret_cast<int4*>(rell)[row * 2 + ehalf] = make_int4(e0, ell_v[h].y, ell_v[h].z, ell_v[h].w);
-            const float dn = (float)(deg_v[h] + 1);
-            rsb[row] = sb_v[h];
-            rinv[row] = (BWD ? p.scale : 1.0f) / dn;    // both lanes of a row write it: a use under `first` only would let
-            rden[row] = dn;                             // hipcc sink the degree load into that branch, behind a full wait
-            const bool agg = first && e0 > 0 && p.out != nullptr;
-            const unsigned long long m = __ballot(agg);
-            if (agg) glist[n_agg + __popcll(m & ((1ull << lane) - 1ull))] = row;
-            n_agg += __popcll(m);
-        }
-        if (lane == 0) *gcount = n_agg;
+        rinv[erow] = (BWD ? p.scale : 1.0f) / dn;       // both lanes of a row write it: a use under `first` only would let
+        rden[erow] = dn;                                // hipcc sink the degree load into that branch, behind a full wait
+        const bool agg = first && e0 > 0 && p.out != nullptr;
+        const unsigned long long m = __ballot(agg);
+        if (agg) glist[__popcll(m & ((1ull << lane) - 1ull))] = erow;
+        if (lane == 0) *gcount = __popcll(m);
     }
     GCNPT_STAMP(p.stamps, 1);
     wave_lds_fence();
@@ -395,33 +379,30 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
         using XT = std::remove_cv_t<std::remove_pointer_t<decltype(X)>>;
         if constexpr (sizeof(XT) == 2) {
             const int i = lane & 15, g = lane >> 4, q4 = i >> 2, pp = i & 3;
-            const size_t nks = (size_t)ceil_div(p.N, ROWS);                 // the image's k-steps are 32 rows whatever the tile is
-            for (int th = wave; th < nt * HV; th += RTW) {
-                const int t = HV == 1 ? th : th / HV, h = HV == 1 ? 0 : th % HV;
-                if ((size_t)tile_id * HV + h >= nks) continue;              // (a 64-row tile whose second half lies past the last row)
+            const size_t nks = n_blocks;
+            for (int t = wave; t < nt; t += RTW) {
                 const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4_t*)(X + (size_t)(ROWS * h + 8 * g + q4) * xstride + 16 * t + 4 * pp));
+                    (__attribute__((address_space(3))) s16x4_t*)(X + (size_t)(8 * g + q4) * xstride + 16 * t + 4 * pp));
                 const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4_t*)(X + (size_t)(ROWS * h + 8 * g + 4 + q4) * xstride + 16 * t + 4 * pp));
+                    (__attribute__((address_space(3))) s16x4_t*)(X + (size_t)(8 * g + 4 + q4) * xstride + 16 * t + 4 * pp));
                 uint4 u;
                 u.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
                 u.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
                 u.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
                 u.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
-                GCNPT_FRAG_STORE(bwd_store, &F[((size_t)(t0 + t) * nks + (size_t)tile_id * HV + h) * 64 + lane], u);
+                GCNPT_FRAG_STORE(bwd_store, &F[((size_t)(t0 + t) * nks + tile_id) * 64 + lane], u);
             }
         } else {
             const int i = lane & 15, g = lane >> 4;
-            const size_t nks = (size_t)ceil_div(p.N, ROWS) * 2;             // fp32 fragments: 16 rows per k-step
-            for (int tk = wave; tk < nt * MT; tk += RTW) {
-                const int t = tk / MT, kk = tk % MT;
-                if ((size_t)tile_id * MT + kk >= nks) continue;
+            const size_t nks = (size_t)n_blocks * 2;
+            for (int tk = wave; tk < nt * 2; tk += RTW) {
+                const int t = tk >> 1, kk = tk & 1;
                 uint4 u;
                 u.x = __float_as_uint(X[(size_t)(16 * kk + 4 * g + 0) * xstride + 16 * t + i]);
                 u.y = __float_as_uint(X[(size_t)(16 * kk + 4 * g + 1) * xstride + 16 * t + i]);
                 u.z = __float_as_uint(X[(size_t)(16 * kk + 4 * g + 2) * xstride + 16 * t + i]);
                 u.w = __float_as_uint(X[(size_t)(16 * kk + 4 * g + 3) * xstride + 16 * t + i]);
-                GCNPT_FRAG_STORE(bwd_store, &F[((size_t)(t0 + t) * nks + (size_t)tile_id * MT + kk) * 64 + lane], u);
+                GCNPT_FRAG_STORE(bwd_store, &F[((size_t)(t0 + t) * nks + 2 * tile_id + kk) * 64 + lane], u);
             }
         }
     };
@@ -442,21 +423,19 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
     const int n_pass = ceil_div(n_tiles, RTW * NTW);
 
     for (int pass = 0; pass < n_pass; ++pass) {
-        f32x4_t acc[MT][NTW];
+        f32x4_t acc[2][NTW];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) acc[mt][j] = (f32x4_t){0, 0, 0, 0};
+        for (int j = 0; j < NTW; ++j) { acc[0][j] = (f32x4_t){0, 0, 0, 0}; acc[1][j] = (f32x4_t){0, 0, 0, 0}; }
         const int tile0 = pass * RTW * NTW + wave;
 
         for (int kc0 = 0; kc0 < ksteps; kc0 += KSMAX) {
             if (pass > 0 || kc0 > 0) load_w(pass, kc0, 0, KSMAX);
             // A fragments are read one k-step ahead of the MFMAs that use them
             constexpr int AW = sizeof(CT) == 2 ? 8 : 4;                  // CT elements per lane per k-step (16 bytes)
-            uint4 a_cur[MT], a_nxt[MT];
-            auto read_a = [&](int kk, uint4 (&dst)[MT]) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) dst[mt] = *reinterpret_cast<const uint4*>(S + (size_t)(arow + 16 * mt) * stride + kk * KSTEP + kgrp * AW);
+            uint4 a_cur[2], a_nxt[2];
+            auto read_a = [&](int kk, uint4 (&dst)[2]) {
+                dst[0] = *reinterpret_cast<const uint4*>(S + (size_t)arow * stride + kk * KSTEP + kgrp * AW);
+                dst[1] = *reinterpret_cast<const uint4*>(S + (size_t)(arow + 16) * stride + kk * KSTEP + kgrp * AW);
             };
             read_a(kc0, a_cur);
 #pragma unroll
@@ -467,20 +446,19 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
                     for (int j = 0; j < NTW; ++j) {
                         if constexpr (sizeof(CT) == 2) {
                             const bf16x8_t bq = __builtin_bit_cast(bf16x8_t, wreg[ks][j]);
-#pragma unroll
-                            for (int mt = 0; mt < MT; ++mt)
-                                acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq, __builtin_bit_cast(bf16x8_t, a_cur[mt]), acc[mt][j], 0, 0, 0);
+                            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq, __builtin_bit_cast(bf16x8_t, a_cur[0]), acc[0][j], 0, 0, 0);
+                            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq, __builtin_bit_cast(bf16x8_t, a_cur[1]), acc[1][j], 0, 0, 0);
                         } else {
                             const f32x4_t bq = __builtin_bit_cast(f32x4_t, wreg[ks][j]);
+                            const f32x4_t a0 = __builtin_bit_cast(f32x4_t, a_cur[0]), a1 = __builtin_bit_cast(f32x4_t, a_cur[1]);
 #pragma unroll
-                            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                                for (int mt = 0; mt < MT; ++mt)
-                                    acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[s], __builtin_bit_cast(f32x4_t, a_cur[mt])[s], acc[mt][j], 0, 0, 0);
+                            for (int s = 0; s < 4; ++s) {
+                                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[s], a0[s], acc[0][j], 0, 0, 0);
+                                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[s], a1[s], acc[1][j], 0, 0, 0);
+                            }
                         }
                     }
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_nxt[mt];
+                    a_cur[0] = a_nxt[0]; a_cur[1] = a_nxt[1];
                 }
             }
         }
@@ -495,9 +473,9 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
                 __syncthreads();
             }
         }
-        float den[MT], inv[MT];
+        float den[2], inv[2];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) { den[mt] = rden[mt * 16 + (lane & 15)]; inv[mt] = rinv[mt * 16 + (lane & 15)]; }
+        for (int mt = 0; mt < 2; ++mt) { den[mt] = rden[mt * 16 + (lane & 15)]; inv[mt] = rinv[mt * 16 + (lane & 15)]; }
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
             const int tl = tile0 + j * RTW;
@@ -505,7 +483,7 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
             const int col0 = tl * 16 + (lane >> 4) * 4;
             const int lcol0 = col0 - pass * ncols_pass;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
+            for (int mt = 0; mt < 2; ++mt) {
                 const int row = mt * 16 + (lane & 15);
                 float v[4];
                 float bq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -554,7 +532,7 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
             constexpr int NW = (int)sizeof(V) / 4;
             const int pieces = width / PER;                                  // 16 threads per row: no division, 256 contiguous bytes each round
 #pragma unroll
-            for (int rh = 0; rh < RW; rh += RTT / 16) {                      // (one round for 32 rows on 8 waves, two for 32 on 4 or 64 on 8, four for 64 on 4)
+            for (int rh = 0; rh < ROWS; rh += RTT / 16) {                    // (one round with 8 waves, two with 4)
             const int row = rh + (tid >> 4), r = r0 + row;
             if (BWD && relu) {
                 // hand-over to the layer below: its dZ instead of dh (gcn.py:390-393 differentiated where the rows are at hand);
@@ -602,7 +580,7 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
         } else if (p.vec_out >= 8 && (width % PER8) == 0 && (c_lo % PER8) == 0) {
             store_rows(uint2{});
         } else {
-            for (int it = tid; it < RW * width; it += RTT) {
+            for (int it = tid; it < ROWS * width; it += RTT) {
                 const int row = it / width, c = it - row * width;
                 const int r = r0 + row;
                 if (r >= p.N) continue;
@@ -622,10 +600,10 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
 }
 
 
-template <typename CT, typename IT, typename OT, bool BWD, int VEC, int NTW, int KSMAX, bool DZIN = false, int NWV = 8, int RW = ROWS>
+template <typename CT, typename IT, typename OT, bool BWD, int VEC, int NTW, int KSMAX, bool DZIN = false, int NWV = 8>
 __global__ __launch_bounds__(NWV * WAVE, 2) void rowtile_kernel(const RowTileParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    rowtile_body<CT, IT, OT, BWD, VEC, NTW, KSMAX, DZIN, NWV, RW>(p, (int)blockIdx.x, (int)gridDim.x, smem_raw);
+    rowtile_body<CT, IT, OT, BWD, VEC, NTW, KSMAX, DZIN, NWV>(p, (int)blockIdx.x, (int)gridDim.x, smem_raw);
 }
 
 // A backward-data launch with the WEIGHT GRADIENT OF THE LAYER ABOVE as a side job: that gradient only needs the two fragment images
@@ -668,23 +646,18 @@ extern thread_local SideWgrad t_side;      // defined in rowtile_kernels.hip
 int rowtile_launch(int combo, int mode, hipStream_t s, const RowTileParams& p);
 
 #ifdef GCNPT_RT_PART
-constexpr int GCNPT_NOT_TAKEN = 1;      // a form that does not apply to this launch (not an error: the dispatcher tries the next one)
-
-template <typename CT, typename IT, typename OT, bool BWD, int VEC, int NTW, int KSMAX, bool DZIN = false, int NWV = 8, int RW = ROWS>
+template <typename CT, typename IT, typename OT, bool BWD, int VEC, int NTW, int KSMAX, bool DZIN = false, int NWV = 8>
 static inline int launch_rowtile_cfg(hipStream_t s, const RowTileParams& p) {
     const int stride = lds_stride_dw(p.Kpad * (int)sizeof(CT) / 4) * 4 / (int)sizeof(CT);
     const int ncols_pass = NWV * NTW * 16;
     const int ostride = out_stride_dw(std::min(round_up(p.NOUT, 16), ncols_pass) * (int)sizeof(OT) / 4) * 4 / (int)sizeof(OT);
-    const size_t s_bytes = (size_t)RW * stride * sizeof(CT), o_bytes = (size_t)RW * ostride * sizeof(OT);
+    const size_t s_bytes = (size_t)ROWS * stride * sizeof(CT), o_bytes = (size_t)ROWS * ostride * sizeof(OT);
     const size_t lds = s_bytes + (BWD ? std::max(s_bytes, o_bytes) : o_bytes) +
-                       (size_t)RW * 13 * sizeof(int) + (size_t)std::max(NWV * WAVE, ncols_pass) * sizeof(float);
-    if (lds > 160 * 1024) {
-        if constexpr (RW != ROWS) return GCNPT_NOT_TAKEN;       // the caller goes on to the 32-row form
-        return fail(GCNPT_E_UNSUPPORTED, "layer: K=%d needs %zu B of LDS per workgroup", p.K, lds);
-    }
-    const int n_tiles = ceil_div(p.N, RW);
+                       (size_t)ROWS * 13 * sizeof(int) + (size_t)std::max(NWV * WAVE, ncols_pass) * sizeof(float);
+    if (lds > 160 * 1024) return fail(GCNPT_E_UNSUPPORTED, "layer: K=%d needs %zu B of LDS per workgroup", p.K, lds);
+    const int n_tiles = ceil_div(p.N, ROWS);
     // the uniform-precision instantiations can carry the layer above's weight gradient on the CUs that have no row tile
-    if constexpr (NWV == 8 && RW == ROWS && BWD && DZIN && std::is_same<IT, OT>::value && sizeof(CT) == sizeof(IT)) {
+    if constexpr (NWV == 8 && BWD && DZIN && std::is_same<IT, OT>::value && sizeof(CT) == sizeof(IT)) {
         if (t_side.sw && t_side.sw->blocks > 0) {
             auto kern = rowtile_wgrad_kernel<CT, IT, OT, VEC, NTW, KSMAX>;
             GCNPT_LDS_ATTR_ONCE(kern, 160 * 1024);
@@ -697,7 +670,7 @@ static inline int launch_rowtile_cfg(hipStream_t s, const RowTileParams& p) {
             return GCNPT_OK;
         }
     }
-    auto kern = rowtile_kernel<CT, IT, OT, BWD, VEC, NTW, KSMAX, DZIN, NWV, RW>;
+    auto kern = rowtile_kernel<CT, IT, OT, BWD, VEC, NTW, KSMAX, DZIN, NWV>;
     GCNPT_LDS_ATTR_ONCE(kern, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(NWV * WAVE), lds, s, p);
     note_launch(n_tiles, NWV * WAVE, lds, sizeof(p));
@@ -719,37 +692,12 @@ static inline bool use_four_waves(const RowTileParams& p) {
     return pass4 <= pass8;
 }
 
-// 64-row workgroups?  0 = no, 1 = 8 waves, 2 = 4 waves
-static inline int rows64_form(const RowTileParams& p) {
-    const int forced = option(GCNPT_OPT_ROWS64);
-    if (forced >= 0) return p.out ? forced : 0;
-    return 0;
-}
-
 // output tiles per wave: the smallest of {2,3,4} that covers NOUT in one pass (8 waves x NTW x 16 columns),
 // with as many K-steps of weight fragments resident in registers as ~128 VGPRs allow.  Rows that cannot be
 // read 16 bytes at a time (width not a multiple of 8, unaligned base) take the element-load instantiation.
 template <typename CT, typename IT, typename OT, bool BWD, int VEC, bool DZIN>
 static inline int launch_rowtile_vec(hipStream_t s, const RowTileParams& p) {
     const int n_tiles = ceil_div(p.NOUT, 16);
-    if constexpr (VEC != 0) {
-        // 64-row workgroups (big batches; GCNPT_OPT_ROWS64: 1 = 8 waves, one workgroup per CU; 2 = 4 waves, two per CU where the LDS allows)
-        const int r64 = rows64_form(p);
-        int rc64 = GCNPT_NOT_TAKEN;
-        if (r64 == 1) {
-            if (n_tiles <= 16) rc64 = launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 2, 8, DZIN, 8, 64>(s, p);
-            else if (n_tiles <= 24) rc64 = launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 3, 7, DZIN, 8, 64>(s, p);
-            else if (n_tiles > 32 && n_tiles <= 40) rc64 = launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 5, 3, DZIN, 8, 64>(s, p);
-            else rc64 = launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 4, 5, DZIN, 8, 64>(s, p);
-        }
-        if (r64 == 2) {
-            if (n_tiles <= 8) rc64 = launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 2, 8, DZIN, 4, 64>(s, p);
-            else if (n_tiles <= 12) rc64 = launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 3, 7, DZIN, 4, 64>(s, p);
-            else if (n_tiles <= 16) rc64 = launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 4, 5, DZIN, 4, 64>(s, p);
-            else rc64 = launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 5, 3, DZIN, 4, 64>(s, p);
-        }
-        if (rc64 != GCNPT_NOT_TAKEN) return rc64;
-    }
     if (use_four_waves(p)) {                                  // 4 waves cover 8 / 12 / 16 column tiles per pass
         if (n_tiles <= 4 * 2) return launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 2, 12, DZIN, 4>(s, p);
         if (n_tiles <= 4 * 3) return launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 3, 7, DZIN, 4>(s, p);

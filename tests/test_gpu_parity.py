@@ -1901,55 +1901,6 @@ def test_deterministic_weight_gradients(api, dev):
 
 
 # ---------------------------------------------------------------------------------------------------
-# 64-row workgroups (big batches: each weight fragment feeds four MFMAs) against the 32-row form
-# ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("dims", [(360, 200, 200), (600, 300, 300), (200, 360, 96), (72, 100, 520)],
-                         ids=["c2_widths", "c5_widths", "23_tiles", "33_tiles"])
-@pytest.mark.parametrize("compute", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("form", [1, 2], ids=["8_waves", "4_waves"])
-@pytest.mark.parametrize("layout", ["padded_odd_tiles", "padded_even_tiles", "packed"])
-def test_64_row_workgroups_match_32(api, dev, dims, compute, form, layout):
-    """gcnpt_set_option(GCNPT_OPT_ROWS64, 1 / 2) forces the big-batch tile of the layer kernel (64 token rows per workgroup, 8 or 4 waves)
-    on a small batch, with a row count that is and is not a multiple of 64 (the last workgroup's second half then lies past the last
-    row and must not touch the fragment images).  Same gather order, k order and epilogue per row: outputs of both layers and the input
-    gradient are bit-identical to the 32-row form's, the fragment images too (so the weight gradients differ by their atomics' order only)."""
-    from gcn_over_pruned_trees_amd.utils import synthetic
-    from gcn_over_pruned_trees_amd import _lib
-    gcn, tree = api
-    B, T, K = (7, 55, 2) if layout != "padded_even_tiles" else (8, 56, 2)      # 385 rows = 13 tiles of 32;  448 rows = 14
-    tb = synthetic.random_tree_batch(51, B, T, "tacred")
-    trees = _prune(tree, tb, K, dev)
-    Wn, bn = synthetic.layer_params(52, list(dims))
-    xn, gyn = synthetic.normal(53, (B, T, dims[0])), synthetic.normal(54, (B, T, dims[-1]))
-    x0 = _t(xn, dev) if compute == torch.float32 else _t(xn, dev).to(torch.bfloat16)
-    g0 = _t(gyn, dev)
-    if layout == "packed":
-        keep = ~_t(tb["masks"], dev)
-        trees = trees.pack(tb["lens"].tolist())
-        x0, g0 = x0[keep].contiguous(), g0[keep].contiguous()
-    res = []
-    old = _lib.lib().gcnpt_get_option(_lib.OPT_ROWS64)
-    try:
-        for r64 in (0, form):
-            _lib.set_option(_lib.OPT_ROWS64, r64)
-            x = x0.clone().requires_grad_()
-            Ws = [_t(w, dev).requires_grad_() for w in Wn]
-            bs = [_t(b, dev).requires_grad_() for b in bn]
-            h, acts = gcn.gcn_layers_with_acts(x, Ws, bs, trees, drop_p=[0.3, 0.0], seeds=[5, 0], compute_dtype=compute)
-            h.backward(g0)
-            torch.cuda.synchronize()
-            res.append((h.detach(), x.grad, [w.grad for w in Ws], [b.grad for b in bs], acts))
-    finally:
-        _lib.set_option(_lib.OPT_ROWS64, old)
-    a, b = res
-    assert float(a[0].abs().max()) > 0 and float(a[1].abs().max()) > 0
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-    assert all(torch.equal(u, v) for u, v in zip(a[4], b[4]))
-    for l in range(2):
-        assert max_rel(b[2][l].cpu().numpy(), a[2][l].cpu().numpy()) <= 1e-5 and max_rel(b[3][l].cpu().numpy(), a[3][l].cpu().numpy()) <= 1e-5
-
-
-# ---------------------------------------------------------------------------------------------------
 # 4-wave workgroups (big batches: two or three workgroups per CU) against the 8-wave form
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dims", [(72, 100), (200, 180), (360, 250), (600, 300), (200, 360), (300, 600)],

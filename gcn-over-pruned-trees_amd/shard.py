@@ -205,11 +205,14 @@ class SparseRowExchange(object):
         all_rows = [torch.empty_like(rows_pad) for _ in range(world)]
         dist.all_gather(all_ids, ids_pad)
         dist.all_gather(all_rows, rows_pad)
-        cat_ids = torch.cat([a[:c] for a, c in zip(all_ids, counts)])
-        cat_rows = torch.cat([a[:c] for a, c in zip(all_rows, counts)])
-        out_ids, inv = torch.unique(cat_ids, return_inverse=True)                  # rank order is fixed: every rank sums in the same order
-        out_rows = torch.zeros((out_ids.numel(), cat_rows.shape[1]), dtype=cat_rows.dtype, device=cat_rows.device)
-        out_rows.index_add_(0, inv, cat_rows)
+        out_ids = torch.unique(torch.cat([a[:c] for a, c in zip(all_ids, counts)]))
+        out_rows = torch.zeros((out_ids.numel(), rows.shape[1]), dtype=rows.dtype, device=rows.device)
+        # one rank's contribution at a time: its ids are unique, so every add below is collision-free and the ranks are taken in rank
+        # order -- every replica computes bit-identical sums (one index_add_ over the concatenation would use float atomics in whatever
+        # order the device schedules them, and the replicas' tables would drift apart in the last bit)
+        for a_ids, a_rows, c in zip(all_ids, all_rows, counts):
+            if c:
+                out_rows.index_add_(0, torch.searchsorted(out_ids, a_ids[:c]), a_rows[:c])
         self.last_volume_bytes = world * width * (rows.shape[1] * rows.element_size() + 8)
         return out_ids, out_rows
 

@@ -34,6 +34,9 @@ constexpr int RT_THREADS = 512;      // 8 waves; wave w owns output tiles w, w+8
 constexpr int RT_WAVES = RT_THREADS / WAVE;
 static_assert(RT_THREADS == 16 * ROWS, "the row store loop gives every row 16 threads (two rounds in the 4-wave form)");
 constexpr int NB_INLINE = 7;         // neighbours per row that the ELL head carries (include/gcnpt.h)
+#ifndef GCNPT_A_AHEAD
+#define GCNPT_A_AHEAD 2              // k-steps the tile's MFMA operand is read ahead of its use (measured 1..4 at the C2 shape: 51.7 / 51.1 / 51.3 / 51.7 us per step)
+#endif
 #ifndef GCNPT_W_EARLY_NUM
 #define GCNPT_W_EARLY_NUM 1          // quarters of a wave's weight fragments requested before the adjacency is known (0..4 measured: 1 is best)
 #endif
@@ -430,27 +433,29 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
 
         for (int kc0 = 0; kc0 < ksteps; kc0 += KSMAX) {
             if (pass > 0 || kc0 > 0) load_w(pass, kc0, 0, KSMAX);
-            // A fragments are read one k-step ahead of the MFMAs that use them
+            // A fragments are read GCNPT_A_AHEAD k-steps ahead of the MFMAs that use them
             constexpr int AW = sizeof(CT) == 2 ? 8 : 4;                  // CT elements per lane per k-step (16 bytes)
-            uint4 a_cur[2], a_nxt[2];
+            constexpr int AH = GCNPT_A_AHEAD;
+            uint4 a_st[AH + 1][2];                                       // [0] = the k-step on the matrix cores, [d] = d k-steps ahead
             auto read_a = [&](int kk, uint4 (&dst)[2]) {
                 dst[0] = *reinterpret_cast<const uint4*>(S + (size_t)arow * stride + kk * KSTEP + kgrp * AW);
                 dst[1] = *reinterpret_cast<const uint4*>(S + (size_t)(arow + 16) * stride + kk * KSTEP + kgrp * AW);
             };
-            read_a(kc0, a_cur);
+#pragma unroll
+            for (int d = 0; d < AH; ++d) read_a(min(kc0 + d, ksteps - 1), a_st[d]);
 #pragma unroll
             for (int ks = 0; ks < KSMAX; ++ks) {
                 if (kc0 + ks < ksteps) {                                 // wave-uniform, no global load inside
-                    read_a(min(kc0 + ks + 1, ksteps - 1), a_nxt);
+                    read_a(min(kc0 + ks + AH, ksteps - 1), a_st[AH]);
 #pragma unroll
                     for (int j = 0; j < NTW; ++j) {
                         if constexpr (sizeof(CT) == 2) {
                             const bf16x8_t bq = __builtin_bit_cast(bf16x8_t, wreg[ks][j]);
-                            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq, __builtin_bit_cast(bf16x8_t, a_cur[0]), acc[0][j], 0, 0, 0);
-                            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq, __builtin_bit_cast(bf16x8_t, a_cur[1]), acc[1][j], 0, 0, 0);
+                            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq, __builtin_bit_cast(bf16x8_t, a_st[0][0]), acc[0][j], 0, 0, 0);
+                            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq, __builtin_bit_cast(bf16x8_t, a_st[0][1]), acc[1][j], 0, 0, 0);
                         } else {
                             const f32x4_t bq = __builtin_bit_cast(f32x4_t, wreg[ks][j]);
-                            const f32x4_t a0 = __builtin_bit_cast(f32x4_t, a_cur[0]), a1 = __builtin_bit_cast(f32x4_t, a_cur[1]);
+                            const f32x4_t a0 = __builtin_bit_cast(f32x4_t, a_st[0][0]), a1 = __builtin_bit_cast(f32x4_t, a_st[0][1]);
 #pragma unroll
                             for (int s = 0; s < 4; ++s) {
                                 acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[s], a0[s], acc[0][j], 0, 0, 0);
@@ -458,7 +463,8 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
                             }
                         }
                     }
-                    a_cur[0] = a_nxt[0]; a_cur[1] = a_nxt[1];
+#pragma unroll
+                    for (int d = 0; d < AH; ++d) { a_st[d][0] = a_st[d + 1][0]; a_st[d][1] = a_st[d + 1][1]; }
                 }
             }
         }

@@ -100,10 +100,13 @@ __device__ __forceinline__ void wave_exclusive_scan3(int* a, int* b, int* c, int
 constexpr int PW_SHIFT = 12, PW_MASK = (1 << PW_SHIFT) - 1, PRUNE_MAX_T = PW_MASK - 3;
 __device__ __forceinline__ int pw_par(int w) { return (w & PW_MASK) - 2; }
 
-// Sentences of up to PRUNE_WAVE0_T tokens: wave 0 runs the pruning phases alone, separated by wave_lds_fence() (gcnpt_common.h) -- two
-// tokens per lane and no workgroup barrier.  Longer ones (ALLW): every phase is a loop over the tokens by ALL 1024 threads with a
+// Sentences of up to PRUNE_WAVE0_T tokens: wave 0 runs the pruning phases alone, separated by wave_lds_fence() (gcnpt_common.h): no
+// workgroup barrier.  Longer ones (ALLW): every phase is a loop over the tokens by ALL 1024 threads with a
 // workgroup barrier behind it, so a 300-token sentence is one round per phase instead of five (round 2: 30 us at T = 300).
-constexpr int PRUNE_WAVE0_T = 128;
+#ifndef GCNPT_PRUNE_WAVE0_T
+#define GCNPT_PRUNE_WAVE0_T 64       // measured (tools/ab_libs.sh): T = 100 takes 8.4 us with wave 0 alone, 7.3 us with all waves; T = 50: 4.1 against 5.4
+#endif
+constexpr int PRUNE_WAVE0_T = GCNPT_PRUNE_WAVE0_T;
 
 // Phases: lengths, LCA, path, distances, kept tokens, degrees, row offsets, compacted edge rows.
 // s_red: [0] pad slots, [1] subject tokens, [2] entity tokens, [3] lca (workgroup-wide sums / minimum of the ALLW form)

@@ -560,6 +560,9 @@ def secondary_shapes(args, dev, seed, steps=150):
     shard = {"workload": "B=16 T=300 600->300->300 prune_k=2 bf16: one rank's share of configs[4] split 8 ways",
              "layers_only": run_one(a3), "with_prune": run_one(a3, with_prune=True), "with_cached_trees": run_one(a3, with_prune="cached")}
     shard["prune_us"] = (shard["with_prune"]["ms_per_step"] - shard["layers_only"]["ms_per_step"]) * 1e3
+    a5 = copy.copy(a3)
+    a5.lengths = "tacred"                                            # configs[4] as it says: "packed variable-length batches"
+    shard["packed_tacred_lengths"] = run_one(a5, packed=True)
     out["per_gpu_shard_of_8"] = shard
     a4 = copy.copy(args)
     a4.batch, a4.lengths, a4.dtype = 1024, "full", "bf16"

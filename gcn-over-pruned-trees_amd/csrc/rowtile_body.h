@@ -66,6 +66,7 @@ struct RowTileParams {
     float next_scale;           //      leaves as that layer's dZ = dh * 1[input > 0] * next_scale / (deg + 1) instead of dh
     unsigned long long* stamps;   // diagnostic builds only
     int knob;
+    int col_split, tiles_pp;    // column-split form only (colsplit_body.h): workgroups per row tile, column tiles each of them produces
 };
 
 // DZIN (bwd only): `src` already holds dZ (the layer above wrote it, see relu_src), so the row loader is the forward's plain
@@ -698,12 +699,21 @@ static inline bool use_four_waves(const RowTileParams& p) {
     return pass4 <= pass8;
 }
 
+// the column-split form for small batches of wide layers (colsplit_body.h): GCNPT_OK / an error when it took the launch, GCNPT_NOT_TAKEN when it does not apply
+constexpr int GCNPT_NOT_TAKEN = 1;
+template <typename CT, typename IT, typename OT, bool BWD, int VEC, bool DZIN>
+static inline int try_colsplit(hipStream_t s, const RowTileParams& p);
+
 // output tiles per wave: the smallest of {2,3,4} that covers NOUT in one pass (8 waves x NTW x 16 columns),
 // with as many K-steps of weight fragments resident in registers as ~128 VGPRs allow.  Rows that cannot be
 // read 16 bytes at a time (width not a multiple of 8, unaligned base) take the element-load instantiation.
 template <typename CT, typename IT, typename OT, bool BWD, int VEC, bool DZIN>
 static inline int launch_rowtile_vec(hipStream_t s, const RowTileParams& p) {
     const int n_tiles = ceil_div(p.NOUT, 16);
+    {
+        const int rc = try_colsplit<CT, IT, OT, BWD, VEC, DZIN>(s, p);
+        if (rc != GCNPT_NOT_TAKEN) return rc;
+    }
     if (use_four_waves(p)) {                                  // 4 waves cover 8 / 12 / 16 column tiles per pass
         if (n_tiles <= 4 * 2) return launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 2, 12, DZIN, 4>(s, p);
         if (n_tiles <= 4 * 3) return launch_rowtile_cfg<CT, IT, OT, BWD, VEC, 3, 7, DZIN, 4>(s, p);

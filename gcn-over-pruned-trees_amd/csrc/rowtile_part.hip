@@ -1,6 +1,6 @@
 // One (precision combination, direction) slice of the row-tile kernel's instantiations: compiled 15 times with -DGCNPT_RT_PART=0..14
 // (combo = part / 3, mode = part % 3; see rowtile_body.h) so that the build is parallel.
-#include "rowtile_body.h"
+#include "colsplit_body.h"
 
 namespace gcnpt {
 

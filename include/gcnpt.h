@@ -74,11 +74,16 @@ const char* gcnpt_last_error(void);
  *       gives (model/gcn.py:270-271), at the price of the split contraction's parallelism
  *   GCNPT_OPT_FOUR_WAVES    (env GCNPT_WAVES4, default -1 = by batch size)  0 / 1 forces the 8- / 4-wave form of the layer kernel
  *   GCNPT_OPT_SIDE_TILES    (env GCNPT_SIDE_TILES, default 192)  batches of up to this many 32-row tiles carry the weight gradient of
- *       layer l+1 as a passenger of layer l's backward-data launch (gcnpt_layers_bwd) */
+ *       layer l+1 as a passenger of layer l's backward-data launch (gcnpt_layers_bwd)
+ *   GCNPT_OPT_COL_SPLIT     (env GCNPT_COL_SPLIT, default -1 = by shape)  the column-split form of the layer kernel (bf16 MFMA operands): every
+ *       32-row tile is given to 2 ... 8 workgroups that gather the same rows and each produce a share of the output columns, so that a
+ *       small batch of a wide layer spreads the layer's weight fragments over the CUs that have no tile.  By itself: <= 128 row tiles and
+ *       >= 170 KB of weight fragments.  0: never;  n >= 1: always, with at least n workgroups per tile (tests).  Same values bit for bit */
 #define GCNPT_OPT_DETERMINISTIC 0
 #define GCNPT_OPT_FOUR_WAVES 1
 #define GCNPT_OPT_SIDE_TILES 2
-#define GCNPT_OPT_COUNT 3
+#define GCNPT_OPT_COL_SPLIT 3
+#define GCNPT_OPT_COUNT 4
 int gcnpt_set_option(int option, int value);
 int gcnpt_get_option(int option);
 

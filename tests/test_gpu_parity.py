@@ -1901,6 +1901,56 @@ def test_deterministic_weight_gradients(api, dev):
 
 
 # ---------------------------------------------------------------------------------------------------
+# the column-split form for small batches of wide layers (csrc/colsplit_body.h) against the one-tile-per-workgroup form
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dims", [(360, 200, 200), (600, 300, 300), (200, 360, 96), (304, 520, 72), (64, 40, 640)],
+                         ids=["c2_widths", "c5_widths", "23_tiles", "33_tiles", "wide_out"])
+@pytest.mark.parametrize("x_dtype", [torch.bfloat16, torch.float32], ids=["x_bf16", "x_fp32"])
+@pytest.mark.parametrize("split", [1, 3, 8], ids=["fewest", "3_per_tile", "8_per_tile"])
+@pytest.mark.parametrize("layout", ["padded", "packed"])
+def test_column_split_form_matches_one_shot(api, dev, dims, x_dtype, split, layout):
+    """gcnpt_set_option(GCNPT_OPT_COL_SPLIT, n) forces the column-split form of the layer kernel (every 32-row tile on >= n workgroups that
+    gather the same rows and each produce a share of the output columns; a wave past the workgroup's share of column tiles requests no
+    weights and skips the matrix phase; the fragment images dealt over the workgroups of a tile) on 44 row tiles whose count is not a multiple of 8.  Same gather
+    order, k order and epilogue as the one-shot form: outputs of all layers, the input gradient and (the dZ hand-over included) every
+    fragment image are bit-identical; the weight gradients differ by the order of their float atomics only.  (Without the option the
+    form takes the small wide-layer batches of the other tests by itself.)"""
+    from gcn_over_pruned_trees_amd.utils import synthetic
+    from gcn_over_pruned_trees_amd import _lib
+    gcn, tree = api
+    B, T, K = 23, 61, 2
+    tb = synthetic.random_tree_batch(31, B, T, "tacred")
+    trees = _prune(tree, tb, K, dev)
+    Wn, bn = synthetic.layer_params(32, list(dims))
+    xn, gyn = synthetic.normal(33, (B, T, dims[0])), synthetic.normal(34, (B, T, dims[-1]))
+    x0, g0 = _t(xn, dev).to(x_dtype), _t(gyn, dev)
+    if layout == "packed":
+        keep = ~_t(tb["masks"], dev)
+        trees = trees.pack(tb["lens"].tolist())
+        x0, g0 = x0[keep].contiguous(), g0[keep].contiguous()
+    res = []
+    old = _lib.lib().gcnpt_get_option(_lib.OPT_COL_SPLIT)
+    try:
+        for cs in (0, split):
+            _lib.set_option(_lib.OPT_COL_SPLIT, cs)
+            x = x0.clone().requires_grad_()
+            Ws = [_t(w, dev).requires_grad_() for w in Wn]
+            bs = [_t(b, dev).requires_grad_() for b in bn]
+            h, acts = gcn.gcn_layers_with_acts(x, Ws, bs, trees, drop_p=[0.3, 0.0], seeds=[5, 0], compute_dtype=torch.bfloat16)
+            h.backward(g0)
+            torch.cuda.synchronize()
+            res.append((h.detach(), x.grad, [w.grad for w in Ws], [b.grad for b in bs], acts))
+    finally:
+        _lib.set_option(_lib.OPT_COL_SPLIT, old)
+    a, b = res
+    assert float(a[0].abs().max()) > 0 and float(a[1].abs().max()) > 0
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert all(torch.equal(u, v) for u, v in zip(a[4], b[4]))
+    for l in range(2):
+        assert max_rel(b[2][l].cpu().numpy(), a[2][l].cpu().numpy()) <= 1e-5 and max_rel(b[3][l].cpu().numpy(), a[3][l].cpu().numpy()) <= 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------
 # 4-wave workgroups (big batches: two or three workgroups per CU) against the 8-wave form
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dims", [(72, 100), (200, 180), (360, 250), (600, 300), (200, 360), (300, 600)],

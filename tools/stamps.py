@@ -49,7 +49,7 @@ def report(name, s):
 def main():
     args = bench.parse()
     dev = torch.device("cuda:0")
-    stack = bench.Stack(args, dev, seed=1234)
+    stack = bench.Stack(args, dev, seed=1234, packed=args.layout == "packed")
     L = stack.L
     L.gcnpt_debug_set_stamps.argtypes = [ctypes.c_void_p]
     L.gcnpt_debug_set_stamps.restype = None
@@ -64,15 +64,16 @@ def main():
         stack.step_native()
     torch.cuda.synchronize()
     # the tree build (slots: 0 entry, 1 parse staged, 2 entity chains, 3 LCA, 4 distances, 5 degrees + scans, 6 row info, 8 -> 7 rows emitted)
-    for _ in range(3):
+    if args.layout != "packed":                     # (the token-packed layout's trees come from pack_trees, not from the tree build)
+        for _ in range(3):
+            stack.prune()
+        torch.cuda.synchronize()
+        buf.zero_()
+        L.gcnpt_debug_set_stamps(buf.data_ptr())
         stack.prune()
-    torch.cuda.synchronize()
-    buf.zero_()
-    L.gcnpt_debug_set_stamps(buf.data_ptr())
-    stack.prune()
-    torch.cuda.synchronize()
-    L.gcnpt_debug_set_stamps(None)
-    report("prune", buf.cpu().numpy().reshape(-1, 16).astype(np.int64))
+        torch.cuda.synchronize()
+        L.gcnpt_debug_set_stamps(None)
+        report("prune", buf.cpu().numpy().reshape(-1, 16).astype(np.int64))
     if os.environ.get("GCNPT_STAMPS_PRUNE_ONLY"):
         return
     for k in range(2, len(names) + 1):              # (the pack kernel has no stamps)

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_colsplit_kernel(const R
                 for (int j = 0; j < 8; ++j) acc[j] += v[j];
             }
         }
-        // rows with more than NBU entries: further round trips (not prefetched)
+        // rows with more than NBU entries: further round trips
         auto round = [&](int e0, int lim, auto from_lds) {
             raw8<IT> nb[NBU], nby[NBU];
             float ninv[NBU];
@@ -270,12 +270,12 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_colsplit_kernel(const R
 #pragma unroll
         for (int u = 0; u < PI; ++u) copy_item(m, r0, u * RTT + tid, R.self[u], R.selfy[u]);
         if (wave * WAVE < n_g) g_finish(m, r0, n_g, tid, R.g);
-        for (int base = RTT; base < n_g; base += RTT) {              // more than 512 (aggregating row, chunk) items: not prefetched
+        for (int base = RTT; base < n_g; base += RTT) {              // more than 512 (aggregating row, chunk) items: further rounds
             GItem g;
             g_issue(m, r0, n_g, base + tid, g);
             g_finish(m, r0, n_g, base + tid, g);
         }
-        for (int first = PI * RTT; first < n_items; first += RTT) {   // K wider than PI covers: not prefetched
+        for (int first = PI * RTT; first < n_items; first += RTT) {   // K wider than PI covers: further batches
             raw8<IT> s, sy;
             issue_self(r0, first, s, sy);
             copy_item(m, r0, first + tid, s, sy);

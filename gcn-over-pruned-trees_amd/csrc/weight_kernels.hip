@@ -125,11 +125,18 @@ static int wg_blocks(int n_layers, const int* Din, const int* H, int nt) {
 }
 
 static int launch_weight_grad(hipStream_t s, const WeightGradMulti& mp, int compute_dtype, int waves, int nt) {
+    // a wave issues KB k-steps of loads per batch whether they are live or not (no load behind a condition): a few dozen row tiles leave
+    // a wave one or two k-steps, and the other three of a 5-deep batch would be 21 dead wave-loads of address processing each
+    int per_wave = 0;
+    for (int l = 0; l < mp.n; ++l) per_wave = std::max(per_wave, ceil_div(mp.l[l].ks_per_wg, waves));
+    const bool shallow = per_wave <= 2;
     if (compute_dtype == GCNPT_BF16) {
         if (nt == 6) return launch_weight_grad_cfg<bf16_t, 4, 6, 3>(s, mp);
+        if (shallow) return waves == 8 ? launch_weight_grad_cfg<bf16_t, 8, WG_NT, 2>(s, mp) : launch_weight_grad_cfg<bf16_t, 4, WG_NT, 2>(s, mp);
         return waves == 8 ? launch_weight_grad_cfg<bf16_t, 8, WG_NT, WG_KB>(s, mp) : launch_weight_grad_cfg<bf16_t, 4, WG_NT, WG_KB>(s, mp);
     }
     if (nt == 6) return launch_weight_grad_cfg<float, 4, 6, 2>(s, mp);
+    if (shallow) return waves == 8 ? launch_weight_grad_cfg<float, 8, WG_NT, 2>(s, mp) : launch_weight_grad_cfg<float, 4, WG_NT, 2>(s, mp);
     return waves == 8 ? launch_weight_grad_cfg<float, 8, WG_NT, WG_KB>(s, mp) : launch_weight_grad_cfg<float, 4, WG_NT, WG_KB>(s, mp);
 }
 

@@ -29,7 +29,7 @@ def fro(a, b):
 
 
 def bf16_case(rng, dev):
-    """bf16 storage: the 4-wave and the 8-wave form must agree bit for bit (forward, input gradient), with dropout on, padded and
+    """bf16 storage: the 4-wave, the 8-wave and the column-split form must agree bit for bit (forward, input gradient), with dropout on, padded and
     token-packed; and stay within bf16 distance of the fp32 result."""
     B, T, K, L = int(rng.randint(1, 24)), int(rng.randint(4, 90)), int(rng.randint(0, 3)), int(rng.randint(1, 4))
     dims = [int(rng.choice([8, 16, 40, 72, 104, 200, 300, 360])) for _ in range(L + 1)]
@@ -46,16 +46,20 @@ def bf16_case(rng, dev):
         x0, g0 = x0[keep].contiguous(), g0[keep].contiguous()
     drop = [0.3] * (L - 1) + [0.0]
     outs = {}
-    for mode in ("0", "1", "fp32"):
-        _lib.set_option(_lib.OPT_FOUR_WAVES, 0 if mode == "fp32" else int(mode))
+    split = int(rng.randint(1, 9))
+    for mode in ("0", "1", "cs", "fp32"):
+        _lib.set_option(_lib.OPT_FOUR_WAVES, -1 if mode == "cs" else (0 if mode == "fp32" else int(mode)))
+        _lib.set_option(_lib.OPT_COL_SPLIT, split if mode == "cs" else 0)       # the column-split form, forced with a random split
         x = (x0.float() if mode == "fp32" else x0.clone()).requires_grad_()
         Ws = [t(w).requires_grad_() for w in Wn]
         bs = [t(b).requires_grad_() for b in bn]
         h = gcn.gcn_layers(x, Ws, bs, trees, drop, list(range(11, 11 + L)), torch.float32 if mode == "fp32" else torch.bfloat16, torch.float32)
         h.backward(g0)
         outs[mode] = (h.detach().float(), x.grad.float(), [w.grad for w in Ws])
-    a, b, f = outs["0"], outs["1"], outs["fp32"]
-    ok = torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    _lib.set_option(_lib.OPT_FOUR_WAVES, -1)
+    _lib.set_option(_lib.OPT_COL_SPLIT, -1)
+    a, b, c, f = outs["0"], outs["1"], outs["cs"], outs["fp32"]
+    ok = torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
     e = fro(a[0].cpu().numpy(), f[0].cpu().numpy())
     if not ok or e > 5e-2:
         print("BF16 MISMATCH B=%d T=%d K=%d dims=%s packed=%s equal=%s fro_vs_fp32=%.2e" % (B, T, K, dims, packed, ok, e))

@@ -150,6 +150,8 @@ class Stack(object):
             # token-packed rows (north_star "packed"): sum(len) rows, pattern with absolute columns; the C-ABI then takes B = rows, T = 0
             pk = self.trees.pack(tb["lens"].tolist())
             keep = ~self.masks
+            self.padded_trees, self.lens_dev = self.trees, t(tb["lens"]).to(torch.int32).contiguous()
+            self.pad_B, self.pad_T = B, T
             self.trees, self.x, self.gy = pk, self.x[keep].contiguous(), self.gy[keep].contiguous()
             self.rows = pk.N
         R = self.rows
@@ -186,12 +188,22 @@ class Stack(object):
 
     # ---- tree launches (each only enqueues on the current stream) ----
     def prune(self, pack=False):
-        """pack: the same launch also packs the weights (gcnpt_prune_to_csr_pack: side job on the CUs the tree build leaves idle)."""
-        tr, P, st = self.trees, self._lib.ptr, self._lib.stream()
+        """pack: the same launch also packs the weights (gcnpt_prune_to_csr_pack: side job on the CUs the tree build leaves idle).
+        Token-packed layout: the padded trees are built first, then gcnpt_pack_trees re-lays them out over the packed rows (lengths
+        and row count known: the loader has them, data/loader.py:109-121)."""
+        P, st = self._lib.ptr, self._lib.stream()
+        tr = self.padded_trees if self.packed else self.trees
+        B, T = (self.pad_B, self.pad_T) if self.packed else (self.B, self.T)
         a = (st, P(self.head), P(self.subj), P(self.obj), P(self.deprel), P(self.masks), None,
-             self.B, self.T, self.args.prune_k, tr.cap, P(tr.row_ptr), P(tr.col_idx), None,
+             B, T, self.args.prune_k, tr.cap, P(tr.row_ptr), P(tr.col_idx), None,
              P(tr.rowT_ptr), P(tr.colT_idx), P(tr.ell), P(tr.ellT), P(tr.pool_mask), P(tr.status))
         self._lib.check(self.L.gcnpt_prune_to_csr_pack(*(a + self._native_args(0)[0])) if pack else self.L.gcnpt_prune_to_csr(*a))
+        if self.packed:
+            pk = self.trees
+            self._lib.check(self.L.gcnpt_pack_trees(
+                st, P(tr.row_ptr), P(tr.col_idx), None, P(tr.rowT_ptr), P(tr.colT_idx), P(tr.ell), P(tr.ellT), P(tr.pool_mask),
+                P(self.lens_dev), B, T, tr.cap, P(pk.cu_seqlens), P(pk.row_ptr), P(pk.col_idx), None, P(pk.rowT_ptr), P(pk.colT_idx),
+                P(pk.ell), P(pk.ellT), P(pk.pool_mask), P(pk.row_sent), pk.N, pk.nnz_cap, P(pk.status)))
 
     def gather(self, pack=False):
         """The batch's PrunedTrees from the cached dataset (gcnpt_gather_trees) into the same buffers prune() fills."""
@@ -563,6 +575,7 @@ def secondary_shapes(args, dev, seed, steps=150):
     a5 = copy.copy(a3)
     a5.lengths = "tacred"                                            # configs[4] as it says: "packed variable-length batches"
     shard["packed_tacred_lengths"] = run_one(a5, packed=True)
+    shard["packed_tacred_lengths_with_prune"] = run_one(a5, packed=True, with_prune=True)      # + tree build + gcnpt_pack_trees
     out["per_gpu_shard_of_8"] = shard
     a4 = copy.copy(args)
     a4.batch, a4.lengths, a4.dtype = 1024, "full", "bf16"

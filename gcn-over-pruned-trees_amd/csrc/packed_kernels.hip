@@ -25,32 +25,40 @@ struct PackDst {
     int32_t* status;
 };
 
-// sum over j < n of f(j), every thread of the workgroup gets the result
+// sums over j < n of three per-sentence quantities at once (one round of loads, one pair of barriers); every thread gets the results
 template <typename F>
-__device__ __forceinline__ int block_prefix(int n, F f, int* scratch) {
-    int v = 0;
-    for (int j = threadIdx.x; j < n; j += PK_THREADS) v += f(j);
+__device__ __forceinline__ void block_prefix3(int n, F f, int (*scratch)[3], int (&out)[3]) {
+    int v[3] = {0, 0, 0};
+    for (int j = threadIdx.x; j < n; j += PK_THREADS) {
+        int x[3];
+        f(j, x);
+        v[0] += x[0]; v[1] += x[1]; v[2] += x[2];
+    }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
-    __syncthreads();
-    int s = 0;
+    for (int q = 0; q < 3; ++q)
 #pragma unroll
-    for (int w = 0; w < PK_THREADS / WAVE; ++w) s += scratch[w];
-    return s;
+        for (int d = 32; d >= 1; d >>= 1) v[q] += __shfl_xor(v[q], d);
+    if ((threadIdx.x & 63) == 0) { scratch[threadIdx.x >> 6][0] = v[0]; scratch[threadIdx.x >> 6][1] = v[1]; scratch[threadIdx.x >> 6][2] = v[2]; }
+    __syncthreads();
+    out[0] = out[1] = out[2] = 0;
+#pragma unroll
+    for (int w = 0; w < PK_THREADS / WAVE; ++w) { out[0] += scratch[w][0]; out[1] += scratch[w][1]; out[2] += scratch[w][2]; }
 }
 
 // one workgroup per sentence: its row offset cu[b] and entry offsets are prefix sums over the sentences before it (B is a few
 // hundred at most: every workgroup sums for itself, no second pass), then rows, ELL heads and entries are copied with the
 // columns shifted by cu[b]
 __global__ __launch_bounds__(PK_THREADS) void pack_trees_kernel(const PackSrc src, int B, int T, int cap, const PackDst dst, int n_rows, int nnz_cap) {
-    __shared__ int scratch[PK_THREADS / WAVE];
+    __shared__ int scratch[PK_THREADS / WAVE][3];
     const int b = blockIdx.x, t = threadIdx.x;
     auto nnz_of = [&](const int32_t* rp, int j) { return rp[(size_t)j * (T + 1) + T] - rp[(size_t)j * (T + 1)]; };
-    const int cu = block_prefix(b, [&](int j) { return min(src.len[j], T); }, scratch);
-    const int eo = block_prefix(b, [&](int j) { return nnz_of(src.row_ptr, j); }, scratch);
-    const int eoT = src.rowT_ptr ? block_prefix(b, [&](int j) { return nnz_of(src.rowT_ptr, j); }, scratch) : 0;
+    int pre[3];
+    block_prefix3(b, [&](int j, int (&x)[3]) {
+        x[0] = min(src.len[j], T);
+        x[1] = nnz_of(src.row_ptr, j);
+        x[2] = src.rowT_ptr ? nnz_of(src.rowT_ptr, j) : 0;
+    }, scratch, pre);
+    const int cu = pre[0], eo = pre[1], eoT = pre[2];
     const int len = min(src.len[b], T);
     const int nnz = nnz_of(src.row_ptr, b), nnzT = src.rowT_ptr ? nnz_of(src.rowT_ptr, b) : 0;
     const bool fits = cu + len <= n_rows && eo + nnz <= nnz_cap && eoT + nnzT <= nnz_cap;

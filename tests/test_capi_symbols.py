@@ -61,7 +61,8 @@ def test_argument_validation_needs_no_gpu():
     assert L.gcnpt_layer_bwd_data_wgrad(None, p, p, 0, p, p, p, p, p, 1, 1, 8, 8, p, 0, 0, 1.0, p, p, p, None, 1.0, 1, None, p, 8, 8, p, p) == _lib.E_INVALID
     assert b"two fragment images" in L.gcnpt_last_error()
     # the option table: the library's one piece of process state, no environment access after load
-    assert L.gcnpt_get_option(_lib.OPT_SIDE_TILES) == 192 and L.gcnpt_get_option(_lib.OPT_FOUR_WAVES) == -1
+    assert L.gcnpt_get_option(_lib.OPT_SIDE_TILES) == 192 and L.gcnpt_get_option(_lib.OPT_FOUR_WAVES) == -1 and L.gcnpt_get_option(_lib.OPT_COL_SPLIT) == -1
+    assert L.gcnpt_set_option(_lib.OPT_COL_SPLIT, 9) == _lib.E_INVALID
     assert L.gcnpt_set_option(99, 1) == _lib.E_INVALID and L.gcnpt_set_option(_lib.OPT_DETERMINISTIC, 2) == _lib.E_INVALID
     old = _lib.set_option(_lib.OPT_DETERMINISTIC, 1)
     os.environ["GCNPT_DETERMINISTIC"] = "0"                       # ignored: defaults were read once, at load

@@ -164,8 +164,7 @@ class Stack(object):
         self.wb = [torch.empty((self.L.gcnpt_packed_bytes(d, h, self.compute),), dtype=torch.uint8, device=dev) for h, d in dims]
         # saved operands in MFMA fragment order: S_l = (A+I)h_l written by fwd, dZ_l written by bwd_data
         self.sf = [torch.empty((self.L.gcnpt_frag_bytes(R, d, self.compute),), dtype=torch.uint8, device=dev) for h, d in dims]
-        self.zf = [torch.empty((self.L.gcnpt_wgrad_scratch_bytes(self.rows if packed else B, 0 if packed else T, h, self.compute),), dtype=torch.uint8,
-                               device=dev) for h, d in dims]
+        self.zf = [torch.empty((self.L.gcnpt_frag_bytes(R, h, self.compute),), dtype=torch.uint8, device=dev) for h, d in dims]
         # flat gradient buckets [dW0, db0, dW1, db1] (one; a ring of them in the async exchange mode)
         self.buckets = [torch.zeros((self.n_grad,), dtype=torch.float32, device=dev) for _ in range(N_BUCKETS)]
         # loader-side pre-pruning (N4): a "dataset" of 20 batches pruned once; a step then only gathers its batch's rows
@@ -180,9 +179,6 @@ class Stack(object):
             self.B, self.T = self.rows, 0                   # what the C-ABI takes for packed rows (include/gcnpt.h, gcnpt_pack_trees)
         # small batches: layer 1's weight gradient rides in layer 0's backward-data launch (gcnpt_layer_bwd_data_wgrad)
         self.riders = (self.rows + 31) // 32 <= self.L.gcnpt_get_option(_lib.OPT_SIDE_TILES)
-        # the form the library runs this stack in (include/gcnpt.h, GCNPT_OPT_DATAFLOW): 1 = sentence slices, 0 = row tiles
-        two = lambda a, b: (ctypes.c_int * 2)(a, b)  # noqa: E731
-        self.sent = bool(self.L.gcnpt_layers_form(2, self.B, self.T, two(Din, H), two(H, H), self.act, two(self.act, self.act), self.compute))
 
     def grads(self, k):
         H, Din = self.H, self.Din
@@ -230,7 +226,7 @@ class Stack(object):
             fwd = (n, P(self.x), self.act, A(self.wf), A(self.b), P(tr.row_ptr), P(tr.col_idx), P(tr.ell), None, self.B, self.T, Din, H,
                    A([self.h1, self.h2]), act, self.compute, (ctypes.c_float * n)(self.args.drop, 0.0), (ctypes.c_uint64 * n)(0x5eed, 0),
                    A(self.sf), None)
-            bwd = (n, P(self.gy), P(self.x), A([self.h1, self.h2]), act, A(self.wb), P(tr.ell), P(tr.rowT_ptr), P(tr.colT_idx), P(tr.ellT), self.B, self.T,
+            bwd = (n, P(self.gy), A([self.h1, self.h2]), act, A(self.wb), P(tr.ell), P(tr.rowT_ptr), P(tr.colT_idx), P(tr.ellT), self.B, self.T,
                    Din, H, A([self.dx, self.dh1]), act, self.compute, (ctypes.c_float * n)(self.scale, 1.0), A(self.zf), A(self.sf),
                    A([g[0], g[2]]), A([g[1], g[3]]))
             vp = ctypes.c_void_p
@@ -240,8 +236,6 @@ class Stack(object):
 
     def launch_names(self):
         """The launches of one step, in order (what gcnpt_layers_bwd enqueues follows csrc/rowtile_kernels.hip, layers_bwd_impl)."""
-        if self.sent:
-            return ["pack", "fwd0", "fwd1", "bwd_data1", "bwd_data0", "bwd_weight"]
         if self.riders:
             return ["pack", "fwd0", "fwd1", "bwd_data1", "bwd_data0+wgrad1", "bwd_weight0"]
         return ["pack", "fwd0", "fwd1", "bwd_data1", "bwd_data0", "bwd_weight"]
@@ -294,7 +288,7 @@ class Stack(object):
             self.amax = torch.empty((B, 3, H), dtype=torch.int32, device=self.dev)
             self.dtop = torch.empty_like(self.h2)
         tr = self.trees
-        bwd = (bwd[0], P(self.dtop)) + bwd[2:]              # (n, gy -> dZ of the top layer, x, ...)
+        bwd = (bwd[0], P(self.dtop)) + bwd[2:]
         rc = (L.gcnpt_pack_weights_multi(st, *pack) or L.gcnpt_layers_fwd(st, *fwd)
               or L.gcnpt_pool3_fwd(st, P(self.h2), self.act, P(tr.pool_mask), P(self.subj), P(self.obj), self.B, self.T, self.H, 0, P(self.pooled),
                                    P(self.amax)))
@@ -345,16 +339,6 @@ class Stack(object):
             out["bwd_weight%d" % l] = self.zf[l].numel() + self.sf[l].numel() + 4 * (H * Din + H)
             out["bwd_weight"] = out.get("bwd_weight", 0) + out["bwd_weight%d" % l]
             out["pack"] = out.get("pack", 0) + 4 * H * Din + self.wf[l].numel() + self.wb[l].numel()
-        if self.sent:
-            # sentence slices: no fragment image of (A+I)h; the backward leaves the rows of G (e N H) and per-sentence column sums, the
-            # weight gradient reads G and the layer's input rows
-            for l, (H, Din) in enumerate([tuple(w.shape) for w in self.W]):
-                top, bottom = l == nl - 1, l == 0
-                out["fwd%d" % l] = e * N * (Din + H) + self.wf[l].numel() + 4 * H + csr
-                out["bwd_data%d" % l] = e * N * ((2 if top else 1) * H + (1 if bottom else 2) * Din) + self.wb[l].numel() + 2 * csr + \
-                    e * N * H + 4 * (H * Din + H)
-                out["bwd_weight%d" % l] = e * N * (H + Din) + 4 * (H * Din + H)
-            out["bwd_weight"] = sum(out["bwd_weight%d" % l] for l in range(nl))
         out["bwd_data0+wgrad1"] = out["bwd_data0"] + out["bwd_weight1"]
         out["prune"] = 4 * 8 * N + N + 2 * (csr + 4 * B * (T + 1) + 4 * self.nnz) + N + 4 * (B + 1)
         return out
@@ -826,7 +810,6 @@ def main():
                        "ranks_started_by": ("bench.py itself (--gpus N without a launcher)" if os.environ.get("GCNPT_BENCH_SELF_LAUNCHED")
                                             else "torch.distributed.run / caller") if world > 1 else None,
                        "ms_per_step_by_rank": [round(t, 6) for t in rank_ms], "grad_bucket_abs_sum": grad_abs_sum,
-                       "dataflow": "sentence slices (transform-first)" if stack.sent else "row tiles (gather-first)",
                        "launch": "hipGraph replay" if graphed else "eager launches from 3 native calls per step (gcnpt_pack_weights_multi, gcnpt_layers_fwd, gcnpt_layers_bwd)",
                        "kernels_per_step": ", ".join(names),
                        "launch_trial_us_per_step": {m: round(t * 1e6, 2) for m, t in trial.items()} or None, "nnz_per_batch": stack.nnz,

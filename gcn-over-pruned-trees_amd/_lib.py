@@ -9,8 +9,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GCNPT_LIB") or os.path.join(_HERE, "csrc", "libgcnpt.so")   # GCNPT_LIB: diagnostic builds
 
 F32, BF16 = 0, 1
-ABI_VERSION = 7            # GCNPT_ABI_VERSION of the include/gcnpt.h this binding was written against
-OPT_DETERMINISTIC, OPT_FOUR_WAVES, OPT_SIDE_TILES, OPT_COL_SPLIT, OPT_DATAFLOW, OPT_SENT_SLICES = 0, 1, 2, 3, 4, 5      # gcnpt_set_option keys (include/gcnpt.h)
+ABI_VERSION = 6            # GCNPT_ABI_VERSION of the include/gcnpt.h this binding was written against
+OPT_DETERMINISTIC, OPT_FOUR_WAVES, OPT_SIDE_TILES, OPT_COL_SPLIT = 0, 1, 2, 3      # gcnpt_set_option keys (include/gcnpt.h)
 OK, E_INVALID, E_PRUNE_NEGATIVE, E_NO_SUBJECT, E_NO_LCA, E_CYCLE, E_BAD_HEAD, E_ASSERT, E_CAPACITY, E_HIP, E_UNSUPPORTED, E_LENGTH = \
     0, -1, -2, -3, -4, -5, -6, -7, -8, -9, -10, -11
 
@@ -27,12 +27,10 @@ SIGNATURES = {
     "gcnpt_pack_weights": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "gcnpt_pack_weights_multi": (_i, [_p, _i, _p, _p, _p, _i, _p, _p]),
     "gcnpt_frag_bytes": (_sz, [_i, _i, _i]),
-    "gcnpt_wgrad_scratch_bytes": (_sz, [_i, _i, _i, _i]),
-    "gcnpt_layers_form": (_i, [_i, _i, _i, _p, _p, _i, _p, _i]),
     "gcnpt_layer_fwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _f, _u64, _p, _p]),
     "gcnpt_layer_bwd_data": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _f, _p, _p, _p, _p, _f, _i]),
     "gcnpt_layer_bwd_data_wgrad": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _f, _p, _p, _p, _p, _f, _i] + [_p, _p, _i, _i, _p, _p]),
-    "gcnpt_layers_bwd_range": (_i, [_p, _i] + [_p] * 9 + [_i, _i] + [_p] * 4 + [_i] + [_p] * 5 + [_i, _i, _i]),
+    "gcnpt_layers_bwd_range": (_i, [_p, _i] + [_p] * 8 + [_i, _i] + [_p] * 4 + [_i] + [_p] * 5 + [_i, _i, _i]),
     "gcnpt_set_option": (_i, [_i, _i]),
     "gcnpt_get_option": (_i, [_i]),
     "gcnpt_last_launch": (_i, [_p, _p, _p, _p]),
@@ -41,7 +39,7 @@ SIGNATURES = {
     "gcnpt_layer_bwd_weight": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _i]),
     "gcnpt_layer_bwd_weight_multi": (_i, [_p, _i, _p, _p, _i, _i, _p, _p, _p, _p, _i]),
     "gcnpt_layers_fwd": (_i, [_p, _i, _p, _i] + [_p] * 6 + [_i, _i] + [_p] * 4 + [_i] + [_p] * 4),
-    "gcnpt_layers_bwd": (_i, [_p, _i] + [_p] * 9 + [_i, _i] + [_p] * 4 + [_i] + [_p] * 5),
+    "gcnpt_layers_bwd": (_i, [_p, _i] + [_p] * 8 + [_i, _i] + [_p] * 4 + [_i] + [_p] * 5),
     "gcnpt_pack_trees": (_i, [_p] * 10 + [_i, _i, _i] + [_p] * 10 + [_i, _i, _p]),
     "gcnpt_pack_rows": (_i, [_p, _p, _i, _p, _i, _i, _i, _p]),
     "gcnpt_unpack_rows": (_i, [_p, _p, _i, _p, _i, _i, _i, _p]),
@@ -50,7 +48,7 @@ SIGNATURES = {
     "gcnpt_pool3_fwd": (_i, [_p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "gcnpt_pool3_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i]),
     "gcnpt_pool3_bwd_dz": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _f, _p, _i]),
-    "gcnpt_layers_bwd_dz": (_i, [_p, _i] + [_p] * 9 + [_i, _i] + [_p] * 4 + [_i] + [_p] * 5),
+    "gcnpt_layers_bwd_dz": (_i, [_p, _i] + [_p] * 8 + [_i, _i] + [_p] * 4 + [_i] + [_p] * 5),
     "gcnpt_diag_layer_fwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p, _f, _u64, _p]),
     "gcnpt_diag_layer_bwd": (_i, [_p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _f]),
     "gcnpt_gather_trees": (_i, [_p] * 11 + [_i, _i, _i, _p, _i, _i, _i] + [_p] * 9),

@@ -16,7 +16,6 @@
 //       whole rows in 16-byte stores.
 // The dense [B,T,T] bmm of the reference (gcn.py:269) never exists: aggregation is a gather.
 #include "rowtile_body.h"
-#include "sent_common.h"
 
 // =====================================================================================================
 // C-ABI
@@ -69,20 +68,12 @@ static int dispatch_rowtile(hipStream_t s, const RowTileParams& p, int in_dtype,
 static int layer_fwd_impl(void* stream, const void* h, int h_dtype, const void* w_fwd, const float* bias,
                           const int32_t* row_ptr, const int32_t* col_idx, const int32_t* ell, const int32_t* deg_ell,
                           int B, int T, int Din, int H, void* out, int out_dtype, int compute_dtype, float drop_p,
-                          uint64_t seed, void* s_frag, const uint64_t* seed_dev, int form) {
-    // form: 0 = row tiles, 1 = sentence slices (must be plannable: the caller decided for a whole stack), -1 = whichever fits
+                          uint64_t seed, void* s_frag, const uint64_t* seed_dev) {
     GCNPT_REQUIRE(h && w_fwd && bias && row_ptr && col_idx && ell && out, "layer_fwd: null pointer");
     GCNPT_REQUIRE(B > 0 && T >= 0 && Din > 0 && H > 0, "layer_fwd: sizes must be positive");
     GCNPT_REQUIRE(dtype_ok(h_dtype) && dtype_ok(out_dtype) && dtype_ok(compute_dtype), "layer_fwd: bad dtype");
     GCNPT_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "layer_fwd: drop_p=%f outside [0,1)", (double)drop_p);
     if (rows_of(B, T) > 0x7fffffffLL / 2) return fail(GCNPT_E_UNSUPPORTED, "layer_fwd: B*T too large");
-    if (form != 0) {
-        const int rc = sent_layer_fwd((hipStream_t)stream, h, h_dtype, w_fwd, bias, row_ptr, col_idx, ell, deg_ell, B, T, Din, H, out, out_dtype,
-                                      compute_dtype, drop_p, seed, seed_dev);
-        if (rc != GCNPT_SS_NOT_TAKEN) return rc;
-        if (form == 1) return fail(GCNPT_E_INVALID, "layers_fwd: the stack runs in the sentence-slice form, which needs rows aligned to 16 bytes "
-                                                    "(8 for widths that are not multiples of 8 elements)");
-    }
     RowTileParams p{};
     p.stamps = static_cast<unsigned long long*>(g_debug_stamps); p.knob = g_debug_knob;
     p.src = h; p.yref = nullptr; p.wfrag = w_fwd; p.bias = bias;
@@ -101,9 +92,8 @@ extern "C" int gcnpt_layer_fwd(void* stream, const void* h, int h_dtype, const v
                                const int32_t* row_ptr, const int32_t* col_idx, const int32_t* ell, const int32_t* deg_ell,
                                int B, int T, int Din, int H, void* out, int out_dtype, int compute_dtype, float drop_p,
                                uint64_t seed, void* s_frag, const uint64_t* seed_dev) {
-    // (without a fragment image to leave -- inference -- the sentence-slice form where the shape allows it)
     return layer_fwd_impl(stream, h, h_dtype, w_fwd, bias, row_ptr, col_idx, ell, deg_ell, B, T, Din, H, out, out_dtype, compute_dtype, drop_p, seed,
-                          s_frag, seed_dev, s_frag ? 0 : -1);
+                          s_frag, seed_dev);
 }
 
 // One weight gradient some launch should compute: the two fragment images, the layer's widths, its accumulators
@@ -214,10 +204,9 @@ extern "C" int gcnpt_layers_fwd(void* stream, int n_layers, const void* x, int x
         GCNPT_REQUIRE(Din[l] == H[l - 1], "layers_fwd: layer %d reads %d columns but layer %d writes %d", l, Din[l], l - 1, H[l - 1]);
     const void* h = x;
     int h_dtype = x_dtype;
-    const int form = sent_stack_form(n_layers, B, T, Din, H, x_dtype, out_dtype, compute_dtype) ? 1 : 0;     // gcnpt_layers_bwd* decide the same way
     for (int l = 0; l < n_layers; ++l) {
         const int rc = layer_fwd_impl(stream, h, h_dtype, w_fwd[l], bias[l], row_ptr, col_idx, ell, deg_ell, B, T, Din[l], H[l], out[l],
-                                      out_dtype[l], compute_dtype, drop_p[l], seed[l], s_frag ? s_frag[l] : nullptr, seed_dev, form);
+                                      out_dtype[l], compute_dtype, drop_p[l], seed[l], s_frag ? s_frag[l] : nullptr, seed_dev);
         if (rc != GCNPT_OK) return rc;
         h = out[l];
         h_dtype = out_dtype[l];
@@ -230,62 +219,18 @@ extern "C" int gcnpt_layers_fwd(void* stream, int n_layers, const void* x, int x
 // (<= GCNPT_OPT_SIDE_TILES row tiles): the weight gradient of layer l+1 rides in the backward-data launch of layer l, on the CUs
 // without a row tile (rowtile_wgrad_kernel); what is left for the launch at the end of the sweep is the bottom layer (and any layer
 // whose launch could not carry one).
-// The sweep in the sentence-slice form: one launch per layer, top first (each leaves the layer below its dZ, the rows of G and the
-// column sums of dZ), then every layer's weight gradient from rows in ONE launch
-static int layers_bwd_sent(void* stream, int n_layers, const void* gy, const void* x, const void* const* Y, const int* y_dtype,
-                           const void* const* w_bwd, const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
-                           const int32_t* ellT, int B, int T, const int* Din, const int* H, void* const* dh, const int* dh_dtype,
-                           int compute_dtype, const float* scale, void* const* wg, float* const* dW, float* const* db, bool gy_is_dz,
-                           int first_launch, int n_launches) {
-    GCNPT_REQUIRE(!wg || x, "layers_bwd: the weight gradients of the sentence-slice form need x, layer 0's input rows");
-    const void* g = gy;
-    int launch = 0, groups[LAYERS_MAX] = {};
-    auto wanted = [&](void) { const bool w = launch >= first_launch && launch < first_launch + n_launches; ++launch; return w; };
-    for (int l = n_layers - 1; l >= 0; --l) {
-        if (dh[l] || wg) {
-            const bool hand_down = l > 0, handed = l < n_layers - 1 || gy_is_dz;
-            if (wanted()) {
-                const int rc = sent_layer_bwd((hipStream_t)stream, g, Y[l], y_dtype[l], w_bwd[l], ell, rowT_ptr, colT_idx, ellT, B, T, Din[l], H[l], dh[l],
-                                              dh_dtype[l], compute_dtype, scale[l], wg ? wg[l] : nullptr, wg ? dW[l] : nullptr, wg ? db[l] : nullptr,
-                                              hand_down ? Y[l - 1] : nullptr, hand_down ? scale[l - 1] : 1.0f, handed ? 1 : 0, &groups[l]);
-                if (rc == GCNPT_SS_NOT_TAKEN)
-                    return fail(GCNPT_E_INVALID, "layers_bwd: the stack runs in the sentence-slice form, which needs rows aligned to 16 bytes "
-                                                 "(8 for widths that are not multiples of 8 elements)");
-                if (rc != GCNPT_OK) return rc;
-            }
-        }
-        g = dh[l];
-    }
-    if (!wg || !wanted()) return GCNPT_OK;
-    const void* hrows[LAYERS_MAX];
-    for (int l = 0; l < n_layers; ++l) {
-        hrows[l] = l == 0 ? x : Y[l - 1];
-        if (groups[l] == 0) {                       // (a launch outside the requested range: what its plan would have used)
-            SentParams sp{};
-            SentPlan pl{};
-            plan_sent(sp, pl, B, T, H[l], Din[l], (int)esize(compute_dtype), (int)esize(y_dtype[l]), (int)esize(dh_dtype[l]), false, true, 8, 16);
-            groups[l] = sp.n_groups;
-        }
-    }
-    return sent_wgrads((hipStream_t)stream, n_layers, wg, hrows, dh_dtype, groups, B, T, Din, H, dW, db, compute_dtype);
-}
-
-static int layers_bwd_impl(void* stream, int n_layers, const void* gy, const void* x, const void* const* Y, const int* y_dtype,
+static int layers_bwd_impl(void* stream, int n_layers, const void* gy, const void* const* Y, const int* y_dtype,
                            const void* const* w_bwd, const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
                            const int32_t* ellT, int B, int T, const int* Din, const int* H, void* const* dh,
                            const int* dh_dtype, int compute_dtype, const float* scale, void* const* z_frag,
                            const void* const* s_frag, float* const* dW, float* const* db, bool gy_is_dz, int first_launch, int n_launches) {
     GCNPT_REQUIRE(n_layers >= 1 && n_layers <= LAYERS_MAX, "layers_bwd: 1..%d layers per call", LAYERS_MAX);
     GCNPT_REQUIRE(gy && Y && y_dtype && w_bwd && Din && H && dh && dh_dtype && scale, "layers_bwd: null pointer");
-    GCNPT_REQUIRE(!z_frag || (dW && db), "layers_bwd: weight gradients need z_frag, dW and db");
+    GCNPT_REQUIRE(!z_frag || (s_frag && dW && db), "layers_bwd: weight gradients need z_frag, s_frag, dW and db");
     for (int l = 1; l < n_layers; ++l) {
         GCNPT_REQUIRE(Din[l] == H[l - 1], "layers_bwd: layer %d reads %d columns but layer %d writes %d", l, Din[l], l - 1, H[l - 1]);
         GCNPT_REQUIRE(dh[l] && dh_dtype[l] == y_dtype[l - 1], "layers_bwd: dh[%d] must exist and have the dtype of Y[%d]", l, l - 1);
     }
-    if (sent_stack_form(n_layers, B, T, Din, H, dh_dtype[0], y_dtype, compute_dtype))        // as gcnpt_layers_fwd decided
-        return layers_bwd_sent(stream, n_layers, gy, x, Y, y_dtype, w_bwd, ell, rowT_ptr, colT_idx, ellT, B, T, Din, H, dh, dh_dtype, compute_dtype,
-                               scale, z_frag, dW, db, gy_is_dz, first_launch, n_launches);
-    GCNPT_REQUIRE(!z_frag || s_frag, "layers_bwd: the row-tile form's weight gradients need s_frag");
     const void* g = gy;
     bool wg_done[LAYERS_MAX] = {};
     int launch = 0;
@@ -322,35 +267,35 @@ static int layers_bwd_impl(void* stream, int n_layers, const void* gy, const voi
     return launch_wgrads(stream, rest, n_r, B, T, compute_dtype);
 }
 
-extern "C" int gcnpt_layers_bwd(void* stream, int n_layers, const void* gy, const void* x, const void* const* Y, const int* y_dtype,
+extern "C" int gcnpt_layers_bwd(void* stream, int n_layers, const void* gy, const void* const* Y, const int* y_dtype,
                                 const void* const* w_bwd, const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
                                 const int32_t* ellT, int B, int T, const int* Din, const int* H, void* const* dh,
                                 const int* dh_dtype, int compute_dtype, const float* scale, void* const* z_frag,
                                 const void* const* s_frag, float* const* dW, float* const* db) {
-    return layers_bwd_impl(stream, n_layers, gy, x, Y, y_dtype, w_bwd, ell, rowT_ptr, colT_idx, ellT, B, T, Din, H, dh, dh_dtype, compute_dtype, scale,
+    return layers_bwd_impl(stream, n_layers, gy, Y, y_dtype, w_bwd, ell, rowT_ptr, colT_idx, ellT, B, T, Din, H, dh, dh_dtype, compute_dtype, scale,
                            z_frag, s_frag, dW, db, false, 0, 1 << 30);
 }
 
 // the same sweep when the caller already holds dZ of the TOP layer (gcnpt_pool3_bwd_dz leaves it): the top layer then gathers one
 // row per neighbour like the layers below it, instead of dY, Y and a degree
-extern "C" int gcnpt_layers_bwd_dz(void* stream, int n_layers, const void* dz_top, const void* x, const void* const* Y, const int* y_dtype,
+extern "C" int gcnpt_layers_bwd_dz(void* stream, int n_layers, const void* dz_top, const void* const* Y, const int* y_dtype,
                                    const void* const* w_bwd, const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
                                    const int32_t* ellT, int B, int T, const int* Din, const int* H, void* const* dh,
                                    const int* dh_dtype, int compute_dtype, const float* scale, void* const* z_frag,
                                    const void* const* s_frag, float* const* dW, float* const* db) {
-    return layers_bwd_impl(stream, n_layers, dz_top, x, Y, y_dtype, w_bwd, ell, rowT_ptr, colT_idx, ellT, B, T, Din, H, dh, dh_dtype, compute_dtype,
+    return layers_bwd_impl(stream, n_layers, dz_top, Y, y_dtype, w_bwd, ell, rowT_ptr, colT_idx, ellT, B, T, Din, H, dh, dh_dtype, compute_dtype,
                            scale, z_frag, s_frag, dW, db, true, 0, 1 << 30);
 }
 
 // launches [first_launch, first_launch + n_launches) of the sweep gcnpt_layers_bwd would enqueue (measurement: bench.py charges a launch
 // t(k) - t(k-1) from truncated steps; a partial sweep leaves partial results)
-extern "C" int gcnpt_layers_bwd_range(void* stream, int n_layers, const void* gy, const void* x, const void* const* Y, const int* y_dtype,
+extern "C" int gcnpt_layers_bwd_range(void* stream, int n_layers, const void* gy, const void* const* Y, const int* y_dtype,
                                       const void* const* w_bwd, const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
                                       const int32_t* ellT, int B, int T, const int* Din, const int* H, void* const* dh,
                                       const int* dh_dtype, int compute_dtype, const float* scale, void* const* z_frag,
                                       const void* const* s_frag, float* const* dW, float* const* db, int gy_is_dz, int first_launch,
                                       int n_launches) {
     GCNPT_REQUIRE(first_launch >= 0 && n_launches >= 0, "layers_bwd_range: negative range");
-    return layers_bwd_impl(stream, n_layers, gy, x, Y, y_dtype, w_bwd, ell, rowT_ptr, colT_idx, ellT, B, T, Din, H, dh, dh_dtype, compute_dtype, scale,
+    return layers_bwd_impl(stream, n_layers, gy, Y, y_dtype, w_bwd, ell, rowT_ptr, colT_idx, ellT, B, T, Din, H, dh, dh_dtype, compute_dtype, scale,
                            z_frag, s_frag, dW, db, gy_is_dz != 0, first_launch, n_launches);
 }

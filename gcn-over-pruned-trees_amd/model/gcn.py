@@ -206,11 +206,7 @@ class _GCNLayersFn(torch.autograd.Function):
         need_w = any(p.requires_grad for p in params)
         g_ell = trees.empty_ell() if cfg["no_adj"] else trees.ell
         outs = [torch.empty(lead + (H,), dtype=cfg["out_dtype"] if l == L - 1 else cfg["mid_dtype"], device=dev) for l, (H, _) in enumerate(dims)]
-        # the form the library runs this stack in (include/gcnpt.h): sentence slices write no fragment image of (A+I)h -- their weight
-        # gradient contracts rows -- so nothing is allocated for one
-        sent = bool(lib.gcnpt_layers_form(L, B, T, ints([k for _, k in dims]), ints([h for h, _ in dims]), _lib.dtype_code(x.dtype),
-                                          ints([_lib.dtype_code(o.dtype) for o in outs]), compute))
-        s_frag = [torch.empty((lib.gcnpt_frag_bytes(rows, K, compute),), **u8) if (need_w and not sent) else None for _, K in dims]
+        s_frag = [torch.empty((lib.gcnpt_frag_bytes(rows, K, compute),), **u8) if need_w else None for _, K in dims]
         # every layer's launch from ONE native call (gcnpt_layers_fwd): no interpreter time between the launches
         _lib.check(lib.gcnpt_layers_fwd(
             st, L, _lib.ptr(x), _lib.dtype_code(x.dtype), _lib.ptr_array(wf), _lib.ptr_array(b32), _lib.ptr(trees.row_ptr),
@@ -220,12 +216,12 @@ class _GCNLayersFn(torch.autograd.Function):
         if cfg.get("acts") is not None:
             cfg["acts"].extend(outs)          # every layer's stored output (what the backward reads): tests drive the oracle's backward with them
         ctx.trees, ctx.cfg, ctx.dims, ctx.shape, ctx.need_w = trees, cfg, dims, (B, T, Din, L), need_w
-        ctx.rows, ctx.lead, ctx.sent = rows, lead, sent
+        ctx.rows, ctx.lead = rows, lead
         ctx.x_dtype = x.dtype
         ctx.param_dtypes = [p.dtype for p in params]
         pool = cfg.get("pool")
         if pool is None:
-            ctx.save_for_backward(x, *outs, *wb, *[f for f in s_frag if f is not None])
+            ctx.save_for_backward(*outs, *wb, *[f for f in s_frag if f is not None])
             return outs[-1]
         # the consumer of the stack, fused into the op (gcn.py:114-121): the three masked poolings in one pass over h_L.  Its backward
         # then hands the top layer dZ instead of dh (gcnpt_pool3_bwd_dz), and that layer gathers one row per neighbour, not three
@@ -236,20 +232,18 @@ class _GCNLayersFn(torch.autograd.Function):
         argmax = torch.empty((B, 3, H), dtype=torch.int32, device=dev) if kind == 0 else None
         _lib.check(lib.gcnpt_pool3_fwd(st, _lib.ptr(outs[-1]), _lib.dtype_code(outs[-1].dtype), _lib.ptr(pm), _lib.ptr(sp), _lib.ptr(op), B, T, H, kind,
                                        _lib.ptr(pooled), _lib.ptr(argmax)))
-        ctx.save_for_backward(x, *outs, *wb, *[f for f in s_frag if f is not None])
+        ctx.save_for_backward(*outs, *wb, *[f for f in s_frag if f is not None])
         ctx.pool = (pm, sp, op, argmax, kind)
         return pooled
 
     @staticmethod
     def backward(ctx, gout):
         B, T, Din, L = ctx.shape
-        x, saved = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        saved = ctx.saved_tensors
         outs, wb, s_frag = saved[:L], saved[L:2 * L], saved[2 * L:]
         trees, cfg, dims = ctx.trees, ctx.cfg, ctx.dims
         lib, st, dev, compute = _lib.lib(), _lib.stream(), gout.device, cfg["compute"]
         want_w = ctx.need_w and any(ctx.needs_input_grad[3:])
-        if not ctx.sent and len(s_frag) != L:
-            want_w = False
         g_ellT = trees.empty_ell() if cfg["no_adj"] else trees.ellT
         u8 = dict(dtype=torch.uint8, device=dev)
         z_frag, dWs, dbs = [None] * L, [None] * L, [None] * L
@@ -268,16 +262,16 @@ class _GCNLayersFn(torch.autograd.Function):
         dhs = [torch.empty(ctx.lead + (K,), dtype=in_dtypes[l], device=dev) if (l > 0 or ctx.needs_input_grad[0]) else None
                for l, (_, K) in enumerate(dims)]
         if want_w:
-            z_frag = [torch.empty((lib.gcnpt_wgrad_scratch_bytes(B, T, H, compute),), **u8) for H, _ in dims]     # (either form's scratch)
+            z_frag = [torch.empty((lib.gcnpt_frag_bytes(ctx.rows, H, compute),), **u8) for H, _ in dims]
             dWs = [torch.empty((H, K), dtype=torch.float32, device=dev) for H, K in dims]       # cleared by the sweep's launches
             dbs = [torch.empty((H,), dtype=torch.float32, device=dev) for H, _ in dims]
         ints = lambda v: (ctypes.c_int * L)(*v)  # noqa: E731
         # the backward sweep and all weight gradients from ONE native call (gcnpt_layers_bwd; _bwd_dz: its first tensor already is dZ)
         _lib.check((lib.gcnpt_layers_bwd if pool is None else lib.gcnpt_layers_bwd_dz)(
-            st, L, _lib.ptr(g), _lib.ptr(x), _lib.ptr_array(list(outs)), ints([_lib.dtype_code(o.dtype) for o in outs]), _lib.ptr_array(list(wb)),
+            st, L, _lib.ptr(g), _lib.ptr_array(list(outs)), ints([_lib.dtype_code(o.dtype) for o in outs]), _lib.ptr_array(list(wb)),
             _lib.ptr(trees.ell), _lib.ptr(trees.rowT_ptr), _lib.ptr(trees.colT_idx), _lib.ptr(g_ellT), B, T, ints([k for _, k in dims]),
             ints([h for h, _ in dims]), _lib.ptr_array(dhs), ints([_lib.dtype_code(t) for t in in_dtypes]), compute,
-            (ctypes.c_float * L)(*scales), _lib.ptr_array(z_frag) if want_w else None, _lib.ptr_array(list(s_frag)) if (want_w and not ctx.sent) else None,
+            (ctypes.c_float * L)(*scales), _lib.ptr_array(z_frag) if want_w else None, _lib.ptr_array(list(s_frag)) if want_w else None,
             _lib.ptr_array(dWs) if want_w else None, _lib.ptr_array(dbs) if want_w else None))
         g = dhs[0]
         grads = [None] * (2 * L)

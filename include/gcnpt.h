@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define GCNPT_ABI_VERSION 7
+#define GCNPT_ABI_VERSION 6
 
 /* element types of activation / gradient buffers and of the MFMA operands */
 #define GCNPT_F32 0
@@ -78,20 +78,12 @@ const char* gcnpt_last_error(void);
  *   GCNPT_OPT_COL_SPLIT     (env GCNPT_COL_SPLIT, default -1 = by shape)  the column-split form of the layer kernel (bf16 MFMA operands): every
  *       32-row tile is given to 2 ... 8 workgroups that gather the same rows and each produce a share of the output columns, so that a
  *       small batch of a wide layer spreads the layer's weight fragments over the CUs that have no tile.  By itself: <= 128 row tiles and
- *       >= 170 KB of weight fragments.  0: never;  n >= 1: always, with at least n workgroups per tile (tests).  Same values bit for bit
- *   GCNPT_OPT_DATAFLOW      (env GCNPT_DATAFLOW, default -1 = by shape)  the form gcnpt_layers_fwd / gcnpt_layers_bwd* run a stack in:
- *       1 = sentence slices (transform-first: a workgroup owns whole sentences x a slice of the output columns, P = h W^T on the matrix
- *       cores, the tree aggregation as a gather of P rows from LDS, weight gradient as G^T h from rows) wherever the shape allows it,
- *       0 = row tiles (gather-first 32-row tiles, fragment images for the weight gradient).  Results agree to reassociation (fp32: ~4e-7)
- *   GCNPT_OPT_SENT_SLICES   (env GCNPT_SENT_SLICES, default 0 = planned)  n >= 1: column slices per sentence group in the sentence-slice
- *       form (measurement / tests) */
+ *       >= 170 KB of weight fragments.  0: never;  n >= 1: always, with at least n workgroups per tile (tests).  Same values bit for bit */
 #define GCNPT_OPT_DETERMINISTIC 0
 #define GCNPT_OPT_FOUR_WAVES 1
 #define GCNPT_OPT_SIDE_TILES 2
 #define GCNPT_OPT_COL_SPLIT 3
-#define GCNPT_OPT_DATAFLOW 4
-#define GCNPT_OPT_SENT_SLICES 5
-#define GCNPT_OPT_COUNT 6
+#define GCNPT_OPT_COUNT 4
 int gcnpt_set_option(int option, int value);
 int gcnpt_get_option(int option);
 
@@ -219,23 +211,12 @@ int gcnpt_layer_bwd_weight_multi(void* stream, int n_layers, const void* const* 
  *   the caller: it holds dZ of layer l-1, see the hand-over above); scale[l] = 1/(1-p_l) of the
  *   dropout layer l's forward applied.  z_frag == NULL: no weight gradients (dW, db, s_frag unused); otherwise z_frag[l],
  *   s_frag[l], dW[l], db[l] for every layer; the weight gradient of layer l+1 rides in layer l's backward-data launch (small batches,
- *   see gcnpt_layer_bwd_data_wgrad) and what is left follows in ONE launch (gcnpt_layer_bwd_weight_multi).
- * The two forms of a stack (GCNPT_OPT_DATAFLOW; gcnpt_layers_form tells which one these shapes take -- both calls of a step decide alike):
- *   row tiles        the per-layer launches above; s_frag[l] / z_frag[l] are the fragment images;
- *   sentence slices  (padded layout, sentences of <= 128 tokens, widths that are multiples of 4): a workgroup owns whole sentences x a
- *                    slice of the output columns, P = h W^T on the matrix cores, the tree aggregation as a gather of P rows from LDS; the
- *                    forward writes NO image (s_frag is not touched); z_frag[l] is scratch of gcnpt_wgrad_scratch_bytes(B, T, H[l],
- *                    compute_dtype) bytes in which the backward leaves the rows of G = (A+I)^T dZ and column sums of dZ, and the weight
- *                    gradients dW = G^T h contract them with the layers' own input rows: x [dev] = layer 0's input rows (dtype
- *                    dh_dtype[0]) must then be given (it may be NULL when z_frag is NULL).
- * Allocate z_frag[l] with gcnpt_wgrad_scratch_bytes (>= gcnpt_frag_bytes): it serves either form. */
-size_t gcnpt_wgrad_scratch_bytes(int B, int T, int H, int dtype);
-int gcnpt_layers_form(int n_layers, int B, int T, const int* Din, const int* H, int x_dtype, const int* out_dtype, int compute_dtype);
+ *   see gcnpt_layer_bwd_data_wgrad) and what is left follows in ONE launch (gcnpt_layer_bwd_weight_multi). */
 int gcnpt_layers_fwd(void* stream, int n_layers, const void* x, int x_dtype, const void* const* w_fwd, const float* const* bias,
                      const int32_t* row_ptr, const int32_t* col_idx, const int32_t* ell, const int32_t* deg_ell, int B, int T,
                      const int* Din, const int* H, void* const* out, const int* out_dtype, int compute_dtype,
                      const float* drop_p, const uint64_t* seed, void* const* s_frag, const uint64_t* seed_dev);
-int gcnpt_layers_bwd(void* stream, int n_layers, const void* gy, const void* x, const void* const* Y, const int* y_dtype,
+int gcnpt_layers_bwd(void* stream, int n_layers, const void* gy, const void* const* Y, const int* y_dtype,
                      const void* const* w_bwd, const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
                      const int32_t* ellT, int B, int T, const int* Din, const int* H, void* const* dh, const int* dh_dtype,
                      int compute_dtype, const float* scale, void* const* z_frag, const void* const* s_frag, float* const* dW,
@@ -301,7 +282,7 @@ int gcnpt_pool3_bwd(void* stream, const float* g, const int32_t* argmax, const u
 int gcnpt_pool3_bwd_dz(void* stream, const float* g, const int32_t* argmax, const uint8_t* pool_mask, const int64_t* subj_pos,
                        const int64_t* obj_pos, int B, int T, int H, int type, const void* y, const int32_t* ell, float scale, void* dz,
                        int dtype);
-int gcnpt_layers_bwd_dz(void* stream, int n_layers, const void* dz_top, const void* x, const void* const* Y, const int* y_dtype,
+int gcnpt_layers_bwd_dz(void* stream, int n_layers, const void* dz_top, const void* const* Y, const int* y_dtype,
                         const void* const* w_bwd, const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
                         const int32_t* ellT, int B, int T, const int* Din, const int* H, void* const* dh, const int* dh_dtype,
                         int compute_dtype, const float* scale, void* const* z_frag, const void* const* s_frag, float* const* dW,
@@ -320,7 +301,7 @@ int gcnpt_layer_bwd_data_wgrad(void* stream, const void* dY, const void* Y, int 
                                int up_Din, int up_H, float* up_dW, float* up_db);
 /* Launches [first_launch, first_launch + n_launches) of the sweep gcnpt_layers_bwd (gy_is_dz = 0) / gcnpt_layers_bwd_dz (1) would
  * enqueue, in its order (measurement aid: bench.py times truncated steps to charge each launch its in-step duration). */
-int gcnpt_layers_bwd_range(void* stream, int n_layers, const void* gy, const void* x, const void* const* Y, const int* y_dtype,
+int gcnpt_layers_bwd_range(void* stream, int n_layers, const void* gy, const void* const* Y, const int* y_dtype,
                            const void* const* w_bwd, const int32_t* ell, const int32_t* rowT_ptr, const int32_t* colT_idx,
                            const int32_t* ellT, int B, int T, const int* Din, const int* H, void* const* dh, const int* dh_dtype,
                            int compute_dtype, const float* scale, void* const* z_frag, const void* const* s_frag, float* const* dW,

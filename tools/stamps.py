@@ -93,7 +93,7 @@ def main():
                              L.gcnpt_layer_fwd(st, stack._lib.ptr(stack.h1), stack.act, stack._lib.ptr(stack.wf[1]), stack._lib.ptr(stack.b[1]),
                                                stack._lib.ptr(stack.trees.row_ptr), stack._lib.ptr(stack.trees.col_idx), stack._lib.ptr(stack.trees.ell), None,
                                                stack.B, stack.T, stack.H, stack.H, stack._lib.ptr(stack.h2), stack.act, stack.compute, 0.0, 0,
-                                               None if stack.sent else stack._lib.ptr(stack.sf[1]), None))
+                                               stack._lib.ptr(stack.sf[1]), None))
         else:
             stack._lib.check(L.gcnpt_layers_bwd_range(st, *(bwd + (0, k - 2 - nl, 1))))
         torch.cuda.synchronize()

@@ -8,7 +8,7 @@ One "step" = the hot path over one synthetic TACRED-shaped batch of 50 sentences
 (BASELINE.json configs[1]: 2-layer GCN, no LSTM, Din 360 -> 200 -> 200, prune_k 1, bf16 storage,
 fp32 accumulation, dropout 0.5 between the layers), entirely through the C-ABI of include/gcnpt.h:
     pack W0+W1 -> layer0 fwd -> layer1 fwd -> layer1 bwd-data -> layer0 bwd-data with layer1's weight gradient riding -> layer0 bwd-weight
-(six launches from three native calls: gcnpt_pack_weights_multi, gcnpt_layers_fwd, gcnpt_layers_bwd).
+(six launches from ONE native call, gcnpt_layers_step, whose argument struct is marshalled once).
 Inputs (x, gy, weights, the loader's integer tensors) are resident in HBM before the timed region.
 `value` is the layer stack alone, as the metric says; `with_prune` / `with_cached_trees` repeat the measurement with the
 pruned-tree adjacency build / its assembly from a pre-pruned dataset inside every step.
@@ -39,6 +39,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 SGD_LR = 1e-9                  # N > 1: the device-side update between the all-reduce and the next step's pack
+MAX_GRAD_NORM = 5.0            # train.py:85 --max_grad_norm default
 
 
 def parse():
@@ -71,12 +72,14 @@ def parse():
                     help="threads of the headline cpu_baseline leg (8 = what BASELINE.md timed the reference itself with); an all-cores "
                          "leg and the NumPy port (4 BLAS threads, its measured optimum) are reported beside it")
     ap.add_argument("--launch", choices=["auto", "graph", "native"], default="auto",
-                    help="graph: the step's launches replayed as one hipGraph; native: eager launches from three native calls per step "
-                         "(gcnpt_pack_weights_multi, gcnpt_layers_fwd, gcnpt_layers_bwd), which keeps the queue fed as long as the host is "
-                         "fast enough; auto: both are tried during warm-up and the faster one is timed")
+                    help="graph: the step's launches replayed as one hipGraph; native: eager launches from one native call per step "
+                         "(gcnpt_layers_step), which keeps the queue fed as long as the host is fast enough; auto: both are tried during "
+                         "warm-up and the faster one is timed")
     ap.add_argument("--exchange", choices=["sync", "async"], default="sync",
                     help="N > 1.  sync (the headline): all-reduce, device-side SGD update, and the next step's pack waits for both. "
                          "async: the round-2 ring of buckets whose all-reduce nobody consumes -- an upper bound, not data-parallel SGD")
+    ap.add_argument("--repeats", type=int, default=20, help="N = 1: repeats of the timed K-step region behind the contract's one, for ms_per_step_median")
+    ap.add_argument("--no-clip", action="store_true", help="N > 1, A/B: plain W -= lr*g instead of the reference's clip_grad_norm_ + SGD update")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
     ap.add_argument("--no-floor", action="store_true", help="skip the launch-floor leg (the step's launches with empty bodies)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements on rank 0 (with_prune, with_cached_trees, the fp32 "
@@ -234,6 +237,30 @@ class Stack(object):
             self._nargs[k] = (pack, fwd, bwd)
         return self._nargs[k]
 
+    def step_struct(self, k=0, parts=7):
+        """gcnpt_step_t for gradient bucket k (built once per (k, parts)): the whole step is then ONE native call."""
+        if not hasattr(self, "_steps"):
+            self._steps = {}
+        if (k, parts) not in self._steps:
+            L, tr, g, n = self._lib, self.trees, self.grads(k), len(self.W)
+            st = L.Step()
+            st.n_layers, st.B, st.T, st.compute_dtype, st.parts, st.gy_is_dz = n, self.B, self.T, self.compute, parts, 0
+            outs, dhs = [self.h1, self.h2], [self.dx, self.dh1]
+            for l in range(n):
+                st.W[l], st.bias[l], st.Din[l], st.H[l] = self.W[l].data_ptr(), self.b[l].data_ptr(), self.W[l].shape[1], self.W[l].shape[0]
+                st.w_fwd[l], st.w_bwd[l] = self.wf[l].data_ptr(), self.wb[l].data_ptr()
+                st.out[l], st.out_dtype[l] = outs[l].data_ptr(), self.act
+                st.drop_p[l], st.seed[l] = (self.args.drop, 0x5eed) if l == 0 else (0.0, 0)
+                st.s_frag[l], st.z_frag[l] = self.sf[l].data_ptr(), self.zf[l].data_ptr()
+                st.dh[l], st.dh_dtype[l], st.scale[l] = dhs[l].data_ptr(), self.act, self.scale if l == 0 else 1.0
+                st.dW[l], st.db[l] = g[2 * l].data_ptr(), g[2 * l + 1].data_ptr()
+            P = L.ptr
+            st.row_ptr, st.col_idx, st.ell, st.deg_ell = P(tr.row_ptr), P(tr.col_idx), P(tr.ell), None
+            st.rowT_ptr, st.colT_idx, st.ellT, st.ell_bwd = P(tr.rowT_ptr), P(tr.colT_idx), P(tr.ellT), P(tr.ell)
+            st.x, st.x_dtype, st.gy, st.seed_dev = P(self.x), self.act, P(self.gy), None
+            self._steps[(k, parts)] = (st, ctypes.byref(st))
+        return self._steps[(k, parts)][1]
+
     def launch_names(self):
         """The launches of one step, in order (what gcnpt_layers_bwd enqueues follows csrc/rowtile_kernels.hip, layers_bwd_impl)."""
         if self.riders:
@@ -241,17 +268,16 @@ class Stack(object):
         return ["pack", "fwd0", "fwd1", "bwd_data1", "bwd_data0", "bwd_weight"]
 
     def step_native(self, k=0, with_prune=False):
-        """One step as three native calls (pack, all forward layers, backward sweep + weight gradients): eager launches, no graph.
-        The argument lists are built once: the host has ~45 us per step for five launches and must not spend them marshalling."""
-        pack, fwd, bwd = self._native_args(k)
+        """One step as ONE native call (gcnpt_layers_step: pack, all forward layers, backward sweep + weight gradients): eager launches,
+        no graph.  The argument struct is built once: the host has ~45 us per step for six launches and must not spend them marshalling."""
         st = self._lib.stream()
         merged = bool(with_prune) and not self.args.separate_pack       # the tree launch carries the weight pack
         if with_prune == "cached":
             self.gather(pack=merged)
         elif with_prune:
             self.prune(pack=merged)
-        L = self.L
-        rc = (0 if merged else L.gcnpt_pack_weights_multi(st, *pack)) or L.gcnpt_layers_fwd(st, *fwd) or L.gcnpt_layers_bwd(st, *bwd)
+        # pack + forward sweep + backward sweep from ONE native call (gcnpt_layers_step: the argument struct is built once)
+        rc = self.L.gcnpt_layers_step(st, self.step_struct(k, 6 if merged else 7))
         if rc:
             self._lib.check(rc)
 
@@ -451,14 +477,14 @@ def kernel_breakdown(stack, use_graph, rounds=100, reps=8):
 
 def launch_floor(stack, shapes, steps, use_graph):
     """The step's launches -- same grids, workgroup sizes, LDS and kernel-argument sizes -- with bodies that return at entry
-    (gcnpt_launch_empty_seq, grouped into the same three native calls as the real step).  Two numbers: `device` = per step when 8
+    (gcnpt_launch_empty_seq, one native call per step like the real step).  Two numbers: `device` = per step when 8
     steps' worth of empty launches are replayed as ONE hipGraph (the replay's fixed cost is spread out: what the dispatches cost the
     device back to back), `native` = the same eager loop the timed step runs in (what the host can issue).  What is left of
     ms_per_step after subtracting the device floor is the kernels' own work (one workgroup's dependent chain per launch)."""
     L, lib = stack.L, stack._lib
     n = len(shapes)
     cols = [(ctypes.c_int * n)(*[s[i] for s in shapes]) for i in range(4)]
-    groups = [(0, 1), (1, 1 + len(stack.W)), (1 + len(stack.W), n)]
+    groups = [(0, n)]                               # one native call per step, as gcnpt_layers_step
     calls = [(hi - lo, [ctypes.cast(ctypes.byref(c, 4 * lo), ctypes.POINTER(ctypes.c_int)) for c in cols]) for lo, hi in groups if hi > lo]
 
     def empty_step():
@@ -706,8 +732,14 @@ def main():
         per-step update (train.py:224-227).  async: ring of buckets, asynchronous all-reduce nobody consumes (upper bound)."""
         def run_sync(i):
             replays[0][0]()
-            dist.all_reduce(stack.buckets[0])                       # SUM: supported by every backend; the 1/world goes into the step size
-            stack.wflat.add_(stack.buckets[0], alpha=-SGD_LR / world)
+            g = stack.buckets[0]
+            dist.all_reduce(g)                                       # SUM: supported by every backend; the 1/world goes into the step size
+            if args.no_clip:
+                stack.wflat.add_(g, alpha=-SGD_LR / world)
+            else:
+                # the reference's update: clip_grad_norm_(max_grad_norm = 5) then SGD (train.py:224-227), on the device, no host sync
+                coef = (MAX_GRAD_NORM / (torch.linalg.vector_norm(g) / world + 1e-6)).clamp_(max=1.0)
+                stack.wflat.addcmul_(g, coef, value=-SGD_LR / world)
 
         def run_async(i):
             k = i % N_BUCKETS
@@ -748,6 +780,14 @@ def main():
     stack.wflat.copy_(w0)
     wall, ev = timed(make_run(replays, exchange, reducer), args.steps, args.warmup, barrier)
     drain()
+    # the contract's `value` / `ms_per_step` are that ONE K-step region; beside it the median over repeats of the same region (a
+    # 20-step region is ~1 ms: one sample is at the mercy of whatever else the host does in that millisecond)
+    reps_ms = []
+    if not multi:
+        for _ in range(args.repeats):
+            w_r, _ = timed(make_run(replays, exchange, reducer), args.steps, 0, barrier)
+            reps_ms.append(w_r / args.steps * 1e3)
+        drain()
     rank_ms = [wall / args.steps * 1e3]
     if multi:
         mine = torch.tensor([wall], dtype=torch.float64, device=dev)
@@ -810,14 +850,18 @@ def main():
                        "ranks_started_by": ("bench.py itself (--gpus N without a launcher)" if os.environ.get("GCNPT_BENCH_SELF_LAUNCHED")
                                             else "torch.distributed.run / caller") if world > 1 else None,
                        "ms_per_step_by_rank": [round(t, 6) for t in rank_ms], "grad_bucket_abs_sum": grad_abs_sum,
-                       "launch": "hipGraph replay" if graphed else "eager launches from 3 native calls per step (gcnpt_pack_weights_multi, gcnpt_layers_fwd, gcnpt_layers_bwd)",
+                       "launch": "hipGraph replay" if graphed else "eager launches from 1 native call per step (gcnpt_layers_step)",
                        "kernels_per_step": ", ".join(names),
                        "launch_trial_us_per_step": {m: round(t * 1e6, 2) for m, t in trial.items()} or None, "nnz_per_batch": stack.nnz,
-                       "dp_mode": ("synchronous SGD: step -> all_reduce(SUM) of the flat fp32 bucket (%d B) over %s -> W -= lr*g/world on the device -> "
-                                   "the next step's weight pack reads W" % (4 * stack.n_grad, args.dist_backend)) if (multi and exchange == "sync")
+                       "dp_mode": ("synchronous SGD: step -> all_reduce(SUM) of the flat fp32 bucket (%d B) over %s -> clip to max_grad_norm %g + W -= lr*g/world on the device -> "
+                                   "the next step's weight pack reads W" % (4 * stack.n_grad, args.dist_backend, MAX_GRAD_NORM)) if (multi and exchange == "sync")
                                   else ("ASYNC RING (not synchronous SGD; --exchange async)" if multi else "none (1 GPU)"),
                        "weight_abs_drift_after_timed_steps": weight_drift if multi else None},
             "event_ms_per_step": ev / args.steps * 1e3,
+            "ms_per_step_median": float(np.median(reps_ms)) if reps_ms else None,
+            "ms_per_step_repeats": {"n": len(reps_ms), "min": float(np.min(reps_ms)), "max": float(np.max(reps_ms))} if reps_ms else None,
+            "launch_mode": "hipGraph replay" if graphed else "eager, one native call per step",
+            "launch_trial_us_per_step": {m: round(t * 1e6, 2) for m, t in trial.items()} or None,
         }
         if async_bound is not None:
             result["async_upper_bound"] = async_bound
@@ -942,7 +986,7 @@ def main():
                                           "native_loop_us_per_step": fl["native"] * 1e6,
                                           "note": "the step's %d launches with the same grid / workgroup size / LDS / kernel-argument size and bodies that return "
                                                   "at entry (gcnpt_launch_empty_seq): launch_floor_us = per step when 8 steps of them replay as one hipGraph "
-                                                  "(device-side dispatch cost, back to back); native_loop_us_per_step = the same three native calls per step "
+                                                  "(device-side dispatch cost, back to back); native_loop_us_per_step = the same one native call per step "
                                                   "issued eagerly (host issue rate: with empty kernels the host, not the device, is the limit); "
                                                   "chain_us = ms_per_step - launch_floor_us is what the kernels' own work adds" % len(shapes)}
         if not args.no_secondary_shapes and world == 1 and args.layout == "padded":

@@ -9,13 +9,26 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GCNPT_LIB") or os.path.join(_HERE, "csrc", "libgcnpt.so")   # GCNPT_LIB: diagnostic builds
 
 F32, BF16 = 0, 1
-ABI_VERSION = 6            # GCNPT_ABI_VERSION of the include/gcnpt.h this binding was written against
+ABI_VERSION = 7            # GCNPT_ABI_VERSION of the include/gcnpt.h this binding was written against
 OPT_DETERMINISTIC, OPT_FOUR_WAVES, OPT_SIDE_TILES, OPT_COL_SPLIT = 0, 1, 2, 3      # gcnpt_set_option keys (include/gcnpt.h)
 OK, E_INVALID, E_PRUNE_NEGATIVE, E_NO_SUBJECT, E_NO_LCA, E_CYCLE, E_BAD_HEAD, E_ASSERT, E_CAPACITY, E_HIP, E_UNSUPPORTED, E_LENGTH = \
     0, -1, -2, -3, -4, -5, -6, -7, -8, -9, -10, -11
 
 # every symbol include/gcnpt.h declares: (restype, argtypes)
 _p, _i, _f, _u64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_uint64, ctypes.c_size_t
+
+
+class Step(ctypes.Structure):
+    """gcnpt_step_t of include/gcnpt.h: a whole step's arguments, marshalled once (gcnpt_layers_step)."""
+    _fields_ = [("n_layers", _i), ("B", _i), ("T", _i), ("compute_dtype", _i), ("parts", _i), ("gy_is_dz", _i),
+                ("W", _p * 8), ("bias", _p * 8), ("Din", _i * 8), ("H", _i * 8), ("w_fwd", _p * 8), ("w_bwd", _p * 8),
+                ("row_ptr", _p), ("col_idx", _p), ("ell", _p), ("deg_ell", _p), ("rowT_ptr", _p), ("colT_idx", _p), ("ellT", _p), ("ell_bwd", _p),
+                ("x", _p), ("x_dtype", _i), ("out", _p * 8), ("out_dtype", _i * 8), ("drop_p", _f * 8), ("seed", _u64 * 8), ("seed_dev", _p),
+                ("s_frag", _p * 8),
+                ("gy", _p), ("dh", _p * 8), ("dh_dtype", _i * 8), ("scale", _f * 8), ("z_frag", _p * 8), ("dW", _p * 8), ("db", _p * 8)]
+
+
+STEP_PACK, STEP_FWD, STEP_BWD = 1, 2, 4         # gcnpt_step_t.parts
 SIGNATURES = {
     "gcnpt_abi_version": (_i, []),
     "gcnpt_last_error": (ctypes.c_char_p, []),
@@ -39,6 +52,7 @@ SIGNATURES = {
     "gcnpt_layer_bwd_weight": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _i]),
     "gcnpt_layer_bwd_weight_multi": (_i, [_p, _i, _p, _p, _i, _i, _p, _p, _p, _p, _i]),
     "gcnpt_layers_fwd": (_i, [_p, _i, _p, _i] + [_p] * 6 + [_i, _i] + [_p] * 4 + [_i] + [_p] * 4),
+    "gcnpt_layers_step": (_i, [_p, ctypes.POINTER(Step)]),
     "gcnpt_layers_bwd": (_i, [_p, _i] + [_p] * 8 + [_i, _i] + [_p] * 4 + [_i] + [_p] * 5),
     "gcnpt_pack_trees": (_i, [_p] * 10 + [_i, _i, _i] + [_p] * 10 + [_i, _i, _p]),
     "gcnpt_pack_rows": (_i, [_p, _p, _i, _p, _i, _i, _i, _p]),

@@ -299,3 +299,26 @@ extern "C" int gcnpt_layers_bwd_range(void* stream, int n_layers, const void* gy
     return layers_bwd_impl(stream, n_layers, gy, Y, y_dtype, w_bwd, ell, rowT_ptr, colT_idx, ellT, B, T, Din, H, dh, dh_dtype, compute_dtype, scale,
                            z_frag, s_frag, dW, db, gy_is_dz != 0, first_launch, n_launches);
 }
+
+// pack + forward sweep + backward sweep from one call, arguments marshalled once (include/gcnpt.h, gcnpt_step_t)
+extern "C" int gcnpt_layers_step(void* stream, const gcnpt_step_t* st) {
+    GCNPT_REQUIRE(st, "layers_step: null pointer");
+    const int L = st->n_layers;
+    GCNPT_REQUIRE(L >= 1 && L <= LAYERS_MAX, "layers_step: 1..%d layers per call", LAYERS_MAX);
+    if (st->parts & 1) {
+        const int rc = gcnpt_pack_weights_multi(stream, L, st->W, st->H, st->Din, st->compute_dtype, st->w_fwd, st->w_bwd);
+        if (rc != GCNPT_OK) return rc;
+    }
+    if (st->parts & 2) {
+        const int rc = gcnpt_layers_fwd(stream, L, st->x, st->x_dtype, st->w_fwd, st->bias, st->row_ptr, st->col_idx, st->ell, st->deg_ell, st->B, st->T,
+                                        st->Din, st->H, st->out, st->out_dtype, st->compute_dtype, st->drop_p, st->seed, st->s_frag, st->seed_dev);
+        if (rc != GCNPT_OK) return rc;
+    }
+    if (st->parts & 4) {
+        const bool wg = st->z_frag[0] != nullptr;
+        return layers_bwd_impl(stream, L, st->gy, st->out, st->out_dtype, st->w_bwd, st->ell_bwd ? st->ell_bwd : st->ell, st->rowT_ptr, st->colT_idx, st->ellT,
+                               st->B, st->T, st->Din, st->H, st->dh, st->dh_dtype, st->compute_dtype, st->scale, wg ? st->z_frag : nullptr,
+                               wg ? st->s_frag : nullptr, wg ? st->dW : nullptr, wg ? st->db : nullptr, st->gy_is_dz != 0, 0, 1 << 30);
+    }
+    return GCNPT_OK;
+}

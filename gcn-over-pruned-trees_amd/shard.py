@@ -226,19 +226,66 @@ class SparseRowExchange(object):
         return dense
 
 
-def sync_sgd_step(dist, bucket, lr, sparse=(), weight=None):
-    """One synchronous data-parallel SGD update, the reference's per-step optimizer.step() (train.py:224-227; plain SGD is its default,
-    train.py:82): all-reduce the flat bucket (FlatGradBucket; weight = this rank's share of the global batch, default 1/world), exchange
-    the row-sparse gradients [(param, idx, g, SparseRowExchange)], then p -= lr * grad on every rank.  After it every rank holds the
-    same weights a single process would hold after the same step on the concatenated batch."""
-    bucket.all_reduce(dist, weight=weight)
-    w = weight if weight is not None else 1.0 / dist.get_world_size()
+def sync_sgd_step(dist, bucket, lr, sparse=(), weight=None, max_grad_norm=None, accumulate=1, state=None):
+    """One micro-batch of synchronous data-parallel SGD with the reference's update rule (train.py:209, 224-227; plain SGD is its
+    default, train.py:82): gradients of `accumulate` micro-batches are SUMMED (update_gap = int(50 / batch_size); the reference does not
+    divide), the global L2 norm of the summed gradient -- every parameter, the embedding table included -- is clipped to `max_grad_norm`
+    exactly as torch.nn.utils.clip_grad_norm_ does (coefficient max_norm / (norm + 1e-6), capped at 1), then p -= lr * grad.
+
+    bucket: FlatGradBucket holding this micro-batch's gradients of the dense parameters; weight = this rank's share of the micro-batch
+    (shard size / global size; default 1 / world).  sparse: [(param, idx, g, SparseRowExchange)] row-sparse gradients (the embedding
+    table: g = gradient of param[idx]).  state: a dict the caller keeps across calls (needed when accumulate > 1: it holds the running
+    sums).  Returns True when this call applied the update (every `accumulate`-th call); the bucket is cleared for the next
+    micro-batch either way.  One all-reduce of the flat bucket and one exchange per sparse parameter per UPDATE, not per micro-batch.
+    After an update every rank holds the weights a single process would hold after the same micro-batches on the concatenated
+    batches (tests/test_shard_gloo.py).  torch.nn.utils.clip_grad_norm_ itself cannot be used on a model whose embedding gradient is a
+    sparse tensor (linalg_vector_norm has no sparse kernel), which is one more reason the clip lives here."""
+    world = dist.get_world_size()
+    w = weight if weight is not None else 1.0 / world
+    if accumulate > 1 and state is None:
+        raise ValueError("sync_sgd_step(accumulate > 1) needs a `state` dict kept across calls")
+    state = state if state is not None else {}
+    for p, v in zip(bucket.params, bucket.views):               # (as FlatGradBucket.all_reduce: fold detached gradients back in)
+        g = p.grad
+        if g is None:
+            v.zero_()
+        elif g.data_ptr() != v.data_ptr():
+            v.copy_(g)
+        p.grad = v
     with torch.no_grad():
-        for p, v in zip(bucket.params, bucket.views):
-            p.add_(v, alpha=-lr)
-        for p, idx, g, ex in sparse:
-            ids, rows = ex.exchange(idx, g, weight=w)
-            p.index_add_(0, ids, rows.to(p.dtype), alpha=-lr)
+        acc = state.get("flat")
+        if acc is None:
+            acc = state["flat"] = torch.zeros_like(bucket.flat)
+        acc.add_(bucket.flat, alpha=w)
+        rows_acc = state.setdefault("rows", [[] for _ in sparse])
+        for j, (p, idx, g, ex) in enumerate(sparse):
+            rows_acc[j].append((idx.reshape(-1), g.reshape(idx.numel(), -1) * w))
+        state["n"] = state.get("n", 0) + 1
+        bucket.zero()
+        if state["n"] < accumulate:
+            return False
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        exchanged = []
+        for j, (p, idx, g, ex) in enumerate(sparse):
+            ids, rows = ex.exchange(torch.cat([a for a, _ in rows_acc[j]]), torch.cat([b for _, b in rows_acc[j]]))
+            exchanged.append((p, ids, rows))
+        coef = None
+        if max_grad_norm is not None:
+            sq = acc.double().pow(2).sum()
+            for _, _, rows in exchanged:
+                sq = sq + rows.double().pow(2).sum()
+            coef = (float(max_grad_norm) / (sq.sqrt() + 1e-6)).clamp(max=1.0).to(acc.dtype)     # clip_grad_norm_'s coefficient, no host sync
+        flat = acc if coef is None else acc * coef
+        o = 0
+        for p in bucket.params:
+            p.add_(flat[o:o + p.numel()].view_as(p), alpha=-lr)
+            o += p.numel()
+        for p, ids, rows in exchanged:
+            p.index_add_(0, ids, (rows if coef is None else rows * coef).to(p.dtype), alpha=-lr)
+        acc.zero_()
+        state["rows"] = [[] for _ in sparse]
+        state["n"] = 0
+    return True
 
 
 def all_gather_pooled(dist, pooled, sizes=None):

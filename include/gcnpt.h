@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define GCNPT_ABI_VERSION 6
+#define GCNPT_ABI_VERSION 7
 
 /* element types of activation / gradient buffers and of the MFMA operands */
 #define GCNPT_F32 0
@@ -221,6 +221,32 @@ int gcnpt_layers_bwd(void* stream, int n_layers, const void* gy, const void* con
                      const int32_t* ellT, int B, int T, const int* Din, const int* H, void* const* dh, const int* dh_dtype,
                      int compute_dtype, const float* scale, void* const* z_frag, const void* const* s_frag, float* const* dW,
                      float* const* db);
+
+/* ---- a whole step of the stack from ONE host call ----------------------------------------------------------------------------------
+ * gcnpt_pack_weights_multi + gcnpt_layers_fwd + gcnpt_layers_bwd (or _bwd_dz) enqueue a step's launches from three calls whose ~50
+ * arguments a binding has to marshal every time; on a slow host that is what decides whether the device queue stays fed (bench.py:
+ * launch_floor).  gcnpt_layers_step takes the same arguments ONCE, in a struct the caller fills at set-up and keeps: the per-step cost
+ * is one call and one pointer.  Fields have exactly the meaning of the arguments of the three entry points above (arrays: entry l =
+ * layer l, n_layers <= 8).  parts: bit 0 = pack the weights, bit 1 = forward sweep, bit 2 = backward sweep + weight gradients; the
+ * parts run in that order.  gy_is_dz != 0: `gy` already is dZ of the top layer (gcnpt_layers_bwd_dz).  z_frag[0] == NULL: no weight
+ * gradients.  The struct is read during the call only. */
+typedef struct gcnpt_step {
+    int n_layers, B, T, compute_dtype, parts, gy_is_dz;
+    /* weights (gcnpt_pack_weights_multi) */
+    const float* W[8]; const float* bias[8]; int Din[8], H[8];
+    void* w_fwd[8]; void* w_bwd[8];
+    /* pattern (gcnpt_prune_to_csr / gcnpt_pack_trees) */
+    const int32_t* row_ptr; const int32_t* col_idx; const int32_t* ell; const int32_t* deg_ell;
+    const int32_t* rowT_ptr; const int32_t* colT_idx; const int32_t* ellT; const int32_t* ell_bwd;   /* ell_bwd: the degrees' ELL head the backward uses (= the forward pattern's) */
+    /* forward (gcnpt_layers_fwd) */
+    const void* x; int x_dtype;
+    void* out[8]; int out_dtype[8]; float drop_p[8]; uint64_t seed[8]; const uint64_t* seed_dev;
+    void* s_frag[8];
+    /* backward (gcnpt_layers_bwd): gradients of the layers' inputs, scales 1/(1-p), saved-operand images, accumulators */
+    const void* gy; void* dh[8]; int dh_dtype[8]; float scale[8];
+    void* z_frag[8]; float* dW[8]; float* db[8];
+} gcnpt_step_t;
+int gcnpt_layers_step(void* stream, const gcnpt_step_t* step);
 
 /* ---- token-packed variable-length batches (north_star "packed") ----------------------------------------
  * The reference pads every batch to its longest sentence (data/loader.py:109-121, model/gcn.py:96-97,106): B*T token rows of

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(handle, n), "libgcnpt.so does not export %s" % n
     assert sorted(_lib.SIGNATURES) == names                      # the ctypes binding covers the header, nothing else
-    assert _lib.lib().gcnpt_abi_version() == _lib.ABI_VERSION == 6
+    assert _lib.lib().gcnpt_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_argument_validation_needs_no_gpu():
@@ -57,6 +57,12 @@ def test_argument_validation_needs_no_gpu():
     assert b"dh[1] must exist" in L.gcnpt_last_error()
     assert L.gcnpt_layers_bwd(None, 2, p, ptrs, two(0, 0), ptrs, p, p, p, p, 1, 1, two(8, 8), two(8, 8), ptrs, two(0, 0), 0, f2, ptrs, None, None, None) == _lib.E_INVALID
     assert b"weight gradients need" in L.gcnpt_last_error()
+    # the whole step from one call: the struct is validated like the three calls it stands for
+    st = _lib.Step()
+    st.n_layers, st.B, st.T, st.parts = 9, 1, 1, 7
+    assert L.gcnpt_layers_step(None, ctypes.byref(st)) == _lib.E_INVALID and L.gcnpt_layers_step(None, None) == _lib.E_INVALID
+    st.n_layers = 2
+    assert L.gcnpt_layers_step(None, ctypes.byref(st)) == _lib.E_INVALID and b"pack_weights" in L.gcnpt_last_error()
     # the backward-data call that carries the layer above's weight gradient needs that gradient's images and accumulators
     assert L.gcnpt_layer_bwd_data_wgrad(None, p, p, 0, p, p, p, p, p, 1, 1, 8, 8, p, 0, 0, 1.0, p, p, p, None, 1.0, 1, None, p, 8, 8, p, p) == _lib.E_INVALID
     assert b"two fragment images" in L.gcnpt_last_error()

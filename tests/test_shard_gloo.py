@@ -159,6 +159,52 @@ def _sync_sgd(rank, world, unequal):
     assert ex.last_volume_bytes < 40 * 6 * 4 * world                           # less than a dense exchange of even this tiny table
 
 
+def _sync_sgd_clipped(rank, world, unequal, accumulate):
+    """VERDICT r3 item 5 / ADVICE r3: the reference's update is clip_grad_norm_(max_grad_norm) then SGD every update_gap micro-batches
+    (train.py:209,224-227).  N-rank weights after 3 CLIPPED updates (the bound is far below the gradient norm, so the clip is active
+    every time) of `accumulate` micro-batches each == one process calling clip_grad_norm_ on the dense gradients of the concatenated
+    micro-batches."""
+    words, y = _emb_data()
+    idx = [torch.arange(0, 8), torch.arange(8, 12)] if unequal else [torch.arange(0, 6), torch.arange(6, 12)]
+    lr, topn, max_norm = 0.05, 30, 0.3
+    m, ref = _EmbModel(), _EmbModel()
+    bucket = shard.FlatGradBucket(m.parameters(), exclude=[m.emb.weight])
+    ex = shard.SparseRowExchange(dist, topn=topn, padding_idx=0)
+    share = len(idx[rank]) / 12.0
+    state, clipped = {}, 0
+    bucket.zero()
+    for step in range(3 * accumulate):
+        perm = torch.roll(torch.arange(12), step)                                # a different micro-batch every call
+        wb, yb = words[perm], y[perm]
+        w = wb[idx[rank]]
+        e = m.emb(w).detach().requires_grad_(True)
+        ((m(w, emb_out=e) - yb[idx[rank]]) ** 2).sum(1).mean().backward()
+        done = shard.sync_sgd_step(dist, bucket, lr, sparse=[(m.emb.weight, w, e.grad, ex)], weight=share, max_grad_norm=max_norm,
+                                   accumulate=accumulate, state=state)
+        assert done == ((step + 1) % accumulate == 0)
+        ((ref(wb) - yb) ** 2).sum(1).mean().backward()                            # gradients accumulate in ref's .grad
+        if done:
+            with torch.no_grad():
+                ref.emb.weight.grad[topn:].zero_()
+            total = torch.nn.utils.clip_grad_norm_(ref.parameters(), max_norm)
+            clipped += int(float(total) > max_norm)
+            with torch.no_grad():
+                for p in ref.parameters():
+                    p.add_(p.grad, alpha=-lr)
+            ref.zero_grad()
+    assert clipped == 3                                                           # the clip was active at every update
+    for (n, p), q in zip(m.named_parameters(), ref.parameters()):
+        assert torch.allclose(p, q, atol=2e-6), (rank, n, (p - q).abs().max())
+
+
+def test_sync_sgd_clipped_equals_clip_grad_norm_equal_shards():
+    _spawn(_sync_sgd_clipped, 2, False, 1)
+
+
+def test_sync_sgd_clipped_and_accumulated_unequal_shards():
+    _spawn(_sync_sgd_clipped, 2, True, 2)
+
+
 def test_sync_sgd_equals_single_process_equal_shards():
     _spawn(_sync_sgd, 2, False)
 

@@ -80,6 +80,8 @@ def parse():
                          "async: the round-2 ring of buckets whose all-reduce nobody consumes -- an upper bound, not data-parallel SGD")
     ap.add_argument("--repeats", type=int, default=20, help="N = 1: repeats of the timed K-step region behind the contract's one, for ms_per_step_median")
     ap.add_argument("--no-clip", action="store_true", help="N > 1, A/B: plain W -= lr*g instead of the reference's clip_grad_norm_ + SGD update")
+    ap.add_argument("--two-step-pack", action="store_true", help="A/B, packed layout with the tree build: gcnpt_prune_to_csr + gcnpt_pack_trees "
+                                                                   "instead of the pruner writing the packed layout itself")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
     ap.add_argument("--no-floor", action="store_true", help="skip the launch-floor leg (the step's launches with empty bodies)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements on rank 0 (with_prune, with_cached_trees, the fp32 "
@@ -192,11 +194,21 @@ class Stack(object):
     # ---- tree launches (each only enqueues on the current stream) ----
     def prune(self, pack=False):
         """pack: the same launch also packs the weights (gcnpt_prune_to_csr_pack: side job on the CUs the tree build leaves idle).
-        Token-packed layout: the padded trees are built first, then gcnpt_pack_trees re-lays them out over the packed rows (lengths
-        and row count known: the loader has them, data/loader.py:109-121)."""
+        Token-packed layout: the pruner writes the packed arrays itself (gcnpt_prune_to_csr_packed: one launch; lengths and row count
+        known: the loader has them, data/loader.py:109-121); --two-step-pack keeps round 3's gcnpt_prune_to_csr + gcnpt_pack_trees."""
         P, st = self._lib.ptr, self._lib.stream()
         tr = self.padded_trees if self.packed else self.trees
         B, T = (self.pad_B, self.pad_T) if self.packed else (self.B, self.T)
+        if self.packed and not self.args.two_step_pack:
+            pk = self.trees
+            if not hasattr(self, "_sync_ws"):
+                self._sync_ws = torch.zeros((B + 2,), dtype=torch.int64, device=self.dev)
+            tail = self._native_args(0)[0] if pack else (0, None, None, None, 0, None, None)
+            self._lib.check(self.L.gcnpt_prune_to_csr_packed(
+                st, P(self.head), P(self.subj), P(self.obj), P(self.deprel), P(self.masks), None, B, T, self.args.prune_k, P(pk.cu_seqlens),
+                P(pk.row_ptr), P(pk.col_idx), None, P(pk.rowT_ptr), P(pk.colT_idx), P(pk.ell), P(pk.ellT), P(pk.pool_mask), P(pk.row_sent), pk.N,
+                pk.nnz_cap, P(pk.status), P(tr.status), P(tr.pool_mask), P(self._sync_ws), *tail))
+            return
         a = (st, P(self.head), P(self.subj), P(self.obj), P(self.deprel), P(self.masks), None,
              B, T, self.args.prune_k, tr.cap, P(tr.row_ptr), P(tr.col_idx), None,
              P(tr.rowT_ptr), P(tr.colT_idx), P(tr.ell), P(tr.ellT), P(tr.pool_mask), P(tr.status))

@@ -519,47 +519,22 @@ static inline int launch_colsplit_cfg(hipStream_t s, RowTileParams p, int col_sp
     return GCNPT_OK;
 }
 
-// The column-split form's configurations: (column tiles per wave, resident k-steps, chunks of own rows per thread), each sized to stay
-// inside 256 registers without spilling.  A layer takes the one that holds all its k-steps and its own rows with the fewest registers;
-// the backward from dY and Y (three loads per gathered row) only takes the two smallest.
-//   A (2,12,3) K <= 384      B (2,7,2) K <= 224      C (3,7,2) K <= 224, wide output      D (1,20,5) K <= 640: the C5 input layer
-//   E (2,10,3) K <= 320: the C5 hidden layers      F (1,10,3): their backward from dY
-// By itself (GCNPT_OPT_COL_SPLIT = -1) the form is taken for at most 128 row tiles (so that 2 ... 8 workgroups per tile fit the 256 CUs)
-// of a layer with at least 170 KB of weight fragments; measured: 71 -> 62 us per step for the per-GPU shard of
-// BASELINE configs[4] (16 packed sentences, 600 -> 300 -> 300), nothing at the C2 widths (156 KB), where it also costs the backward launch its
-// passenger.  n >= 1 forces it with at least n workgroups per tile whatever the batch (tests).
+// the dispatcher: colsplit_plan (rowtile_body.h) says whether and how; GCNPT_NOT_TAKEN leaves the launch to the one-shot form
 template <typename CT, typename IT, typename OT, bool BWD, int VEC, bool DZIN>
 static inline int try_colsplit(hipStream_t s, const RowTileParams& p) {
     if constexpr (sizeof(CT) != 2 || VEC == 0) {
         return GCNPT_NOT_TAKEN;
     } else {
         constexpr bool MASKED = BWD && !DZIN;
-        const int forced = option(GCNPT_OPT_COL_SPLIT);
-        const int n_rt8 = ceil_div(ceil_div(p.N, ROWS), 8);
-        const int ksteps = p.Kpad / 32, n_ctiles = ceil_div(p.NOUT, 16), chunks_pt = ceil_div(ROWS * (p.Kpad / 8), RT_THREADS);
-        const int c_max = forced > 0 ? 8 : std::min(8, 32 / n_rt8);
-        if (forced == 0 || !p.out) return GCNPT_NOT_TAKEN;
-        if (forced < 0 && (c_max < 2 || option(GCNPT_OPT_FOUR_WAVES) >= 0 || (size_t)ksteps * n_ctiles * 1024 < (size_t)170 * 1024)) return GCNPT_NOT_TAKEN;
-        struct Cfg { int ntw, ks, pi; bool masked_ok; };
-        static const Cfg cfgs[6] = {{2, 12, 3, false}, {2, 7, 2, true}, {3, 7, 2, false}, {1, 20, 5, false}, {2, 10, 3, false}, {1, 10, 3, true}};
-        int best = -1, best_c = 0, best_regs = 1 << 30;
-        for (int i = 0; i < 6; ++i) {
-            if (ksteps > cfgs[i].ks || chunks_pt > cfgs[i].pi || (MASKED && !cfgs[i].masked_ok)) continue;
-            const int c_min = ceil_div(n_ctiles, RT_WAVES * cfgs[i].ntw);       // the fewest workgroups per row tile this configuration allows
-            const int want = forced > 0 ? forced : std::min(c_max, ceil_div(n_ctiles, 2));      // as many as there are idle CUs for
-            const int c = std::max(c_min, std::min(want, n_ctiles)), regs = cfgs[i].ntw * cfgs[i].ks + cfgs[i].pi;
-            if (c > c_max && c > c_min) continue;
-            if (forced < 0 && c > c_max) continue;
-            if (regs < best_regs) { best = i; best_c = c; best_regs = regs; }
-        }
-        if (best < 0 || (forced < 0 && best_c < 2)) return GCNPT_NOT_TAKEN;
-        switch (best) {
-            case 0: if constexpr (!MASKED) return launch_colsplit_cfg<CT, IT, OT, BWD, VEC, 2, 12, DZIN, 3>(s, p, best_c); break;
-            case 1: return launch_colsplit_cfg<CT, IT, OT, BWD, VEC, 2, 7, DZIN, 2>(s, p, best_c);
-            case 2: if constexpr (!MASKED) return launch_colsplit_cfg<CT, IT, OT, BWD, VEC, 3, 7, DZIN, 2>(s, p, best_c); break;
-            case 3: if constexpr (!MASKED) return launch_colsplit_cfg<CT, IT, OT, BWD, VEC, 1, 20, DZIN, 5>(s, p, best_c); break;
-            case 4: if constexpr (!MASKED) return launch_colsplit_cfg<CT, IT, OT, BWD, VEC, 2, 10, DZIN, 3>(s, p, best_c); break;
-            default: return launch_colsplit_cfg<CT, IT, OT, BWD, VEC, 1, 10, DZIN, 3>(s, p, best_c);
+        int c = 0;
+        switch (colsplit_plan(p.N, p.Kpad, p.NOUT, (int)sizeof(CT), VEC, MASKED, p.out != nullptr, &c)) {
+            case 0: if constexpr (!MASKED) return launch_colsplit_cfg<CT, IT, OT, BWD, VEC, 2, 12, DZIN, 3>(s, p, c); break;
+            case 1: return launch_colsplit_cfg<CT, IT, OT, BWD, VEC, 2, 7, DZIN, 2>(s, p, c);
+            case 2: if constexpr (!MASKED) return launch_colsplit_cfg<CT, IT, OT, BWD, VEC, 3, 7, DZIN, 2>(s, p, c); break;
+            case 3: if constexpr (!MASKED) return launch_colsplit_cfg<CT, IT, OT, BWD, VEC, 1, 20, DZIN, 5>(s, p, c); break;
+            case 4: if constexpr (!MASKED) return launch_colsplit_cfg<CT, IT, OT, BWD, VEC, 2, 10, DZIN, 3>(s, p, c); break;
+            case 5: return launch_colsplit_cfg<CT, IT, OT, BWD, VEC, 1, 10, DZIN, 3>(s, p, c);
+            default: break;
         }
         return GCNPT_NOT_TAKEN;
     }

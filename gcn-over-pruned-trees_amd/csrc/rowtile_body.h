@@ -641,6 +641,45 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_wgrad_kernel(const RowT
 
 namespace gcnpt {
 
+// Whether a layer launch takes the column-split form (colsplit_body.h), and with which configuration and split: ONE host function for
+// the dispatcher (try_colsplit) and for the backward sweep's prediction of which launch carries a weight gradient (a column-split
+// launch never does).  Configurations (column tiles per wave, resident k-steps, chunks of own rows per thread), each sized to stay
+// inside 256 registers without spilling; a layer takes the one that holds all its k-steps and its own rows with the fewest registers;
+// the backward from dY and Y (three loads per gathered row) only takes the two smallest:
+//   0 (2,12,3) K <= 384      1 (2,7,2) K <= 224      2 (3,7,2) K <= 224, wide output      3 (1,20,5) K <= 640: the C5 input layer
+//   4 (2,10,3) K <= 320: the C5 hidden layers      5 (1,10,3): their backward from dY
+// By itself (GCNPT_OPT_COL_SPLIT = -1) the form is taken for at most 128 row tiles (so that 2 ... 8 workgroups per tile fit the 256 CUs)
+// of a layer with at least 170 KB of weight fragments; measured (EXPERIMENTS.md): 71 -> 62 us per step for the per-GPU shard of
+// BASELINE configs[4] (16 packed sentences, 600 -> 300 -> 300), nothing at the C2 widths (156 KB), where it also costs the backward launch its
+// passenger.  n >= 1 forces it with at least n workgroups per tile whatever the batch (tests).
+struct ColSplitCfg { int ntw, ks, pi; bool masked_ok; };
+constexpr ColSplitCfg COLSPLIT_CFGS[6] = {{2, 12, 3, false}, {2, 7, 2, true}, {3, 7, 2, false}, {1, 20, 5, false}, {2, 10, 3, false}, {1, 10, 3, true}};
+// ct_size: bytes of the MFMA operand type; vec: elements per row load (8 / 4 / 0); masked: backward deriving dZ from dY and Y.
+// Returns the configuration index (>= 0) and sets *split, or -1: the launch takes the one-shot form.
+inline int colsplit_plan(int N, int Kpad, int NOUT, int ct_size, int vec, bool masked, bool have_out, int* split) {
+    if (ct_size != 2 || vec == 0) return -1;
+    const int forced = option(GCNPT_OPT_COL_SPLIT);
+    const int n_rt8 = ceil_div(ceil_div(N, ROWS), 8);
+    const int ksteps = Kpad / 32, n_ctiles = ceil_div(NOUT, 16), chunks_pt = ceil_div(ROWS * (Kpad / 8), RT_THREADS);
+    const int c_max = forced > 0 ? 8 : std::min(8, 32 / n_rt8);
+    if (forced == 0 || !have_out) return -1;
+    if (forced < 0 && (c_max < 2 || option(GCNPT_OPT_FOUR_WAVES) >= 0 || (size_t)ksteps * n_ctiles * 1024 < (size_t)170 * 1024)) return -1;
+    int best = -1, best_c = 0, best_regs = 1 << 30;
+    for (int i = 0; i < 6; ++i) {
+        const ColSplitCfg& g = COLSPLIT_CFGS[i];
+        if (ksteps > g.ks || chunks_pt > g.pi || (masked && !g.masked_ok)) continue;
+        const int c_min = ceil_div(n_ctiles, RT_WAVES * g.ntw);           // the fewest workgroups per row tile this configuration allows
+        const int want = forced > 0 ? forced : std::min(c_max, ceil_div(n_ctiles, 2));      // as many as there are idle CUs for
+        const int c = std::max(c_min, std::min(want, n_ctiles)), regs = g.ntw * g.ks + g.pi;
+        if (c > c_max && c > c_min) continue;
+        if (forced < 0 && c > c_max) continue;
+        if (regs < best_regs) { best = i; best_c = c; best_regs = regs; }
+    }
+    if (best < 0 || (forced < 0 && best_c < 2)) return -1;
+    *split = best_c;
+    return best;
+}
+
 // Weight gradients the next backward-data launch should carry (layers_bwd_impl sets it around that one call; thread-local because it
 // is only an argument that skips four levels of dispatch templates, not state: it never outlives the call that set it)
 struct SideWgrad { const SideWgrads* sw = nullptr; bool carried = false; };

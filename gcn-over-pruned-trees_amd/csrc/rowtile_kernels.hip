@@ -147,6 +147,19 @@ static bool plan_side_wgrad(SideWgrads& sw, const WgradReq& r, int B, int T, int
     return sw.blocks > 0;
 }
 
+// Whether the backward-data launch of a layer carries `ride` (the layer above's weight gradient): what launch_rowtile_cfg / try_colsplit
+// decide when the launch is issued, as ONE predicate for the sweep's bookkeeping of launches it does not issue (gcnpt_layers_bwd_range):
+// the 8-wave one-shot form on ready-made dZ rows in uniform precision carries it, the 4-wave and the column-split forms never do.
+static bool would_carry(const void* g, const void* Y, int g_dtype, const void* dh, int dh_dtype, int compute_dtype, bool handed, int B, int T,
+                        int H, int Din, const WgradReq& ride) {
+    if (!handed || g_dtype != dh_dtype || esize(g_dtype) != esize(compute_dtype) || option(GCNPT_OPT_FOUR_WAVES) == 1) return false;
+    const int N = (int)rows_of(B, T), Kpad = round_up(H, kstep_of(compute_dtype));
+    int split = 0;
+    if (colsplit_plan(N, Kpad, Din, (int)esize(compute_dtype), vec_elems(H, esize(g_dtype), g, Y), false, dh != nullptr, &split) >= 0) return false;
+    SideWgrads sw;
+    return plan_side_wgrad(sw, ride, B, T, compute_dtype);
+}
+
 extern "C" int gcnpt_layer_bwd_weight_multi(void* stream, int n_layers, const void* const* z_frag, const void* const* s_frag,
                                             int B, int T, const int* Din, const int* H, float* const* dW, float* const* db,
                                             int compute_dtype);
@@ -249,9 +262,7 @@ static int layers_bwd_impl(void* stream, int n_layers, const void* gy, const voi
                                                    handed ? 1 : 0, offer ? &ride : nullptr, false, &carried);
                 if (rc != GCNPT_OK) return rc;
             } else if (offer) {                                      // (a launch outside the requested range: would it have carried?)
-                SideWgrads sw;
-                carried = handed && y_dtype[l] == dh_dtype[l] && esize(y_dtype[l]) == esize(compute_dtype) && option(GCNPT_OPT_FOUR_WAVES) != 1 &&
-                          plan_side_wgrad(sw, ride, B, T, compute_dtype);
+                carried = would_carry(g, handed ? nullptr : Y[l], y_dtype[l], dh[l], dh_dtype[l], compute_dtype, handed, B, T, H[l], Din[l], ride);
             }
             if (carried) wg_done[l + 1] = true;                      // what no launch carried goes into the launch at the end of the sweep
         }

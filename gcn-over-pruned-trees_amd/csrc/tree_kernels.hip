@@ -26,6 +26,23 @@ enum : int {
 enum : int { K_KEEP = 1, K_CHILD = 2 };
 enum : int { ERR_CHAIN_BADHEAD = 1, ERR_CHAIN_CYCLE = 2, ERR_BADHEAD = 4, ERR_CYCLE = 8, ERR_ASSERT = 16 };
 
+// Token-packed output of the pruner (gcnpt_prune_to_csr_packed; layout of gcnpt_pack_trees in include/gcnpt.h): row cu[b] + i, columns
+// shifted by cu[b], entry offsets contiguous over the batch.  A sentence's offsets are prefix sums of (len, nnz, nnzT) over the sentences
+// before it, which other workgroups of the SAME launch compute: every workgroup publishes its three counts in ONE 8-byte word (valid bit |
+// len << 40 | nnz << 20 | nnzT, an agent-scope atomic store: the word is its own flag, nothing to order), then sums the words of the
+// sentences before it (agent-scope atomic loads, spinning on the valid bit).  Sentences are taken in TICKET order (an atomic counter), not
+// in blockIdx order, so a workgroup only ever waits for workgroups that already run: no assumption about dispatch order.  The last
+// workgroup to finish polling clears the words and both counters: the workspace is all-zero between launches (graph replay included).
+struct PackedOut {
+    int32_t* cu;                 // NULL = the padded layout (everything below unused)
+    int32_t* row_sent;
+    uint8_t* pool_mask_padded;   // NULL or [B*T]: the mask in the padded layout as well (what GCN.forward returns, gcn.py:262,395)
+    unsigned long long* sync;    // [B + 2], zero between launches: the sentences' words, ticket counter, done counter
+    int32_t* pk_status;          // [2]: 0 / GCNPT_E_CAPACITY, sum(len)
+    int n_rows, nnz_cap;
+};
+constexpr unsigned long long PK_VALID = 1ull << 63;
+
 // exclusive scan of a[0..n) in place, a[n] = total; `scratch` holds blockDim.x ints (any block size)
 __device__ void block_exclusive_scan(int* a, int n, int* scratch) {
     const int t = threadIdx.x, nt = blockDim.x;
@@ -117,7 +134,7 @@ __device__ void prune_sentence(const int64_t* __restrict__ head, const int64_t* 
                                int prune_k, int cap, int* smem, int* s_err, int* s_status, int* s_nrows, int* s_red,
                                int32_t* __restrict__ row_ptr, int32_t* __restrict__ rowT_ptr, int32_t* __restrict__ ell,
                                int32_t* __restrict__ ellT, uint8_t* __restrict__ pool_mask, int32_t* __restrict__ status,
-                               unsigned long long* stamps) {
+                               unsigned long long* stamps, const PackedOut& po, int* s_out) {
     int* pw = smem;                // [T]   parent + flags (see above)
     int* cnt = pw + T;             // [T]   #entity chains through the token; later K_KEEP/K_CHILD bits
     int* deg = cnt + T;            // [T+1] row degree -> row offsets
@@ -279,7 +296,8 @@ __device__ void prune_sentence(const int64_t* __restrict__ head, const int64_t* 
             const int he = (i < len && (pw[i] & (F_HASEDGE << PW_SHIFT))) ? 1 : 0;
             deg[i] += he; degT[i] += he;                             // the 84 on the diagonal
             rank[i] = he;
-            if (pool_mask) pool_mask[base + i] = (deg[i] + degT[i]) == 0;   // gcn.py:262
+            if (po.cu) { if (po.pool_mask_padded) po.pool_mask_padded[base + i] = (deg[i] + degT[i]) == 0; }
+            else if (pool_mask) pool_mask[base + i] = (deg[i] + degT[i]) == 0;   // gcn.py:262
         }
         phase_sync();
         if (!ALLW || threadIdx.x < WAVE) {                           // the three scans: one wave (lane l owns a contiguous segment)
@@ -293,16 +311,83 @@ __device__ void prune_sentence(const int64_t* __restrict__ head, const int64_t* 
     }
     GCNPT_STAMP(stamps, 5);
 
-    if (err) {   // the sentence contributes no edges; every row is empty and masked
-        for (int i = t0; i <= T; i += NT) {
-            row_ptr[(size_t)b * (T + 1) + i] = b * cap;
-            if (rowT_ptr) rowT_ptr[(size_t)b * (T + 1) + i] = b * cap;
+    // ---- where this sentence's rows and entries go.  Padded layout: slots of its own (rows b*T.., entries b*cap..).  Packed: behind
+    //      the sentences before it (see PackedOut)
+    size_t rbase = base;                    // first row
+    int ebase = b * cap, eTbase = b * cap;   // first entry of the two patterns
+    int cshift = 0, nrw = T;                // added to every column; rows this sentence writes
+    bool fits = true;
+    if (po.cu) {
+        const int my_nnz = err ? 0 : deg[T], my_nnzT = err ? 0 : degT[T];
+        if (threadIdx.x == 0)
+            __hip_atomic_store(po.sync + b, PK_VALID | ((unsigned long long)len << 40) | ((unsigned long long)my_nnz << 20) | (unsigned long long)my_nnzT,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int a0 = 0, a1 = 0, a2 = 0;
+        for (int j = t0; j < b; j += NT) {
+            unsigned long long v = __hip_atomic_load(po.sync + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (!(v & PK_VALID)) {
+                __builtin_amdgcn_s_sleep(2);
+                v = __hip_atomic_load(po.sync + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            a0 += (int)((v >> 40) & 0xffff); a1 += (int)((v >> 20) & 0xfffff); a2 += (int)(v & 0xfffff);
         }
-        for (int i = t0; i < T; i += NT)
-            if (pool_mask) pool_mask[base + i] = 1;
-        for (int i = t0; i < T * 8; i += NT) {
-            ell[base * 8 + i] = 0;
-            if (ellT) ellT[base * 8 + i] = 0;
+        a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+        if constexpr (ALLW) {                                          // (the workgroup-wide sums of the earlier phases are consumed: s_red is free)
+            __syncthreads();
+            if (threadIdx.x == 0) { s_red[0] = 0; s_red[1] = 0; s_red[2] = 0; }
+            __syncthreads();
+            if (lane == 0) { atomicAdd(&s_red[0], a0); atomicAdd(&s_red[1], a1); atomicAdd(&s_red[2], a2); }
+            __syncthreads();
+            a0 = s_red[0]; a1 = s_red[1]; a2 = s_red[2];
+        }
+        // every sentence has been polled by this workgroup: the last one to get here leaves the workspace zeroed for the next launch
+        int done = 0;
+        if (threadIdx.x == 0) done = (int)atomicAdd(po.sync + B + 1, 1ull);
+        done = __builtin_amdgcn_readfirstlane(done);
+        if constexpr (ALLW) { if (threadIdx.x == 0) s_red[3] = done; __syncthreads(); done = s_red[3]; }
+        if (done == B - 1)
+            for (int j = t0; j < B + 2; j += NT) po.sync[j] = 0ull;
+        rbase = (size_t)a0; ebase = a1; eTbase = a2; cshift = a0; nrw = len;
+        fits = a0 + len <= po.n_rows && a1 + my_nnz <= po.nnz_cap && a2 + my_nnzT <= po.nnz_cap;
+        if (threadIdx.x == 0) {
+            po.cu[b] = a0;
+            if (b == B - 1) {                                          // the totals: the one writer of the batch-level results
+                po.cu[B] = a0 + len;
+                po.pk_status[0] = fits ? 0 : GCNPT_E_CAPACITY;         // (offsets grow with b: the last sentence fits iff all do)
+                po.pk_status[1] = a0 + len;
+                if (fits) {
+                    row_ptr[a0 + len] = a1 + my_nnz;
+                    if (rowT_ptr) rowT_ptr[a0 + len] = a2 + my_nnzT;
+                }
+            }
+        }
+        if (!fits) {                                                   // nothing of this sentence is written (gcnpt_pack_trees' rule)
+            if (threadIdx.x == 0) { status[b] = err; *s_status = GCNPT_E_CAPACITY; }
+            return;
+        }
+        for (int i = t0; i < len; i += NT) {
+            po.row_sent[a0 + i] = b;
+            if (pool_mask) pool_mask[a0 + i] = err ? 1 : ((deg[i + 1] - deg[i]) + (degT[i + 1] - degT[i])) == 0;
+        }
+        if (err && po.pool_mask_padded)
+            for (int i = t0; i < T; i += NT) po.pool_mask_padded[base + i] = 1;
+    }
+    // row_ptr index of this sentence's row 0 (the padded layout keeps T + 1 offsets per sentence)
+    const size_t rp0 = po.cu ? rbase : (size_t)b * (T + 1);
+    const int n_off = po.cu ? nrw : T + 1;                             // offsets it writes (packed: the next sentence writes the closing one)
+    if (threadIdx.x == 0) { s_out[0] = (int)rbase; s_out[1] = ebase; s_out[2] = eTbase; s_out[3] = cshift; }
+
+    if (err) {   // the sentence contributes no edges; every row is empty and masked
+        for (int i = t0; i < n_off; i += NT) {
+            row_ptr[rp0 + i] = ebase;
+            if (rowT_ptr) rowT_ptr[rp0 + i] = eTbase;
+        }
+        if (!po.cu)
+            for (int i = t0; i < T; i += NT)
+                if (pool_mask) pool_mask[base + i] = 1;
+        for (int i = t0; i < nrw * 8; i += NT) {
+            ell[rbase * 8 + i] = 0;
+            if (ellT) ellT[rbase * 8 + i] = 0;
         }
         if (threadIdx.x == 0) { status[b] = err; *s_status = err; }
         return;
@@ -311,9 +396,9 @@ __device__ void prune_sentence(const int64_t* __restrict__ head, const int64_t* 
     // ---- emit both patterns, columns ascending (same order a dense -> CSR conversion gives).
     // Only rows that carry an edge have entries, and only such rows appear as columns: compact them (ascending)
     // with everything the inner loop needs in ONE word, so that loop is a stream of broadcast LDS reads.
-    for (int i = t0; i <= T; i += NT) {
-        row_ptr[(size_t)b * (T + 1) + i] = b * cap + deg[i];
-        if (rowT_ptr) rowT_ptr[(size_t)b * (T + 1) + i] = b * cap + degT[i];
+    for (int i = t0; i < n_off; i += NT) {
+        row_ptr[rp0 + i] = ebase + deg[i];
+        if (rowT_ptr) rowT_ptr[rp0 + i] = eTbase + degT[i];
     }
     for (int i = t0; i < T; i += NT) {
         const int w = i < len ? pw[i] : 0;
@@ -321,11 +406,11 @@ __device__ void prune_sentence(const int64_t* __restrict__ head, const int64_t* 
             const int f = w >> PW_SHIFT;
             einfo[rank[i]] = i | ((w & PW_MASK) << 12) | ((cnt[i] & K_CHILD) ? 1 << 24 : 0) |
                              ((f & F_FWD_NZ) ? 1 << 25 : 0) | ((f & F_REV_NZ) ? 1 << 26 : 0);
-        } else {                                                     // no entries: an all-zero ELL head
-            int4* e = reinterpret_cast<int4*>(ell + (base + i) * 8);
+        } else if (i < nrw) {                                        // no entries: an all-zero ELL head
+            int4* e = reinterpret_cast<int4*>(ell + (rbase + i) * 8);
             e[0] = make_int4(0, 0, 0, 0); e[1] = make_int4(0, 0, 0, 0);
             if (ellT) {
-                int4* eT = reinterpret_cast<int4*>(ellT + (base + i) * 8);
+                int4* eT = reinterpret_cast<int4*>(ellT + (rbase + i) * 8);
                 eT[0] = make_int4(0, 0, 0, 0); eT[1] = make_int4(0, 0, 0, 0);
             }
         }
@@ -338,15 +423,14 @@ __device__ void prune_sentence(const int64_t* __restrict__ head, const int64_t* 
 // One row of both patterns by ONE WAVE: one candidate column per lane (the edge rows, ascending), ballot + prefix popcount give every
 // entry its slot -- no sorting, any number of entries.  rw / rdeg / rdegT / rlab: the chunk's row info in the lanes' registers (row qq of
 // the chunk is read with v_readlane).
-__device__ __forceinline__ void emit_row_scan(int b, int T, int cap, const int* lab, const int* einfo, int n_edge_rows, int lane, int me, int labr_raw,
+__device__ __forceinline__ void emit_row_scan(size_t base, int ebase, int eTbase, int cshift, const int* lab, const int* einfo, int n_edge_rows, int lane, int me, int labr_raw,
                                               int o_rel, int oT_rel, int32_t* __restrict__ col_idx, int32_t* __restrict__ label,
                                               int32_t* __restrict__ colT_idx, int32_t* __restrict__ ell, int32_t* __restrict__ ellT) {
-    const size_t base = (size_t)b * T;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int r = me & 0xfff, rp = ((me >> 12) & 0xfff) - 2;
     const bool rchild = me & (1 << 24), rfwd = me & (1 << 25), rrev = me & (1 << 26);
     const int labr = labr_raw + FWD_BOUND;
-    const int o = b * cap + o_rel, oT = b * cap + oT_rel;
+    const int o = ebase + o_rel, oT = eTbase + oT_rel;
     int32_t* hd = ell + (base + r) * 8;                       // ELL head: [0] = count, [1..7] = first 7 columns
     int32_t* hdT = ellT ? ellT + (base + r) * 8 : nullptr;
     int n_e = 0, n_eT = 0;
@@ -362,14 +446,14 @@ __device__ __forceinline__ void emit_row_scan(int b, int T, int cap, const int* 
         const unsigned long long m = __ballot(e), mT = __ballot(eT);
         if (e) {
             const int pos = n_e + __popcll(m & lt);
-            col_idx[o + pos] = j;
+            col_idx[o + pos] = j + cshift;
             if (label) label[o + pos] = is_self ? SELF_LOOP_ID : (is_child ? lab[j] : labr);
-            if (pos < 7) hd[1 + pos] = j;
+            if (pos < 7) hd[1 + pos] = j + cshift;
         }
         if (eT) {
             const int pos = n_eT + __popcll(mT & lt);
-            if (colT_idx) colT_idx[oT + pos] = j;
-            if (hdT && pos < 7) hdT[1 + pos] = j;
+            if (colT_idx) colT_idx[oT + pos] = j + cshift;
+            if (hdT && pos < 7) hdT[1 + pos] = j + cshift;
         }
         n_e += __popcll(m);
         n_eT += __popcll(mT);
@@ -388,7 +472,7 @@ __device__ __forceinline__ void emit_row_scan(int b, int T, int cap, const int* 
 // Otherwise: one row at a time per wave, one candidate column per lane (emit_row_scan) -- O(rows^2 / 64) wave iterations, which at
 // T = 300, K = 2 was 11-25 k cycles of the sentence's 29-43 k.
 constexpr int EMIT_SORT_MAX = 12;
-__device__ void emit_rows(int b, int T, int cap, int* smem, int err, int n_edge_rows, int lane, int wave, bool staged,
+__device__ void emit_rows(const int* s_out, int T, int* smem, int err, int n_edge_rows, int lane, int wave, bool staged,
                           int32_t* __restrict__ col_idx, int32_t* __restrict__ label, int32_t* __restrict__ colT_idx,
                           int32_t* __restrict__ ell, int32_t* __restrict__ ellT, unsigned long long* stamps) {
     if (err) return;
@@ -399,7 +483,8 @@ __device__ void emit_rows(int b, int T, int cap, int* smem, int err, int n_edge_
     int* rank = degT + T + 1;          // free as well: fill counter of the transposed rows
     int* lab = rank + T + 1;
     int* einfo = lab + T;
-    const size_t base = (size_t)b * T;
+    const size_t base = (size_t)s_out[0];                  // first row, first entries of the two patterns, column shift (prune_sentence)
+    const int ebase = s_out[1], eTbase = s_out[2], cshift = s_out[3];
     if (staged && n_edge_rows > WAVE) {          // (up to 64 edge rows the scan form is as fast: 4.7 k against 5.3 k cycles at T = 100, K = 1)
         int* entF = einfo + T;         // [nnz]  forward entries: column (the label follows from the pair, see below)
         int* entT = entF + 3 * T;      // [nnzT] transposed entries: column
@@ -453,12 +538,12 @@ __device__ void emit_rows(int b, int T, int cap, int* smem, int err, int n_edge_
             for (int k = 0; k < EMIT_SORT_MAX; ++k) {
                 if (k < n) {
                     const int j = v[k];
-                    col_idx[b * cap + o + k] = j;
+                    col_idx[ebase + o + k] = j + cshift;
                     // the value tree_to_adj wrote there (tree.py:184-192): 84 on the diagonal, deprel[j] for a child j, deprel[r] + 42 for the parent
-                    if (label) label[b * cap + o + k] = j == r ? SELF_LOOP_ID : (pw_par(smem[j]) == r ? lab[j] : lab[r] + FWD_BOUND);
+                    if (label) label[ebase + o + k] = j == r ? SELF_LOOP_ID : (pw_par(smem[j]) == r ? lab[j] : lab[r] + FWD_BOUND);
                 }
-                if (k < nT && colT_idx) colT_idx[b * cap + oT + k] = vT[k];
-                if (k < 7) { hd[1 + k] = k < n ? v[k] : 0; hdT[1 + k] = k < nT ? vT[k] : 0; }
+                if (k < nT && colT_idx) colT_idx[eTbase + oT + k] = vT[k] + cshift;
+                if (k < 7) { hd[1 + k] = k < n ? v[k] + cshift : 0; hdT[1 + k] = k < nT ? vT[k] + cshift : 0; }
             }
             int4* e = reinterpret_cast<int4*>(ell + (base + r) * 8);
             e[0] = make_int4(hd[0], hd[1], hd[2], hd[3]); e[1] = make_int4(hd[4], hd[5], hd[6], hd[7]);
@@ -472,7 +557,7 @@ __device__ void emit_rows(int b, int T, int cap, int* smem, int err, int n_edge_
         for (int x = wave; x < nl; x += PRUNE_THREADS / WAVE) {           // the few long rows: one wave each, scan form
             const int me = einfo[longrows[x]];
             const int r = me & 0xfff;
-            emit_row_scan(b, T, cap, lab, einfo, n_edge_rows, lane, me, lab[r], deg[r], degT[r], col_idx, label, colT_idx, ell, ellT);
+            emit_row_scan(base, ebase, eTbase, cshift, lab, einfo, n_edge_rows, lane, me, lab[r], deg[r], degT[r], col_idx, label, colT_idx, ell, ellT);
         }
         GCNPT_STAMP(stamps, 7);
         return;
@@ -482,7 +567,7 @@ __device__ void emit_rows(int b, int T, int cap, int* smem, int err, int n_edge_
         const int rdeg = deg[rw & 0xfff], rdegT = degT[rw & 0xfff], rlab = lab[rw & 0xfff];
         const int nq = min(WAVE, n_edge_rows - q0);
         for (int qq = wave; qq < nq; qq += PRUNE_THREADS / WAVE) {    // this wave's rows of the chunk
-            emit_row_scan(b, T, cap, lab, einfo, n_edge_rows, lane, __builtin_amdgcn_readlane(rw, qq), __builtin_amdgcn_readlane(rlab, qq),
+            emit_row_scan(base, ebase, eTbase, cshift, lab, einfo, n_edge_rows, lane, __builtin_amdgcn_readlane(rw, qq), __builtin_amdgcn_readlane(rlab, qq),
                           __builtin_amdgcn_readlane(rdeg, qq), __builtin_amdgcn_readlane(rdegT, qq), col_idx, label, colT_idx, ell, ellT);
         }
     }
@@ -495,7 +580,7 @@ __global__ __launch_bounds__(PRUNE_THREADS) void prune_to_csr_kernel(
     int B, int T, int prune_k, int cap, int32_t* __restrict__ row_ptr, int32_t* __restrict__ col_idx,
     int32_t* __restrict__ label, int32_t* __restrict__ rowT_ptr, int32_t* __restrict__ colT_idx,
     int32_t* __restrict__ ell, int32_t* __restrict__ ellT, uint8_t* __restrict__ pool_mask,
-    int32_t* __restrict__ status, unsigned long long* stamps, const PackParams pk, int pk_dtype, int staged) {
+    int32_t* __restrict__ status, unsigned long long* stamps, const PackParams pk, int pk_dtype, int staged, const PackedOut po) {
     extern __shared__ int smem[];  // carved in prune_sentence() (+ the entry lists of emit_rows when staged)
     __shared__ int s_err;
     if ((int)blockIdx.x >= B) {    // side job of gcnpt_prune_to_csr_pack: the launch leaves most CUs idle, these workgroups pack the weights
@@ -503,14 +588,17 @@ __global__ __launch_bounds__(PRUNE_THREADS) void prune_to_csr_kernel(
         return;
     }
 
-    __shared__ int s_status, s_nrows, s_red[4];
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ int s_status, s_nrows, s_red[4], s_out[4], s_ticket;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // packed output: sentences in ticket order (PackedOut), else the workgroup's own
+    if (threadIdx.x == 0) s_ticket = po.cu ? (int)atomicAdd(po.sync + B, 1ull) : (int)blockIdx.x;
     if (threadIdx.x == 0) { s_err = 0; s_status = 0; s_nrows = 0; s_red[0] = s_red[1] = s_red[2] = 0; s_red[3] = 0x7fffffff; }
     GCNPT_STAMP_REAL(stamps);
     GCNPT_STAMP(stamps, 0);
     __shared__ int s_maxlen;
     if (threadIdx.x == 0) s_maxlen = 0;
     __syncthreads();
+    const int b = s_ticket;
     const bool allw = T > PRUNE_WAVE0_T;
     // status[B] = longest sentence of the batch (gcn.py:97): waves of workgroup 0 that have no token to prune count every sentence's
     // non-pad slots while the others prune (wave 0 alone, or the waves holding the T tokens), so the launch needs neither a memset
@@ -535,12 +623,12 @@ __global__ __launch_bounds__(PRUNE_THREADS) void prune_to_csr_kernel(
         if (lane == 0) atomicMax(&s_maxlen, m);
     }
     if (allw) prune_sentence<true>(head, subj_pos, obj_pos, deprel, pad_mask, len_in, b, B, T, prune_k, cap, smem, &s_err, &s_status,
-                                   &s_nrows, s_red, row_ptr, rowT_ptr, ell, ellT, pool_mask, status, stamps);
+                                   &s_nrows, s_red, row_ptr, rowT_ptr, ell, ellT, pool_mask, status, stamps, po, s_out);
     else if (wave == 0) prune_sentence<false>(head, subj_pos, obj_pos, deprel, pad_mask, len_in, b, B, T, prune_k, cap, smem, &s_err, &s_status,
-                                              &s_nrows, s_red, row_ptr, rowT_ptr, ell, ellT, pool_mask, status, stamps);
+                                              &s_nrows, s_red, row_ptr, rowT_ptr, ell, ellT, pool_mask, status, stamps, po, s_out);
     __syncthreads();
     if (b == 0 && threadIdx.x == 0 && (long long)B * T <= PRUNE_SCAN_MAX && first_idle < PRUNE_THREADS / WAVE) status[B] = s_maxlen;
-    emit_rows(b, T, cap, smem, s_status, s_nrows, lane, wave, staged != 0, col_idx, label, colT_idx, ell, ellT, stamps);
+    emit_rows(s_out, T, smem, s_status, s_nrows, lane, wave, staged != 0, col_idx, label, colT_idx, ell, ellT, stamps);
 }
 
 // ---- dense float adjacency -> CSR of (adj != 0) and of its transpose (gcn.py:260-262) -----------------
@@ -799,7 +887,7 @@ static int prune_impl(void* stream, const int64_t* head, const int64_t* subj_pos
                       const int64_t* deprel, const uint8_t* pad_mask, const int32_t* len, int B, int T,
                       int prune_k, int cap, int32_t* row_ptr, int32_t* col_idx, int32_t* label,
                       int32_t* rowT_ptr, int32_t* colT_idx, int32_t* ell, int32_t* ellT, uint8_t* pool_mask,
-                      int32_t* status, const PackParams& pk, int pk_dtype, int pack_blocks) {
+                      int32_t* status, const PackParams& pk, int pk_dtype, int pack_blocks, const PackedOut& po = PackedOut{}) {
     GCNPT_REQUIRE(head && subj_pos && obj_pos && deprel && (pad_mask || len), "prune_to_csr: null input pointer");
     GCNPT_REQUIRE(row_ptr && col_idx && ell && status, "prune_to_csr: null output pointer");
     GCNPT_REQUIRE((rowT_ptr == nullptr) == (ellT == nullptr), "prune_to_csr: rowT_ptr, colT_idx and ellT go together");
@@ -823,7 +911,7 @@ static int prune_impl(void* stream, const int64_t* head, const int64_t* subj_pos
         GCNPT_HIP_CHECK(hipMemsetAsync(status + B, 0, sizeof(int32_t), s));
     hipLaunchKernelGGL(prune_to_csr_kernel, dim3(B + pack_blocks), dim3(PRUNE_THREADS), lds, s, head, subj_pos, obj_pos, deprel,
                        pad_mask, len, B, T, prune_k, cap, row_ptr, col_idx, label, rowT_ptr, colT_idx, ell, ellT, pool_mask, status,
-                       static_cast<unsigned long long*>(g_debug_stamps), pk, pk_dtype, staged);
+                       static_cast<unsigned long long*>(g_debug_stamps), pk, pk_dtype, staged, po);
     GCNPT_HIP_CHECK(hipGetLastError());
     return GCNPT_OK;
 }
@@ -853,6 +941,30 @@ extern "C" int gcnpt_prune_to_csr_pack(void* stream, const int64_t* head, const 
     if (rc != GCNPT_OK) return rc;
     return prune_impl(stream, head, subj_pos, obj_pos, deprel, pad_mask, len, B, T, prune_k, cap, row_ptr, col_idx, label, rowT_ptr, colT_idx,
                       ell, ellT, pool_mask, status, pk, dtype, pack_side_blocks(pk, PRUNE_THREADS));
+}
+
+// The pruner writing the token-packed layout itself (what gcnpt_pack_trees makes of gcnpt_prune_to_csr's arrays, bit for bit), optionally
+// with the weight pack as a side job: one launch instead of two (three with the pack).
+extern "C" int gcnpt_prune_to_csr_packed(void* stream, const int64_t* head, const int64_t* subj_pos, const int64_t* obj_pos,
+                                         const int64_t* deprel, const uint8_t* pad_mask, const int32_t* len, int B, int T, int prune_k,
+                                         int32_t* cu_seqlens, int32_t* row_ptr, int32_t* col_idx, int32_t* label, int32_t* rowT_ptr,
+                                         int32_t* colT_idx, int32_t* ell, int32_t* ellT, uint8_t* pool_mask, int32_t* row_sent, int n_rows,
+                                         int nnz_cap, int32_t* status, int32_t* sent_status, uint8_t* pool_mask_padded, uint64_t* sync_ws,
+                                         int n_layers, const float* const* W, const int* H, const int* Din, int dtype, void* const* w_fwd,
+                                         void* const* w_bwd) {
+    GCNPT_REQUIRE(cu_seqlens && row_sent && status && sent_status && sync_ws && pool_mask, "prune_to_csr_packed: null pointer");
+    GCNPT_REQUIRE(n_rows > 0 && nnz_cap > 0, "prune_to_csr_packed: n_rows and nnz_cap must be positive");
+    GCNPT_REQUIRE(T <= 0xffff && 3 * (long long)T < (1 << 20), "prune_to_csr_packed: T=%d too long", T);
+    PackParams pk{};
+    int blocks = 0;
+    if (n_layers > 0) {
+        const int rc = fill_pack_params(pk, n_layers, W, H, Din, dtype, w_fwd, w_bwd);
+        if (rc != GCNPT_OK) return rc;
+        blocks = pack_side_blocks(pk, PRUNE_THREADS);
+    }
+    PackedOut po{cu_seqlens, row_sent, pool_mask_padded, reinterpret_cast<unsigned long long*>(sync_ws), status, n_rows, nnz_cap};
+    return prune_impl(stream, head, subj_pos, obj_pos, deprel, pad_mask, len, B, T, prune_k, 3 * T, row_ptr, col_idx, label, rowT_ptr, colT_idx,
+                      ell, ellT, pool_mask, sent_status, pk, dtype, blocks, po);
 }
 
 extern "C" int gcnpt_adj_to_csr(void* stream, const float* adj, int B, int T, int cap, int32_t* row_ptr,

@@ -22,8 +22,8 @@ layer loop runs on token-packed rows, sum(len) instead of B*T, padding only at t
 (True: dropout seeds that survive hipGraph capture), `gcn_pool_handover` = True (layer stack + poolings as one op whose backward
 hands the top layer its dZ), `gcn_pack_with_trees` = True (the tree launch also packs the weights in a training step),
 `gcn_sparse_emb_grad` = False (True: the word-embedding table's gradient is a row-sparse tensor of the batch's token rows, for
-shard.SparseRowExchange in a data-parallel loop), `gcn_reuse_packed_weights` = False (True: a TRAINING forward may reuse the packed weight images of the previous one while the weights'
-version counters stand still -- gradient accumulation; off by default because `p.data` updates do not bump them) -- with `gcn_check_trees=False` a whole training step of the no-LSTM
+shard.SparseRowExchange in a data-parallel loop), `gcn_reuse_packed_weights` = False (True: a forward may reuse the packed weight images of the previous one while the weights'
+version counters stand still -- gradient accumulation, a frozen model; off by default because `p.data` updates do not bump them, in eval() either) -- with `gcn_check_trees=False` a whole training step of the no-LSTM
 model can be captured with torch.cuda.graph and replayed, see tests/test_gpu_parity.py::test_training_step_graph_capture).
 """
 import ctypes
@@ -34,7 +34,7 @@ import torch.nn as nn
 
 from .. import _lib
 from ..utils import constant
-from .tree import CompactTrees, PackedTrees, PrunedTrees, adj_to_csr, prune_to_csr
+from .tree import CompactTrees, PackedTrees, PrunedTrees, adj_to_csr, prune_to_csr, prune_to_csr_packed
 
 
 def _row_dims(h, trees, what):
@@ -446,6 +446,14 @@ class GCNRelationModel(nn.Module):
             # lengths, head_to_tree, tree_to_adj and the upload (gcn.py:96-112) in one launch, no host round trip; in a training step the
             # same launch packs the layer weights on the CUs the tree build leaves idle (one launch boundary less)
             pack = self.gcn.weight_pack(head.shape[0], head.shape[1]) if self.opt.get('gcn_pack_with_trees', True) else None
+            if self.opt.get('gcn_packed', False) and self.adj_type == 'regular' and not self.opt.get('gcn_pooled_only', False):
+                # token-packed rows: the layers run on sum(len) rows instead of B*T (one host sync for sum(len), where the reference syncs
+                # for the lengths anyway, gcn.py:96); the SAME launch writes the packed layout (and packs the weights)
+                trees = prune_to_csr_packed(head, subj_pos, obj_pos, deprel, self.opt['prune_k'], masks.eq(0).sum(1), masks=masks, pack=pack)
+                if self.opt.get('gcn_check_trees', True):
+                    trees.padded.check(expect_maxlen=head.shape[1])
+                    trees.check()
+                return self._forward_trees(inputs, trees, pack, subj_pos, obj_pos)
             trees = prune_to_csr(head, subj_pos, obj_pos, deprel, self.opt['prune_k'], masks=masks,
                                  want_label=self.adj_type != 'regular', pack=pack)
             if self.opt.get('gcn_check_trees', True):
@@ -453,15 +461,14 @@ class GCNRelationModel(nn.Module):
             if self.opt.get('gcn_pooled_only', False):
                 # one host sync for the width (a TreeCache avoids it); entity tokens are kept even when the tree does not hold them
                 trees = trees.compact(also_keep=(subj_pos == 0) | (obj_pos == 0))
-            elif self.opt.get('gcn_packed', False) and self.adj_type == 'regular':
-                # token-packed rows: the layers run on sum(len) rows instead of B*T (one host sync for sum(len), where the
-                # reference syncs for the lengths anyway, gcn.py:96)
-                trees = trees.pack(masks.eq(0).sum(1))
         else:
             if (trees.B, trees.T) != tuple(head.shape):
                 raise ValueError("trees are for a [%d,%d] batch, the inputs are %s" % (trees.B, trees.T, tuple(head.shape)))
             if self.opt.get('gcn_check_trees', True):
                 trees.check() if isinstance(trees, PackedTrees) else trees.check(expect_maxlen=head.shape[1])
+        return self._forward_trees(inputs, trees, pack, subj_pos, obj_pos)
+
+    def _forward_trees(self, inputs, trees, pack, subj_pos, obj_pos):
         # regular adjacency on the padded layout: the GCN returns the three pooled vectors itself (stack + pooling as ONE autograd op, so the
         # pooling's backward hands the top layer its dZ); opt['gcn_pool_handover'] = False keeps the two ops apart
         handover = (self.adj_type == 'regular' and isinstance(trees, (PrunedTrees, CompactTrees)) and self.opt.get('gcn_pool_handover', True))
@@ -590,15 +597,16 @@ class GCN(nn.Module):
     def _cache_usable(self):
         """Whether this forward may reuse the packed weight images of an earlier one.  The cache is keyed on the weights' storage and
         version counters, and an in-place update through `p.data` (the reference's own MyAdagrad does that, utils/torch_utils.py:84-88;
-        so do EMA / clipping code) changes the values WITHOUT bumping the counter: a training forward therefore always re-packs (one
-        4 us launch, or none when the tree launch carries it), unless opt['gcn_reuse_packed_weights'] says the caller knows its weights
-        stand still between forwards (gradient accumulation).  eval() / no_grad forwards reuse: call invalidate_weight_cache() after
-        writing to `p.data` by hand there."""
+        so do EMA swaps and hand-written clipping) changes the values WITHOUT bumping the counter -- in train() and in eval() alike
+        (`eval -> p.data.copy_(ema) -> eval` is the usual evaluation of an averaged model).  So every forward re-packs -- one 4 us launch,
+        none at all when the tree launch of the same forward carries it (gcn_pack_with_trees) -- unless opt['gcn_reuse_packed_weights']
+        says the caller knows its weights stand still between forwards (gradient accumulation, a frozen model serving requests); such a
+        caller calls invalidate_weight_cache() after writing to `p.data` by hand."""
         if torch.cuda.is_current_stream_capturing():
             return False                                                  # a captured step must contain its pack
-        ok = (not self.training) or (not torch.is_grad_enabled()) or bool(self.opt.get('gcn_reuse_packed_weights', False))
+        ok = bool(self.opt.get('gcn_reuse_packed_weights', False))
         if not ok:
-            self._wcache.clear()      # a training forward is (presumably) followed by an update: what an earlier eval() cached is void after it
+            self._wcache.clear()
         return ok
 
     def invalidate_weight_cache(self):

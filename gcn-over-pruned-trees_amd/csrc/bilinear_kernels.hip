@@ -52,6 +52,8 @@ struct BilinearParams {
     float* y;               // MODE 0: [slices][M, H], one plane per relation slice; MODE 1: [nb][M, D], one plane per column block
     const float* gy;        // MODE 1: [M, H] upstream gradient
     int M, D, H, TS, n_tiles, mb, nb, slices, d_per_slice;
+    int TSA, chunks;        // k-steps per relation in all (x rows and the image are that wide); the contraction is cut into `chunks` runs
+                            // of <= TS k-steps (Tin > 256: what the registers hold), each with planes of its own
 };
 
 // A workgroup owns 256 tokens (its 4 waves take 64 each: 4 token tiles whose x fragments stay in registers), 48 output columns
@@ -73,19 +75,21 @@ constexpr int BL_FRAGS = BL_GL * BL_WAVES;           // fragment slots per ring 
 template <int MODE>
 __global__ __launch_bounds__(BL_THREADS, 1) void bilinear_fwd_kernel(const BilinearParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bl_smem[];              // ONE LDS object: ring | dummy | e tile
-    const int TS = p.TS, Tpad = TS * 32;
+    const int per_chunk = p.mb * p.nb * p.slices;
+    const int chunk = (int)blockIdx.x / per_chunk, ts0 = chunk * p.TS;                   // this workgroup's run of the contraction
+    const int TS = min(p.TS, p.TSA - ts0), Tpad = p.TSA * 32;
     const int n_frag = BL_NT * TS;
     uint4* wl = reinterpret_cast<uint4*>(bl_smem);                                       // [BL_RING][BL_FRAGS][64]
     uint4* dummy = wl + (size_t)BL_RING * BL_FRAGS * 64;                                 // [BL_WAVES][64]: where unused slots' loads land
     float* es = reinterpret_cast<float*>(dummy + BL_WAVES * 64);                         // [d_per_slice][BL_ROWS + 1]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int id = blockIdx.x;
+    const int id = (int)blockIdx.x - chunk * per_chunk;
     const int slice = id % p.slices, rest = id / p.slices;
     const int bm = rest % p.mb, bn = rest / p.mb;
     const int m0 = bm * BL_ROWS + wave * 16 * BL_MT, nt0 = bn * BL_NT;
     const int d_lo = slice * p.d_per_slice, d_hi = min(p.D, d_lo + p.d_per_slice);
     const int nd = d_hi - d_lo;
-    const size_t d_stride = (size_t)p.D * TS;            // fragments per output tile in the image
+    const size_t d_stride = (size_t)p.D * p.TSA;         // fragments per output tile in the image
 
     // this wave's x fragments: lane (l & 15) = token row, 8 consecutive k per lane -- registers for the whole kernel
     uint4 xf[BL_MT][BL_TSMAX];
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(BL_THREADS, 1) void bilinear_fwd_kernel(const Bilin
         const size_t row = (size_t)min(m0 + 16 * mt + (lane & 15), p.M - 1);
 #pragma unroll
         for (int ts = 0; ts < BL_TSMAX; ++ts)
-            xf[mt][ts] = *reinterpret_cast<const uint4*>(p.x + row * Tpad + min(ts, TS - 1) * 32 + 8 * (lane >> 4));
+            xf[mt][ts] = *reinterpret_cast<const uint4*>(p.x + row * Tpad + (ts0 + min(ts, TS - 1)) * 32 + 8 * (lane >> 4));
     }
     // relation dd -> ring entry: exactly BL_GL loads per wave (fragments wave, wave + 4, ...; slots past 3 TS go to the dummy)
     auto fetch_w = [&](int dd) {
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(BL_THREADS, 1) void bilinear_fwd_kernel(const Bilin
             const int f = wave + u * BL_WAVES;
             const int fc = min(f, n_frag - 1);
             const int j = fc / TS, ts = fc - j * TS;
-            const uint4* src = p.img + ((size_t)min(nt0 + j, p.n_tiles - 1) * d_stride + (size_t)d * TS + ts) * 64 + lane;
+            const uint4* src = p.img + ((size_t)min(nt0 + j, p.n_tiles - 1) * d_stride + (size_t)d * p.TSA + ts0 + ts) * 64 + lane;
             uint4* dst = f < n_frag ? ring + (size_t)f * 64 : dummy + wave * 64;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(BL_THREADS, 1) void bilinear_fwd_kernel(const Bilin
 #pragma unroll
                 for (int j = 0; j < BL_NT; ++j) acc[mt][j] += ev[mt] * P[mt][j];
         } else {
-            float* plane = p.y + (size_t)bn * p.M * p.D;
+            float* plane = p.y + (size_t)(chunk * p.nb + bn) * p.M * p.D;
 #pragma unroll
             for (int mt = 0; mt < BL_MT; ++mt) {
                 float sdot = 0.0f;
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(BL_THREADS, 1) void bilinear_fwd_kernel(const Bilin
     if constexpr (MODE == 1) return;
     // every wave owns its rows: plain 16-byte stores into this relation slice's own plane of y (the caller sums the planes: ten
     // float atomics per element cost more than the whole contraction -- ~50 G atomics/s device-wide -- a plane costs one store)
-    float* plane = p.y + (size_t)slice * p.M * p.H;
+    float* plane = p.y + (size_t)(chunk * p.slices + slice) * p.M * p.H;
     const bool vec = (p.H & 3) == 0;
 #pragma unroll
     for (int mt = 0; mt < BL_MT; ++mt) {
@@ -407,24 +411,27 @@ struct BilinearF32Params {
     float* y;               // MODE 0: [slices][M, H]; MODE 1: [nb][M, D]
     const float* gy;        // MODE 1: [M, H]
     int M, D, H, TS, n_tiles, mb, nb, slices, d_per_slice;
+    int TSA, chunks;        // as BilinearParams: all k-steps of a relation / runs of <= TS k-steps the contraction is cut into
 };
 
 template <int MODE>
 __global__ __launch_bounds__(BL_THREADS, 1) void bilinear_f32_kernel(const BilinearF32Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bf_smem[];              // [2][BF_NT * BF_TSMAX][64] uint4 | e tile
-    const int TS = p.TS, Tpad = TS * 16;
+    const int per_chunk = p.mb * p.nb * p.slices;
+    const int chunk = (int)blockIdx.x / per_chunk, ts0 = chunk * p.TS;
+    const int TS = min(p.TS, p.TSA - ts0), Tpad = p.TSA * 16;
     const int n_frag = BF_NT * TS;
     constexpr int STAGE = BF_NT * BF_TSMAX * 64;                                         // uint4 per stage (all slots: the stores are unconditional)
     uint4* wl = reinterpret_cast<uint4*>(bf_smem);
     float* es = reinterpret_cast<float*>(wl + (size_t)2 * STAGE);                        // [d_per_slice][BF_ROWS + 1]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int id = blockIdx.x;
+    const int id = (int)blockIdx.x - chunk * per_chunk;
     const int slice = id % p.slices, rest = id / p.slices;
     const int bm = rest % p.mb, bn = rest / p.mb;
     const int m0 = bm * BF_ROWS + wave * 16 * BF_MT, nt0 = bn * BF_NT;
     const int d_lo = slice * p.d_per_slice, d_hi = min(p.D, d_lo + p.d_per_slice);
     const int nd = d_hi - d_lo;
-    const size_t d_stride = (size_t)p.D * TS;
+    const size_t d_stride = (size_t)p.D * p.TSA;
 
     // this wave's x fragments: lane (l & 15) = token row, 4 consecutive k per lane -- registers for the whole kernel
     uint4 xf[BF_MT][BF_TSMAX];
@@ -433,7 +440,7 @@ __global__ __launch_bounds__(BL_THREADS, 1) void bilinear_f32_kernel(const Bilin
         const size_t row = (size_t)min(m0 + 16 * mt + (lane & 15), p.M - 1);
 #pragma unroll
         for (int ts = 0; ts < BF_TSMAX; ++ts)
-            xf[mt][ts] = *reinterpret_cast<const uint4*>(p.x + row * Tpad + min(ts, TS - 1) * 16 + 4 * (lane >> 4));
+            xf[mt][ts] = *reinterpret_cast<const uint4*>(p.x + row * Tpad + (ts0 + min(ts, TS - 1)) * 16 + 4 * (lane >> 4));
     }
     // a relation's fragments: thread t fetches fragment-lanes t, t + 256, ... (<= BF_NT * BF_TSMAX * 64 / 256 = 12 per thread)
     constexpr int WPT = BF_NT * BF_TSMAX * 64 / BL_THREADS;
@@ -446,7 +453,7 @@ __global__ __launch_bounds__(BL_THREADS, 1) void bilinear_f32_kernel(const Bilin
             const int q = min(tid + u * BL_THREADS, n_frag * 64 - 1);
             const int f = q >> 6, l = q & 63;
             const int j = f / TS, ts = f - j * TS;
-            wr[u] = *reinterpret_cast<const u32x4_t*>(p.img + ((size_t)min(nt0 + j, p.n_tiles - 1) * d_stride + (size_t)d * TS + ts) * 64 + l);
+            wr[u] = *reinterpret_cast<const u32x4_t*>(p.img + ((size_t)min(nt0 + j, p.n_tiles - 1) * d_stride + (size_t)d * p.TSA + ts0 + ts) * 64 + l);
         }
     };
     // (unconditional stores into a stage sized for BF_TSMAX k-steps: a prefetched register whose only use is a CONDITIONAL store gets
@@ -531,7 +538,7 @@ __global__ __launch_bounds__(BL_THREADS, 1) void bilinear_f32_kernel(const Bilin
 #pragma unroll
                 for (int j = 0; j < BF_NT; ++j) acc[mt][j] += ev[mt] * P[mt][j];
         } else {
-            float* plane = p.y + (size_t)bn * p.M * p.D;
+            float* plane = p.y + (size_t)(chunk * p.nb + bn) * p.M * p.D;
 #pragma unroll
             for (int mt = 0; mt < BF_MT; ++mt) {
                 float sdot = 0.0f;
@@ -550,7 +557,7 @@ __global__ __launch_bounds__(BL_THREADS, 1) void bilinear_f32_kernel(const Bilin
     }
 
     if constexpr (MODE == 1) return;
-    float* plane = p.y + (size_t)slice * p.M * p.H;
+    float* plane = p.y + (size_t)(chunk * p.slices + slice) * p.M * p.H;
     const bool vec = (p.H & 3) == 0;
 #pragma unroll
     for (int mt = 0; mt < BF_MT; ++mt) {
@@ -685,9 +692,11 @@ extern "C" size_t gcnpt_bilinear_packed_bytes(int D, int Tin, int H, int dtype) 
     return (size_t)ceil_div(H, 16) * D * ceil_div(Tin, bl_kstep(dtype)) * 64 * 16;
 }
 
+// (Tin beyond what a wave's registers hold -- 256 in bf16 -- is cut into runs of k-steps, each run with planes of its own: see the
+// `chunks` of the parameter structs.  The bound below only keeps the plane count sane.)
 extern "C" int gcnpt_bilinear_supported(int D, int Tin, int H, int dtype) {
     if (!dtype_ok(dtype)) return 0;
-    return D > 0 && H > 0 && Tin > 0 && ceil_div(Tin, bl_kstep(dtype)) <= (dtype == GCNPT_BF16 ? BL_TSMAX : BF_TSMAX);
+    return D > 0 && H > 0 && Tin > 0 && ceil_div(Tin, bl_kstep(dtype)) <= 8 * (dtype == GCNPT_BF16 ? BL_TSMAX : BF_TSMAX);
 }
 
 extern "C" int gcnpt_bilinear_pack(void* stream, const float* W, int D, int Tin, int H, void* w_img, int transposed, int dtype) {
@@ -705,9 +714,10 @@ extern "C" int gcnpt_bilinear_pack(void* stream, const float* W, int D, int Tin,
 }
 
 static void bilinear_f32_plan(BilinearF32Params& p, int M, int D, int Tin, int H) {
-    p.M = M; p.D = D; p.H = H; p.TS = ceil_div(Tin, 16); p.n_tiles = ceil_div(H, 16);
+    p.M = M; p.D = D; p.H = H; p.TSA = ceil_div(Tin, 16); p.n_tiles = ceil_div(H, 16);
+    p.chunks = ceil_div(p.TSA, BF_TSMAX); p.TS = ceil_div(p.TSA, p.chunks);
     p.mb = ceil_div(M, BF_ROWS); p.nb = ceil_div(p.n_tiles, BF_NT);
-    int slices = std::max(1, std::min(256 / std::max(1, p.mb * p.nb), D / 4));       // one workgroup per CU, one round
+    int slices = std::max(1, std::min(256 / std::max(1, p.mb * p.nb * p.chunks), D / 4));       // one workgroup per CU, one round
     slices = std::max(slices, ceil_div(D, 64));                 // the e tile of a slice must fit LDS beside the two weight stages
     p.d_per_slice = ceil_div(D, slices);
     p.slices = ceil_div(D, p.d_per_slice);
@@ -718,16 +728,17 @@ static int bilinear_f32_launch(hipStream_t s, BilinearF32Params& p) {
     const size_t lds = (size_t)2 * BF_NT * BF_TSMAX * 64 * sizeof(uint4) + sizeof(float) * (BF_ROWS + 1) * (size_t)p.d_per_slice;
     if (lds > 160 * 1024) return fail(GCNPT_E_UNSUPPORTED, "bilinear (fp32): %zu B of LDS", lds);
     GCNPT_LDS_ATTR_ONCE(bilinear_f32_kernel<MODE>, 160 * 1024);
-    hipLaunchKernelGGL(bilinear_f32_kernel<MODE>, dim3(p.mb * p.nb * p.slices), dim3(BL_THREADS), lds, s, p);
+    hipLaunchKernelGGL(bilinear_f32_kernel<MODE>, dim3(p.mb * p.nb * p.slices * p.chunks), dim3(BL_THREADS), lds, s, p);
     GCNPT_HIP_CHECK(hipGetLastError());
     return GCNPT_OK;
 }
 
 static void bilinear_plan(BilinearParams& p, int M, int D, int Tin, int H) {
-    p.M = M; p.D = D; p.H = H; p.TS = ceil_div(Tin, 32); p.n_tiles = ceil_div(H, 16);
+    p.M = M; p.D = D; p.H = H; p.TSA = ceil_div(Tin, 32); p.n_tiles = ceil_div(H, 16);
+    p.chunks = ceil_div(p.TSA, BL_TSMAX); p.TS = ceil_div(p.TSA, p.chunks);
     p.mb = ceil_div(M, BL_ROWS); p.nb = ceil_div(p.n_tiles, BL_NT);
     // relation slices: about one workgroup per CU (each holds ~120 KB of LDS and all registers), at least 4 relations each
-    int slices = std::max(1, std::min(256 / std::max(1, p.mb * p.nb), D / 4));
+    int slices = std::max(1, std::min(256 / std::max(1, p.mb * p.nb * p.chunks), D / 4));
     slices = std::max(slices, ceil_div(D, 48));                 // the e tile of a slice must fit LDS beside the ring (48 x 257 words)
     p.d_per_slice = ceil_div(D, slices);
     p.slices = ceil_div(D, p.d_per_slice);
@@ -738,11 +749,11 @@ extern "C" int gcnpt_bilinear_planes(int M, int D, int Tin, int H, int dtype) {
     if (dtype == GCNPT_F32) {
         BilinearF32Params q{};
         bilinear_f32_plan(q, M, D, Tin, H);
-        return q.slices;
+        return q.slices * q.chunks;
     }
     BilinearParams p{};
     bilinear_plan(p, M, D, Tin, H);
-    return p.slices;
+    return p.slices * p.chunks;
 }
 
 template <int MODE>
@@ -750,7 +761,7 @@ static int bilinear_launch(hipStream_t s, BilinearParams& p) {
     const size_t lds = ((size_t)BL_RING * BL_FRAGS + BL_WAVES) * 64 * sizeof(uint4) + sizeof(float) * (BL_ROWS + 1) * (size_t)p.d_per_slice;
     if (lds > 160 * 1024) return fail(GCNPT_E_UNSUPPORTED, "bilinear: %zu B of LDS", lds);
     GCNPT_LDS_ATTR_ONCE(bilinear_fwd_kernel<MODE>, 160 * 1024);
-    hipLaunchKernelGGL(bilinear_fwd_kernel<MODE>, dim3(p.mb * p.nb * p.slices), dim3(BL_THREADS), lds, s, p);
+    hipLaunchKernelGGL(bilinear_fwd_kernel<MODE>, dim3(p.mb * p.nb * p.slices * p.chunks), dim3(BL_THREADS), lds, s, p);
     GCNPT_HIP_CHECK(hipGetLastError());
     return GCNPT_OK;
 }
@@ -761,7 +772,7 @@ extern "C" int gcnpt_bilinear_fwd(void* stream, const void* x, const float* e, c
     GCNPT_REQUIRE(M > 0 && D > 0 && Tin > 0 && H > 0, "bilinear_fwd: sizes must be positive");
     GCNPT_REQUIRE(aligned16(x) && aligned16(w_img) && aligned16(y_planes), "bilinear_fwd: x, w_img and y_planes must be 16-byte aligned");
     if (!gcnpt_bilinear_supported(D, Tin, H, dtype))
-        return fail(GCNPT_E_UNSUPPORTED, "bilinear_fwd: Tin=%d needs more k-steps per relation than the kernel keeps in registers (Tin <= 256)", Tin);
+        return fail(GCNPT_E_UNSUPPORTED, "bilinear_fwd: Tin=%d is beyond what the traversal kernels are planned for", Tin);
     if (dtype == GCNPT_F32) {
         BilinearF32Params q{};
         q.x = static_cast<const float*>(x); q.e = e; q.img = static_cast<const uint4*>(w_img); q.y = y_planes;
@@ -776,7 +787,8 @@ extern "C" int gcnpt_bilinear_fwd(void* stream, const void* x, const float* e, c
 
 extern "C" int gcnpt_bilinear_de_planes(int M, int D, int Tin, int H, int dtype) {
     if (M <= 0 || !gcnpt_bilinear_supported(D, Tin, H, dtype)) return 0;
-    return ceil_div(ceil_div(H, 16), dtype == GCNPT_BF16 ? BL_NT : BF_NT);
+    const int tsa = ceil_div(Tin, bl_kstep(dtype));
+    return ceil_div(ceil_div(H, 16), dtype == GCNPT_BF16 ? BL_NT : BF_NT) * ceil_div(tsa, dtype == GCNPT_BF16 ? BL_TSMAX : BF_TSMAX);
 }
 
 extern "C" int gcnpt_bilinear_bwd_e(void* stream, const void* x, const float* gy, const void* w_img, int M, int D, int Tin, int H,
@@ -785,7 +797,7 @@ extern "C" int gcnpt_bilinear_bwd_e(void* stream, const void* x, const float* gy
     GCNPT_REQUIRE(M > 0 && D > 0 && Tin > 0 && H > 0, "bilinear_bwd_e: sizes must be positive");
     GCNPT_REQUIRE(aligned16(x) && aligned16(w_img), "bilinear_bwd_e: x and w_img must be 16-byte aligned");
     if (!gcnpt_bilinear_supported(D, Tin, H, dtype))
-        return fail(GCNPT_E_UNSUPPORTED, "bilinear_bwd_e: Tin=%d needs more k-steps per relation than the kernel keeps in registers (Tin <= 256)", Tin);
+        return fail(GCNPT_E_UNSUPPORTED, "bilinear_bwd_e: Tin=%d is beyond what the traversal kernels are planned for", Tin);
     if (dtype == GCNPT_F32) {
         BilinearF32Params q{};
         q.x = static_cast<const float*>(x); q.e = nullptr; q.gy = gy; q.img = static_cast<const uint4*>(w_img); q.y = de_planes;

@@ -411,7 +411,8 @@ int gcnpt_compact_trees(void* stream, const int32_t* src_row_ptr, const int32_t*
  * embeddings, or ones past deprel_max_depth); y_planes [dev] float32 [gcnpt_bilinear_planes(M,D,Tin,H,dtype)][M, H], written
  * completely: the relations are split into that many slices (so that ~256 workgroups exist) and each slice leaves its partial
  * sums in its own plane -- the result is the sum of the planes (plus the bias term e @ b3, gcn.py:413).  No float atomics.
- * gcnpt_bilinear_supported: 0 when Tin needs more k-steps than the kernel keeps in registers (Tin > 256). */
+ * A wave keeps the fragments of its tokens for <= 8 k-steps (Tin <= 256 in bf16) in registers; wider inputs are cut into runs of k-steps and
+ * every run writes planes of its own (gcnpt_bilinear_planes counts them).  gcnpt_bilinear_supported: 0 only for absurd widths (> 64 k-steps). */
 size_t gcnpt_bilinear_packed_bytes(int D, int Tin, int H, int dtype);
 int gcnpt_bilinear_supported(int D, int Tin, int H, int dtype);
 int gcnpt_bilinear_pack(void* stream, const float* W, int D, int Tin, int H, void* w_img, int transposed, int dtype);

@@ -1059,7 +1059,8 @@ def _run_full(api, dev, g, c, trees_from="pruner"):
     return dict(h=f(h), mask=f(mask), dx=f(x.grad), dW=f(net.W.weight.grad), db=f(net.W.bias.grad), dE=dE)
 
 
-@pytest.mark.parametrize("M,D,Tin,H", [(1000, 50, 200, 200), (37, 6, 24, 24), (130, 16, 64, 72), (65, 9, 250, 40), (300, 200, 96, 200)])
+@pytest.mark.parametrize("M,D,Tin,H", [(1000, 50, 200, 200), (37, 6, 24, 24), (130, 16, 64, 72), (65, 9, 250, 40), (300, 200, 96, 200),
+                                       (520, 24, 300, 300), (70, 5, 600, 296)])      # hidden 300 = BASELINE configs[4]: Tin > 256, the contraction in runs
 def test_bilinear_traverse_kernel(api, dev, M, D, Tin, H):
     """gcnpt_bilinear_fwd (bf16 MFMA operands, fp32 accumulate) against the fp32 einsum of the reference's traverse_deprel
     (gcn.py:408-414), and its library-GEMM backward against autograd of that einsum."""
@@ -1077,6 +1078,7 @@ def test_bilinear_traverse_kernel(api, dev, M, D, Tin, H):
     grads = [t.grad.clone() for t in (x, e, W, b)]
     for t in (x, e, W, b):
         t.grad = None
+    assert gcn.bilinear_supported(D, Tin, H, torch.bfloat16) and gcn.bilinear_supported(D, H, Tin, torch.bfloat16)      # no torch.mm path
     got = gcn.bilinear_traverse(x, e, W, b, torch.bfloat16)
     got.backward(gy)
     assert max_rel(got.detach().cpu().numpy(), want.detach().cpu().numpy()) <= 1e-2          # bf16 operands
@@ -1099,7 +1101,8 @@ def test_bilinear_traverse_kernel(api, dev, M, D, Tin, H):
     assert max_rel(e.grad.cpu().numpy(), er.grad.cpu().numpy()) <= 2e-5
 
 
-@pytest.mark.parametrize("M,D,Tin,H", [(1000, 50, 200, 200), (37, 6, 24, 24), (130, 16, 64, 72), (65, 9, 250, 40), (300, 200, 96, 200)])
+@pytest.mark.parametrize("M,D,Tin,H", [(1000, 50, 200, 200), (37, 6, 24, 24), (130, 16, 64, 72), (65, 9, 250, 40), (300, 200, 96, 200),
+                                       (520, 24, 300, 300), (70, 5, 600, 296)])
 def test_bilinear_traverse_kernel_fp32(api, dev, M, D, Tin, H):
     """the traversal contraction (gcn.py:400-415) in EXACT fp32 MFMA (v_mfma_f32_16x16x4_f32), forward and the three
     gradients on the kernels, against the fp32 einsum of the reference's traverse_deprel and its autograd: 1e-5 forward, 1e-4 gradients

@@ -2,72 +2,20 @@
 // compiled once per (precision combination, direction) so that the ~300 instantiations build in parallel, and by rowtile_kernels.hip
 // (the C-ABI), which only needs the parameter structs.
 #pragma once
-#include "layer_common.h"
+#include "rowtile_phases.h"
 #include "wgrad_common.h"
-
-// the kernel's big outputs (rows, fragment images): plain stores, or -DGCNPT_NT_STORES=1 non-temporal ones (experiment: does leaving
-// less dirty data in the L2s shorten the launch boundary?  see DESIGN.md section 5)
-#if defined(GCNPT_NT_STORES) && GCNPT_NT_STORES
-template <typename V> __device__ __forceinline__ void gcnpt_out_store(V* p, const V& v) {
-    if constexpr (sizeof(V) == 16) {
-        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(p));
-    } else {
-        typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-        __builtin_nontemporal_store(__builtin_bit_cast(u32x2, v), reinterpret_cast<u32x2*>(p));
-    }
-}
-#define GCNPT_NT(ptr, val) gcnpt_out_store(ptr, val)
-#else
-#define GCNPT_NT_STORES 0
-#define GCNPT_NT(ptr, val) (*(ptr) = (val))
-#endif
-#define GCNPT_PLAIN(ptr, val) (*(ptr) = (val))
-// level 1: everything; 2: rows + the forward's S image (the dZ image is read by the very next launches); 3: rows only; 4: images only
-#define GCNPT_ROW_STORE(ptr, val) do { if (GCNPT_NT_STORES >= 1 && GCNPT_NT_STORES <= 3) GCNPT_NT(ptr, val); else GCNPT_PLAIN(ptr, val); } while (0)
-#define GCNPT_FRAG_STORE(bwd, ptr, val) do { if (GCNPT_NT_STORES == 1 || GCNPT_NT_STORES == 4 || (GCNPT_NT_STORES == 2 && !(bwd))) GCNPT_NT(ptr, val); else GCNPT_PLAIN(ptr, val); } while (0)
 
 namespace gcnpt {
 
-constexpr int ROWS = 32;             // token rows per workgroup (two 16-row MFMA tiles)
 constexpr int RT_THREADS = 512;      // 8 waves; wave w owns output tiles w, w+8, ...
 constexpr int RT_WAVES = RT_THREADS / WAVE;
 static_assert(RT_THREADS == 16 * ROWS, "the row store loop gives every row 16 threads (two rounds in the 4-wave form)");
-constexpr int NB_INLINE = 7;         // neighbours per row that the ELL head carries (include/gcnpt.h)
 #ifndef GCNPT_A_AHEAD
 #define GCNPT_A_AHEAD 2              // k-steps the tile's MFMA operand is read ahead of its use (measured 1..4 at the C2 shape: 51.7 / 51.1 / 51.3 / 51.7 us per step)
 #endif
 #ifndef GCNPT_W_EARLY_NUM
 #define GCNPT_W_EARLY_NUM 1          // quarters of a wave's weight fragments requested before the adjacency is known (0..4 measured: 1 is best)
 #endif
-
-struct RowTileParams {
-    const void* src;        // fwd: h [N,K]      bwd: dY [N,K]
-    const void* yref;       // bwd: Y [N,K] (stored layer output)
-    const void* wfrag;      // packed B operand, gcnpt_pack_weights
-    const float* bias;      // fwd: [NOUT]
-    const int32_t* g_row_ptr;   // pattern gathered over (fwd: A, bwd: A^T): CSR, only read for rows with > 7 entries
-    const int32_t* g_col_idx;
-    const int32_t* g_ell;       // its ELL head: [8r] = entries of row r, [8r+1..8r+7] = first columns
-    const int32_t* d_ell;       // ELL head whose [8r] gives deg (always the forward pattern A)
-    void* out;              // [N,NOUT]; NULL = only the side outputs below are wanted
-    void* frag_out;         // NULL or fragment image (include/gcnpt.h) of the tile: fwd S = (A+I)h, bwd dZ
-    float* zero_p[4];       // NULL or accumulators to clear for the weight gradients that follow (bwd: dW, db of this layer / the layer below)
-    int zero_n[4];
-    int N, T, K, NOUT, Kpad;
-    unsigned chunk_magic;   // ceil(2^32 / (Kpad / 8)): division by the chunks per row as a multiply-high
-    int vec_in, vec_out;    // vec_in: 8 / 4 / 0 elements per row load (selects the VEC instantiation); vec_out: 16 / 8 / 0 bytes per row store
-    float scale;            // bwd: 1/(1-p) of the dropout applied to Y; fwd: 1/(1-drop_p)
-    float drop_p;           // fwd
-    unsigned drop_thresh16;
-    uint64_t seed;
-    const uint64_t* seed_dev;   // NULL, or a device word added to `seed` (a counter the caller advances between graph replays)
-    const void* relu_src;       // bwd: NULL, or this layer's INPUT rows [N,NOUT] (the stored output of the layer below): the result then
-    float next_scale;           //      leaves as that layer's dZ = dh * 1[input > 0] * next_scale / (deg + 1) instead of dh
-    unsigned long long* stamps;   // diagnostic builds only
-    int knob;
-    int col_split, tiles_pp;    // column-split form only (colsplit_body.h): workgroups per row tile, column tiles each of them produces
-};
 
 // DZIN (bwd only): `src` already holds dZ (the layer above wrote it, see relu_src), so the row loader is the forward's plain
 // gather -- one load per neighbour instead of three (dY, Y, degree).
@@ -96,13 +44,8 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
     CT* Z = reinterpret_cast<CT*>(smem_raw + s_bytes);
     OT* O = reinterpret_cast<OT*>(smem_raw + s_bytes);
     int* meta = reinterpret_cast<int*>(smem_raw + s_bytes + zo_bytes);
-    int* rell = meta;                         // [ROWS][8] ELL heads of the tile's rows (count, 7 sentence-local columns)
-    float* rinv = reinterpret_cast<float*>(meta + 8 * ROWS);   // [ROWS] fwd: 1/(deg+1)   bwd: scale/(deg+1)
-    float* rden = reinterpret_cast<float*>(meta + 9 * ROWS);   // [ROWS] deg+1
-    int* glist = meta + 10 * ROWS;            // [ROWS] tile rows that aggregate at least one entry, compacted
-    int* rsb = meta + 11 * ROWS;              // [ROWS] first row of the row's sentence (b * T)
-    int* gcount = meta + 12 * ROWS;           // [1] the number of entries of glist
-    float* sbias = reinterpret_cast<float*>(meta + 13 * ROWS);   // [max(RTT, columns of a pass)] fwd: the bias of this pass's columns
+    const TileMeta m = tile_meta(meta);                         // ELL heads, denominators, the list of aggregating rows (rowtile_phases.h)
+    float* sbias = reinterpret_cast<float*>(meta + TILE_META_INTS);   // [max(RTT, columns of a pass)] fwd: the bias of this pass's columns
 
     // `wave` through readfirstlane: the compiler then knows it is uniform and does every wave-dependent address in SALU
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -112,8 +55,6 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
     const int xg = block_id & 7, xq = n_blocks >> 3, xr = n_blocks & 7;
     const int tile_id = xg * xq + min(xg, xr) + (block_id >> 3);
     const int r0 = tile_id * ROWS;
-    const IT* src = static_cast<const IT*>(p.src);
-    const IT* yref = static_cast<const IT*>(p.yref);
     const uint4* wfrag = static_cast<const uint4*>(p.wfrag);
     const int n_tiles = ceil_div(p.NOUT, 16);
     const int ksteps = p.Kpad / KSTEP;
@@ -125,37 +66,20 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
     // (1) the tile's adjacency: the 32 ELL heads (1 KiB) and the degrees for the denominators.  EVERY wave loads all of
     //     them (64 lanes x 16 bytes; waves 1..7 hit wave 0's lines) and keeps its own copy of the derived tables: the load
     //     is unconditional and first in the queue, and no wave waits for another one before it can start gathering.
-    const int erow = lane >> 1, ehalf = lane & 1;
-    const size_t er = (size_t)min(r0 + erow, p.N - 1);
-    const int4 ell_v = reinterpret_cast<const int4*>(p.g_ell)[er * 2 + ehalf];
-    const int deg_v = p.d_ell[er * 8];                                                   // gcn.py:261
-    const int sb_v = p.T ? (int)er / p.T * p.T : 0;   // the one division by T, done while the loads are on their way (T = 0: packed rows, columns are absolute)
+    const TileHeads heads = load_tile_heads(p, r0, lane);
     float bias_v = 0.0f;                           // fwd: one bias element per thread, parked in LDS with the heads (registers are
     if constexpr (!BWD) bias_v = p.bias[min(tid, p.NOUT - 1)];      // too scarce to carry 4 per tile through the whole kernel)
     float bias_w = 0.0f;                           // (4 waves x 5 tiles: 320 columns per pass, a second element for the first 64 threads)
     if constexpr (!BWD && RTW * NTW * 16 > RTT) bias_w = p.bias[min(RTT + tid, p.NOUT - 1)];
 
     // own rows of the first batch (everyone)
+    const TileGather<CT, IT, MASKED, VEC, NBU> G{p, m, S, stride, r0};
     const int nchunk = p.Kpad / 8;
-    auto div_chunk = [&](int x) { return (int)__umulhi((unsigned)x, p.chunk_magic); };    // x / nchunk, exact for x * nchunk < 2^32
     const int n_items = ROWS * nchunk;
-    // VEC: 8 = rows read 16 bytes at a time (K % 8 == 0), 4 = in 8-byte (bf16) / 16-byte (f32) halves (K % 4 == 0), 0 = element loads
-    const int kmax8 = VEC == 8 ? p.K - 8 : (VEC == 4 ? p.K - 4 : p.K - 1);
-    auto ld8 = [&](const IT* base, size_t row, int k0c, raw8<IT>& dst) {
-        if constexpr (VEC == 8) issue8<IT, true>(base, row, p.K, k0c, dst);
-        else if constexpr (VEC == 4) issue8_half<IT>(base, row, p.K, k0c, dst);
-        else issue8<IT, false>(base, row, p.K, k0c, dst);
-    };
     raw8<IT> self[ITEMS], selfy[ITEMS];
     auto issue_self = [&](int batch) {
 #pragma unroll
-        for (int u = 0; u < ITEMS; ++u) {
-            const int it = (batch * ITEMS + u) * RTT + tid;
-            const int row = div_chunk(it), k0 = (it - row * nchunk) * 8;
-            const size_t r = (size_t)min(r0 + row, p.N - 1);
-            ld8(src, r, min(k0, kmax8), self[u]);
-            if (MASKED) ld8(yref, r, min(k0, kmax8), selfy[u]);
-        }
+        for (int u = 0; u < ITEMS; ++u) G.issue_self((batch * ITEMS + u) * RTT + tid, self[u], selfy[u]);
     };
     issue_self(0);
 
@@ -191,142 +115,22 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
 
     // park the heads in LDS and compact the rows that aggregate anything (a pruned tree keeps ~1 token in 8).  All
     // waves write the same values to the same places; each reads back only after its own writes (wave_lds_fence).
-    {
-        const bool first = ehalf == 0;
-        const int e0 = (first && r0 + erow >= p.N) ? 0 : ell_v.x;                    // rows past the end aggregate nothing
-        reinterpret_cast<int4*>(rell)[erow * 2 + ehalf] = make_int4(e0, ell_v.y, ell_v.z, ell_v.w);
-        const float dn = (float)(deg_v + 1);
-        rsb[erow] = sb_v;
-        if constexpr (!BWD) {
-            sbias[tid] = bias_v;
-            if constexpr (RTW * NTW * 16 > RTT) { if (tid < RTW * NTW * 16 - RTT) sbias[RTT + tid] = bias_w; }
-        }
-        rinv[erow] = (BWD ? p.scale : 1.0f) / dn;       // both lanes of a row write it: a use under `first` only would let
-        rden[erow] = dn;                                // hipcc sink the degree load into that branch, behind a full wait
-        const bool agg = first && e0 > 0 && p.out != nullptr;
-        const unsigned long long m = __ballot(agg);
-        if (agg) glist[__popcll(m & ((1ull << lane) - 1ull))] = erow;
-        if (lane == 0) *gcount = __popcll(m);
+    park_tile_heads<BWD>(p, m, heads, r0, lane, p.out != nullptr);
+    if constexpr (!BWD) {
+        sbias[tid] = bias_v;
+        if constexpr (RTW * NTW * 16 > RTT) { if (tid < RTW * NTW * 16 - RTT) sbias[RTT + tid] = bias_w; }
     }
     GCNPT_STAMP(p.stamps, 1);
     wave_lds_fence();
     GCNPT_STAMP(p.stamps, 2);
 
-    // (2) gcn.py:269 as a gather, S[row,:] = x[row,:] + sum_{c in pattern row} x[c,:], in two maps that share one barrier:
-    //   (2a) rows that aggregate something, compacted: item gi = (list slot, 8-column chunk), so the ~4 such rows of a
-    //        tile spread over ALL waves and their neighbour loads (<= NBU per round; a pruned-tree row has 3-4 entries)
-    //        leave in ONE round trip per item.  The first 7 neighbours come from the ELL head in LDS, the (rare) rest
-    //        from col_idx; lanes without an e-th neighbour load their own row and drop it.
-    //   (2b) every other row is a plain copy of the loads issued at the top.
-    struct GItem { raw8<IT> s, sy, nb[NBU], nby[NBU]; int dcnt[NBU]; };
-    const int n_g = *gcount * nchunk;
-    auto g_decode = [&](int gi, int& row, int& k0, int& n) {
-        const bool has = gi < n_g;
-        const int li = has ? div_chunk(gi) : 0;
-        row = has ? glist[li] : 0;
-        k0 = has ? (gi - li * nchunk) * 8 : 0;
-        n = (has && k0 < p.K) ? rell[row * 8] : 0;
-        return has;
-    };
-    auto g_issue = [&](int gi, GItem& g) {
-        int row, k0, n;
-        g_decode(gi, row, k0, n);
-        const size_t r = (size_t)min(r0 + row, p.N - 1);
-        const int sbase = rsb[row];                                    // first row of this row's sentence
-        const int k0c = min(k0, kmax8);
-        ld8(src, r, k0c, g.s);
-        if (MASKED) ld8(yref, r, k0c, g.sy);
-#pragma unroll
-        for (int e = 0; e < NBU; ++e) {
-            // no e-th neighbour: the first 16 bytes of the tile's first row, one cache line for all such lanes.  (NOT the
-            // item's own row: hipcc would then reuse the load above, wait for it, and branch around the others.)
-            const bool on = e < min(n, NB_INLINE);
-            const size_t c = on ? (size_t)(sbase + rell[row * 8 + 1 + e]) : (size_t)r0;
-            const int kc = on ? k0c : 0;
-            ld8(src, c, kc, g.nb[e]);
-            if (MASKED) {
-                ld8(yref, c, kc, g.nby[e]);
-                g.dcnt[e] = p.d_ell[c * 8];
-            }
-        }
-    };
-    auto g_finish = [&](int gi, const GItem& g) {
-        int row, k0, n;
-        const bool has = g_decode(gi, row, k0, n);
-        const bool live = has && k0 < p.K;
-        const size_t rc = (size_t)min(r0 + row, p.N - 1);
-        const int sbase = rsb[row];
-        const int k0c = min(k0, kmax8);
-        float acc[8];
-        unpack8<IT>(g.s, live, acc);                                    // the explicit W(h) term, gcn.py:271
-        if (MASKED) {
-            float y[8];
-            unpack8<IT>(g.sy, live, y);
-            const float inv = rinv[row];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = (y[j] > 0.0f) ? acc[j] * inv : 0.0f;
-        }
-        const int n_ell = min(n, NB_INLINE);
-#pragma unroll
-        for (int e = 0; e < NBU; ++e) {
-            const bool on = e < n_ell;
-            float v[8];
-            unpack8<IT>(g.nb[e], on, v);
-            if (MASKED) {
-                float y[8];
-                unpack8<IT>(g.nby[e], on, y);
-                const float ninv = p.scale / (float)(g.dcnt[e] + 1);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] += (y[j] > 0.0f) ? v[j] * ninv : 0.0f;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] += v[j];
-            }
-        }
-        // rows with more than NBU entries (branching tree nodes, dense adjacency input): further round trips
-        auto round = [&](int e0, int lim, auto from_lds) {
-            raw8<IT> nb[NBU], nby[NBU];
-            float ninv[NBU];
-#pragma unroll
-            for (int e = 0; e < NBU; ++e) {
-                const bool on = e0 + e < lim;
-                size_t c;
-                if constexpr (decltype(from_lds)::value) {
-                    c = (size_t)(sbase + rell[row * 8 + 1 + min(e0 + e, NB_INLINE - 1)]);
-                } else {                                            // > 7 entries: continue in the CSR
-                    const int beg = p.T ? p.g_row_ptr[(size_t)(sbase / p.T) * (p.T + 1) + (rc - sbase)] : p.g_row_ptr[rc];
-                    c = (size_t)(sbase + p.g_col_idx[on ? beg + e0 + e : beg]);
-                }
-                c = on ? c : rc;
-                ld8(src, c, k0c, nb[e]);
-                if (MASKED) {
-                    ld8(yref, c, k0c, nby[e]);
-                    ninv[e] = p.scale / (float)(p.d_ell[c * 8] + 1);
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < NBU; ++e) {
-                const bool on = e0 + e < lim;
-                float v[8];
-                unpack8<IT>(nb[e], on, v);
-                if (MASKED) {
-                    float y[8];
-                    unpack8<IT>(nby[e], on, y);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[j] += (y[j] > 0.0f) ? v[j] * ninv[e] : 0.0f;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[j] += v[j];
-                }
-            }
-        };
-        for (int e0 = NBU; e0 < n_ell; e0 += NBU) round(e0, n_ell, std::true_type{});
-        for (int e0 = NB_INLINE; e0 < n; e0 += NBU) round(e0, n, std::false_type{});
-        if (has) tile<CT>::put8(S + (size_t)row * stride + k0, acc);
-    };
+    // (2) gcn.py:269 as a gather, S[row,:] = x[row,:] + sum_{c in pattern row} x[c,:] (TileGather, rowtile_phases.h): the rows that
+    //     aggregate something as (row, chunk) items over ALL waves, every other row a plain copy of the loads issued at the top
+    typedef GatherItem<IT, NBU> GItem;
+    const int n_g = *m.gcount * nchunk;
 
     GItem g0;
-    g_issue(tid, g0);
+    G.issue(n_g, tid, g0);
     load_w(0, 0, KS_EARLY, KSMAX);                              // 156 KB per workgroup at Din=360, H=200
     GCNPT_STAMP(p.stamps, 3);
 
@@ -334,39 +138,16 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
     const int n_batches = ceil_div(n_items, ITEMS * RTT);
     auto copy_batch = [&](int batch) {
 #pragma unroll
-        for (int u = 0; u < ITEMS; ++u) {
-            const int it = (batch * ITEMS + u) * RTT + tid;
-            if (it >= n_items) continue;
-            const int row = div_chunk(it), k0 = (it - row * nchunk) * 8;
-            const bool live = r0 + row < p.N && k0 < p.K;
-            if constexpr (!BWD && sizeof(IT) == 2 && sizeof(CT) == 2) {     // bf16 rows into a bf16 tile: the 16 bytes as they are
-                if (!(p.out && rell[row * 8] > 0))
-                    *reinterpret_cast<uint4*>(S + (size_t)row * stride + k0) = live ? self[u].a : make_uint4(0, 0, 0, 0);
-                continue;
-            }
-            float acc[8];
-            unpack8<IT>(self[u], live, acc);                            // the explicit W(h) term, gcn.py:271
-            if (MASKED) {
-                float y[8];
-                unpack8<IT>(selfy[u], live, y);
-                const float inv = rinv[row];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = (y[j] > 0.0f) ? acc[j] * inv : 0.0f;
-            }
-            if (BWD) {
-                if (p.frag_out) tile<CT>::put8(Z + (size_t)row * stride + k0, acc);
-            }
-            if (!(p.out && rell[row * 8] > 0)) tile<CT>::put8(S + (size_t)row * stride + k0, acc);   // else: (2a) writes it
-        }
+        for (int u = 0; u < ITEMS; ++u) G.template copy_item<BWD>((batch * ITEMS + u) * RTT + tid, self[u], selfy[u], Z);
     };
     copy_batch(0);
     GCNPT_STAMP(p.stamps, 4);
     // (2a) -- only the waves that own an item: the sums cost a wave ~120 VALU instructions whether its lanes are live or not
-    if (wave * WAVE < n_g) g_finish(tid, g0);
+    if (wave * WAVE < n_g) G.finish(n_g, tid, g0);
     for (int base = RTT; base < n_g; base += RTT) {      // tiles with more than 512 / (K/8) aggregating rows
         GItem g;
-        g_issue(base + tid, g);
-        g_finish(base + tid, g);
+        G.issue(n_g, base + tid, g);
+        G.finish(n_g, base + tid, g);
     }
     for (int batch = 1; batch < n_batches; ++batch) {                  // K > 384: the tile's own rows take several batches
         issue_self(batch);
@@ -378,39 +159,7 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
 
     // side outputs: the tile in MFMA fragment order for the weight gradient (rows are its contraction index),
     // and cleared accumulators for the kernel that follows
-    // emit_image: column tiles [t0, t0 + nt) of the image F from the LDS tile X whose column 0 is the image's column 16 * t0
-    auto emit_image = [&](uint4* F, auto* X, const int xstride, const int t0, const int nt, const bool bwd_store) {
-        using XT = std::remove_cv_t<std::remove_pointer_t<decltype(X)>>;
-        if constexpr (sizeof(XT) == 2) {
-            const int i = lane & 15, g = lane >> 4, q4 = i >> 2, pp = i & 3;
-            const size_t nks = n_blocks;
-            for (int t = wave; t < nt; t += RTW) {
-                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4_t*)(X + (size_t)(8 * g + q4) * xstride + 16 * t + 4 * pp));
-                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4_t*)(X + (size_t)(8 * g + 4 + q4) * xstride + 16 * t + 4 * pp));
-                uint4 u;
-                u.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
-                u.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
-                u.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
-                u.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
-                GCNPT_FRAG_STORE(bwd_store, &F[((size_t)(t0 + t) * nks + tile_id) * 64 + lane], u);
-            }
-        } else {
-            const int i = lane & 15, g = lane >> 4;
-            const size_t nks = (size_t)n_blocks * 2;
-            for (int tk = wave; tk < nt * 2; tk += RTW) {
-                const int t = tk >> 1, kk = tk & 1;
-                uint4 u;
-                u.x = __float_as_uint(X[(size_t)(16 * kk + 4 * g + 0) * xstride + 16 * t + i]);
-                u.y = __float_as_uint(X[(size_t)(16 * kk + 4 * g + 1) * xstride + 16 * t + i]);
-                u.z = __float_as_uint(X[(size_t)(16 * kk + 4 * g + 2) * xstride + 16 * t + i]);
-                u.w = __float_as_uint(X[(size_t)(16 * kk + 4 * g + 3) * xstride + 16 * t + i]);
-                GCNPT_FRAG_STORE(bwd_store, &F[((size_t)(t0 + t) * nks + 2 * tile_id + kk) * 64 + lane], u);
-            }
-        }
-    };
-    if (p.frag_out) emit_image(static_cast<uint4*>(p.frag_out), BWD ? Z : S, stride, 0, ceil_div(p.K, 16), BWD);
+    if (p.frag_out) emit_tile_image(static_cast<uint4*>(p.frag_out), BWD ? Z : S, stride, wave, RTW, ceil_div(p.K, 16), lane, (size_t)n_blocks, tile_id, BWD);
     if constexpr (BWD) {
         if (p.frag_out) __syncthreads();                         // every wave has read its share of Z: the region becomes O
     }
@@ -422,7 +171,6 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
     if (!p.out) return;
 
     // (3) + (4)
-    OT* out = static_cast<OT*>(p.out);
     const int arow = lane & 15, kgrp = lane >> 4;
     const int n_pass = ceil_div(n_tiles, RTW * NTW);
 
@@ -482,126 +230,21 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
         }
         float den[2], inv[2];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) { den[mt] = rden[mt * 16 + (lane & 15)]; inv[mt] = rinv[mt * 16 + (lane & 15)]; }
+        for (int mt = 0; mt < 2; ++mt) { den[mt] = m.rden[mt * 16 + (lane & 15)]; inv[mt] = m.rinv[mt * 16 + (lane & 15)]; }
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
             const int tl = tile0 + j * RTW;
             if (tl >= n_tiles) continue;
             const int col0 = tl * 16 + (lane >> 4) * 4;
-            const int lcol0 = col0 - pass * ncols_pass;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const int row = mt * 16 + (lane & 15);
-                float v[4];
-                float bq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                if constexpr (!BWD) {
-                    const float4 bv = *reinterpret_cast<const float4*>(sbias + lcol0);
-                    bq[0] = bv.x; bq[1] = bv.y; bq[2] = bv.z; bq[3] = bv.w;
-                }
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float x = acc[mt][j][g];
-                    if (!BWD) {
-                        x = div_by(x + 2.0f * bq[g], den[mt], inv[mt]);   // gcn.py:270-271 (the bias enters twice), 390
-                        x = x > 0.0f ? x : 0.0f;                         // gcn.py:392
-                    }
-                    v[g] = x;
-                }
-                if (!BWD && p.drop_p > 0.0f) {                            // gcn.py:393: one hash per column pair
-#pragma unroll
-                    for (int h2 = 0; h2 < 2; ++h2) {
-                        const unsigned dh = drop_hash(p.seed + seed_off, (unsigned)(r0 + row), (unsigned)(col0 >> 1) + h2);
-                        v[2 * h2] = drop_keep(dh, 0u, p.drop_thresh16) ? v[2 * h2] * p.scale : 0.0f;
-                        v[2 * h2 + 1] = drop_keep(dh, 1u, p.drop_thresh16) ? v[2 * h2 + 1] * p.scale : 0.0f;
-                    }
-                }
-                OT* dst = O + (size_t)row * ostride + lcol0;
-                if constexpr (sizeof(OT) == 2) {
-                    uint2 pk;
-                    pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-                    pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-                    *reinterpret_cast<uint2*>(dst) = pk;
-                } else {
-                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                }
-            }
+            const f32x4_t aj[2] = {acc[0][j], acc[1][j]};
+            epilogue_tile<OT, BWD>(p, aj, col0, col0 - pass * ncols_pass, r0, den, inv, sbias, O, ostride, seed_off, lane);
         }
         __syncthreads();
         GCNPT_STAMP(p.stamps, 9);
 
-        // whole rows leave in 16-byte pieces (8-byte ones when the row width only allows those: bf16 rows of 300 columns)
+        // whole rows leave in 16-byte pieces; bwd with relu_src: as the layer below's dZ (store_tile_rows, rowtile_phases.h)
         const int c_lo = pass * ncols_pass, c_hi = min(p.NOUT, c_lo + ncols_pass);
-        const int width = c_hi - c_lo;
-        const OT* relu = BWD ? static_cast<const OT*>(p.relu_src) : nullptr;
-        auto store_rows = [&](auto vtag) {
-            using V = decltype(vtag);                                       // uint4 or uint2
-            constexpr int PER = (int)sizeof(V) / (int)sizeof(OT);
-            constexpr int NW = (int)sizeof(V) / 4;
-            const int pieces = width / PER;                                  // 16 threads per row: no division, 256 contiguous bytes each round
-#pragma unroll
-            for (int rh = 0; rh < ROWS; rh += RTT / 16) {                    // (one round with 8 waves, two with 4)
-            const int row = rh + (tid >> 4), r = r0 + row;
-            if (BWD && relu) {
-                // hand-over to the layer below: its dZ instead of dh (gcn.py:390-393 differentiated where the rows are at hand);
-                // the input rows are fetched in one batch, then masked and scaled while the tile leaves LDS
-                constexpr int RP = 4;
-                const float f = p.next_scale / rden[row];
-                const size_t rr = (size_t)min(r, p.N - 1) * p.NOUT + c_lo;
-                for (int pc0 = tid & 15; pc0 < pieces; pc0 += 16 * RP) {
-                    V hin[RP];
-#pragma unroll
-                    for (int u = 0; u < RP; ++u) hin[u] = *reinterpret_cast<const V*>(relu + rr + min(pc0 + 16 * u, pieces - 1) * PER);
-#pragma unroll
-                    for (int u = 0; u < RP; ++u) {
-                        const int pc = pc0 + 16 * u;
-                        if (pc >= pieces || r >= p.N) continue;
-                        V o = *reinterpret_cast<const V*>(O + (size_t)row * ostride + pc * PER);
-                        if constexpr (sizeof(OT) == 2) {
-                            unsigned* ow = reinterpret_cast<unsigned*>(&o);
-                            const unsigned* hw = reinterpret_cast<const unsigned*>(&hin[u]);
-#pragma unroll
-                            for (int q = 0; q < NW; ++q) {
-                                const float lo = bf16_to_f32((bf16_t)(hw[q] & 0xffffu)) > 0.0f ? bf16_to_f32((bf16_t)(ow[q] & 0xffffu)) * f : 0.0f;
-                                const float hi = bf16_to_f32((bf16_t)(hw[q] >> 16)) > 0.0f ? bf16_to_f32((bf16_t)(ow[q] >> 16)) * f : 0.0f;
-                                ow[q] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
-                            }
-                        } else {
-                            float* ow = reinterpret_cast<float*>(&o);
-                            const float* hw = reinterpret_cast<const float*>(&hin[u]);
-#pragma unroll
-                            for (int q = 0; q < NW; ++q) ow[q] = hw[q] > 0.0f ? ow[q] * f : 0.0f;
-                        }
-                        GCNPT_ROW_STORE(reinterpret_cast<V*>(out + (size_t)r * p.NOUT + c_lo + pc * PER), o);
-                    }
-                }
-            } else if (r < p.N) {
-                for (int pc = tid & 15; pc < pieces; pc += 16)
-                    GCNPT_ROW_STORE(reinterpret_cast<V*>(out + (size_t)r * p.NOUT + c_lo + pc * PER),
-                                    *reinterpret_cast<const V*>(O + (size_t)row * ostride + pc * PER));
-            }
-            }
-        };
-        constexpr int PER16 = 16 / (int)sizeof(OT), PER8 = 8 / (int)sizeof(OT);
-        if (p.vec_out == 16 && (width % PER16) == 0 && (c_lo % PER16) == 0) {
-            store_rows(uint4{});
-        } else if (p.vec_out >= 8 && (width % PER8) == 0 && (c_lo % PER8) == 0) {
-            store_rows(uint2{});
-        } else {
-            for (int it = tid; it < ROWS * width; it += RTT) {
-                const int row = it / width, c = it - row * width;
-                const int r = r0 + row;
-                if (r >= p.N) continue;
-                OT v = O[(size_t)row * ostride + c];
-                if (BWD && relu) {
-                    const OT hv = relu[(size_t)r * p.NOUT + c_lo + c];
-                    float x, hx;
-                    if constexpr (sizeof(OT) == 2) { x = bf16_to_f32(v); hx = bf16_to_f32(hv); } else { x = v; hx = hv; }
-                    x = hx > 0.0f ? x * (p.next_scale / rden[row]) : 0.0f;
-                    if constexpr (sizeof(OT) == 2) v = f32_to_bf16(x); else v = x;
-                }
-                out[(size_t)r * p.NOUT + c_lo + c] = v;
-            }
-        }
+        store_tile_rows<OT, BWD, RTT>(p, O, ostride, m.rden, r0, c_lo, c_hi - c_lo, tid);
     }
     GCNPT_STAMP(p.stamps, 10);
 }

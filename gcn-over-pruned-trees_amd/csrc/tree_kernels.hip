@@ -789,6 +789,111 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_trees_kernel(const Tree
     }
 }
 
+// The same assembly straight into the TOKEN-PACKED layout (what gcnpt_pack_trees makes of gcnpt_gather_trees' arrays, bit for bit): a
+// sentence's offsets are prefix sums over the batch sentences before it, which every workgroup takes from the CACHE itself (lengths and
+// offsets of the cached sentences are all there: no inter-workgroup hand-off as in the pruner's packed form).
+struct GatherPackedDst {
+    int32_t *cu, *row_ptr, *col_idx, *label, *rowT_ptr, *colT_idx, *ell, *ellT;
+    uint8_t *pool_mask, *pool_mask_padded;
+    int32_t *row_sent, *status, *sent_status;
+    int n_rows, nnz_cap;
+};
+__global__ __launch_bounds__(GATHER_THREADS) void gather_trees_packed_kernel(const TreeArrays src, const int32_t* __restrict__ src_len,
+                                                                            int S, int Ts, int cap_s, const int64_t* __restrict__ idx,
+                                                                            int B, int T, const GatherPackedDst dst, const PackParams pk,
+                                                                            int pk_dtype) {
+    __shared__ int s_red[GATHER_THREADS / WAVE][4];
+    if ((int)blockIdx.x >= B) {
+        pack_side_job(pk, pk_dtype, B);
+        return;
+    }
+    const int b = blockIdx.x, t = threadIdx.x;
+    // what sentence j of the batch contributes: its code, rows and entries (a failed sentence: its rows, no entries -- as the padded
+    // assembly leaves it)
+    auto look = [&](int j, int& code, int& len, int& nnz, int& nnzT, size_t& s) {
+        const int64_t s64 = idx[j];
+        const bool known = s64 >= 0 && s64 < S;
+        s = known ? (size_t)s64 : 0;
+        const int l = known ? src_len[s] : 0;
+        nnz = src.row_ptr[s * (Ts + 1) + Ts] - (int)s * cap_s;
+        nnzT = src.rowT_ptr ? src.rowT_ptr[s * (Ts + 1) + Ts] - (int)s * cap_s : 0;
+        code = known ? src.status[s] : GCNPT_E_INVALID;
+        if (code == 0 && l > T) code = GCNPT_E_LENGTH;
+        if (code == 0 && (nnz > 3 * T || nnzT > 3 * T)) code = GCNPT_E_CAPACITY;
+        len = min(l, T);
+        if (code != 0) { nnz = 0; nnzT = 0; }
+    };
+    int a[4] = {0, 0, 0, 0};                                        // rows, entries, transposed entries before b; longest sentence
+    for (int j = t; j < B; j += GATHER_THREADS) {
+        int code, len, nnz, nnzT;
+        size_t s;
+        look(j, code, len, nnz, nnzT, s);
+        if (j < b) { a[0] += len; a[1] += nnz; a[2] += nnzT; }
+        const int64_t sj = idx[j];
+        a[3] = max(a[3], (sj >= 0 && sj < S) ? src_len[sj] : 0);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { a[0] += __shfl_xor(a[0], d); a[1] += __shfl_xor(a[1], d); a[2] += __shfl_xor(a[2], d); a[3] = max(a[3], __shfl_xor(a[3], d)); }
+    if ((t & 63) == 0) { s_red[t >> 6][0] = a[0]; s_red[t >> 6][1] = a[1]; s_red[t >> 6][2] = a[2]; s_red[t >> 6][3] = a[3]; }
+    __syncthreads();
+    int cu = 0, eo = 0, eoT = 0, longest = 0;
+#pragma unroll
+    for (int w = 0; w < GATHER_THREADS / WAVE; ++w) { cu += s_red[w][0]; eo += s_red[w][1]; eoT += s_red[w][2]; longest = max(longest, s_red[w][3]); }
+    int code, len, nnz, nnzT;
+    size_t s;
+    look(b, code, len, nnz, nnzT, s);
+    const bool ok = code == 0;
+    const bool fits = cu + len <= dst.n_rows && eo + nnz <= dst.nnz_cap && eoT + nnzT <= dst.nnz_cap;
+    if (t == 0) {
+        dst.cu[b] = cu;
+        dst.sent_status[b] = code;
+        if (b == 0) dst.sent_status[B] = longest;
+        if (b == B - 1) {
+            dst.cu[B] = cu + len;
+            dst.status[0] = fits ? 0 : GCNPT_E_CAPACITY;
+            dst.status[1] = cu + len;
+            if (fits) {
+                dst.row_ptr[cu + len] = eo + nnz;
+                if (dst.rowT_ptr) dst.rowT_ptr[cu + len] = eoT + nnzT;
+            }
+        }
+    }
+    if (dst.pool_mask_padded)
+        for (int i = t; i < T; i += GATHER_THREADS)
+            dst.pool_mask_padded[(size_t)b * T + i] = (ok && i < Ts) ? src.pool_mask[s * Ts + i] : (uint8_t)1;
+    if (!fits) return;
+    const int rp0 = (int)s * cap_s;
+    for (int i = t; i < len; i += GATHER_THREADS) {
+        dst.row_ptr[cu + i] = eo + (ok ? src.row_ptr[s * (Ts + 1) + i] - rp0 : 0);
+        if (dst.rowT_ptr) dst.rowT_ptr[cu + i] = eoT + (ok ? src.rowT_ptr[s * (Ts + 1) + i] - rp0 : 0);
+        dst.pool_mask[cu + i] = ok ? src.pool_mask[s * Ts + i] : (uint8_t)1;
+        dst.row_sent[cu + i] = b;
+    }
+    for (int k = t; k < nnz; k += GATHER_THREADS) {
+        dst.col_idx[eo + k] = src.col_idx[s * cap_s + k] + cu;
+        if (dst.label) dst.label[eo + k] = src.label[s * cap_s + k];
+    }
+    if (dst.colT_idx)
+        for (int k = t; k < nnzT; k += GATHER_THREADS) dst.colT_idx[eoT + k] = src.colT_idx[s * cap_s + k] + cu;
+    for (int q = t; q < 2 * len; q += GATHER_THREADS) {             // ELL heads, 16 bytes at a time: [count, c0..c2] / [c3..c6], live slots + cu
+        const int i = q >> 1, half = q & 1;
+        const size_t o = (s * Ts + i) * 2 + half;
+        auto shift = [&](const int32_t* e_src, int32_t* e_dst) {
+            const int cnt = ok ? e_src[(s * Ts + i) * 8] : 0;
+            int4 v = ok ? reinterpret_cast<const int4*>(e_src)[o] : make_int4(0, 0, 0, 0);
+            int* e = reinterpret_cast<int*>(&v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int slot = half * 4 + j - 1;                   // entry number of this word (-1 = the count)
+                if (slot >= 0) e[j] = slot < cnt ? e[j] + cu : 0;
+            }
+            reinterpret_cast<int4*>(e_dst)[((size_t)(cu + i)) * 2 + half] = v;
+        };
+        shift(src.ell, dst.ell);
+        if (dst.ellT) shift(src.ellT, dst.ellT);
+    }
+}
+
 // ---- N1: "pooled-only" rows (gcn.py:116-121 pools h over the tokens of the pruned tree only, and a tree token's row of
 // every layer depends on tree tokens only -- the adjacency has no entry outside the tree).  The kept tokens of a sentence
 // are renumbered 0..kept-1 in token order and the pattern is rewritten in those numbers for a [B, Tc] batch: the layer
@@ -1048,6 +1153,41 @@ extern "C" int gcnpt_gather_trees_pack(void* stream, const int32_t* src_row_ptr,
     return gather_impl(stream, src_row_ptr, src_col_idx, src_label, src_rowT_ptr, src_colT_idx, src_ell, src_ellT, src_pool_mask, src_status,
                        src_len, S, Ts, cap_s, idx, B, T, cap, row_ptr, col_idx, label, rowT_ptr, colT_idx, ell, ellT, pool_mask, status,
                        pk, dtype, pack_side_blocks(pk, GATHER_THREADS));
+}
+
+extern "C" int gcnpt_gather_trees_packed(void* stream, const int32_t* src_row_ptr, const int32_t* src_col_idx, const int32_t* src_label,
+                                        const int32_t* src_rowT_ptr, const int32_t* src_colT_idx, const int32_t* src_ell,
+                                        const int32_t* src_ellT, const uint8_t* src_pool_mask, const int32_t* src_status,
+                                        const int32_t* src_len, int S, int Ts, int cap_s, const int64_t* idx, int B, int T,
+                                        int32_t* cu_seqlens, int32_t* row_ptr, int32_t* col_idx, int32_t* label, int32_t* rowT_ptr,
+                                        int32_t* colT_idx, int32_t* ell, int32_t* ellT, uint8_t* pool_mask, int32_t* row_sent, int n_rows,
+                                        int nnz_cap, int32_t* status, int32_t* sent_status, uint8_t* pool_mask_padded, int n_layers,
+                                        const float* const* W, const int* H, const int* Din, int dtype, void* const* w_fwd,
+                                        void* const* w_bwd) {
+    GCNPT_REQUIRE(src_row_ptr && src_col_idx && src_ell && src_status && src_len && src_pool_mask && idx, "gather_trees_packed: null cache pointer");
+    GCNPT_REQUIRE(cu_seqlens && row_ptr && col_idx && ell && pool_mask && row_sent && status && sent_status, "gather_trees_packed: null output pointer");
+    GCNPT_REQUIRE(S > 0 && Ts > 0 && cap_s > 0 && B > 0 && T > 0 && n_rows > 0 && nnz_cap > 0, "gather_trees_packed: sizes must be positive");
+    GCNPT_REQUIRE(!label || src_label, "gather_trees_packed: labels wanted but the cache holds none");
+    GCNPT_REQUIRE((rowT_ptr == nullptr) == (colT_idx == nullptr) && (rowT_ptr == nullptr) == (ellT == nullptr),
+                  "gather_trees_packed: rowT_ptr, colT_idx and ellT go together");
+    GCNPT_REQUIRE(!rowT_ptr || (src_rowT_ptr && src_colT_idx && src_ellT), "gather_trees_packed: transposed pattern wanted but the cache holds none");
+    PackParams pk{};
+    int blocks = 0;
+    if (n_layers > 0) {
+        const int rc = fill_pack_params(pk, n_layers, W, H, Din, dtype, w_fwd, w_bwd);
+        if (rc != GCNPT_OK) return rc;
+        blocks = pack_side_blocks(pk, GATHER_THREADS);
+    }
+    const TreeArrays src{const_cast<int32_t*>(src_row_ptr), const_cast<int32_t*>(src_col_idx), const_cast<int32_t*>(src_label),
+                         const_cast<int32_t*>(rowT_ptr ? src_rowT_ptr : nullptr), const_cast<int32_t*>(src_colT_idx),
+                         const_cast<int32_t*>(src_ell), const_cast<int32_t*>(src_ellT), const_cast<uint8_t*>(src_pool_mask),
+                         const_cast<int32_t*>(src_status)};
+    const GatherPackedDst dst{cu_seqlens, row_ptr, col_idx, label, rowT_ptr, colT_idx, ell, ellT, pool_mask, pool_mask_padded, row_sent, status,
+                              sent_status, n_rows, nnz_cap};
+    hipLaunchKernelGGL(gather_trees_packed_kernel, dim3(B + blocks), dim3(GATHER_THREADS), 0, (hipStream_t)stream, src, src_len, S, Ts, cap_s, idx, B,
+                       T, dst, pk, dtype);
+    GCNPT_HIP_CHECK(hipGetLastError());
+    return GCNPT_OK;
 }
 
 extern "C" int gcnpt_compact_trees(void* stream, const int32_t* src_row_ptr, const int32_t* src_col_idx, const int32_t* src_label,

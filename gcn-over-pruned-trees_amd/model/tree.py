@@ -486,6 +486,49 @@ class TreeCache(object):
             return CompactTrees(ct, tok, self.compact.kept.index_select(0, idx.clamp(0, len(self) - 1)), int(T))
         return self._gather(self.trees, self.lens, idx, int(T), want_label, pack)
 
+    def batch_packed(self, idx, T, want_label=None, want_transpose=True, pack=None, n_rows=None, want_padded_mask=True):
+        """batch(idx, T).pack(lens[idx]) in ONE launch (gcnpt_gather_trees_packed), bit for bit.  n_rows: the batch's token count
+        (sum of min(len, T)) when the caller knows it -- the loader does; otherwise it is summed on the device (one sync)."""
+        idx = _lib.require_gpu(idx).to(torch.int64).contiguous()
+        src, B, T = self.trees, int(idx.numel()), int(T)
+        want_label = (src.label is not None) if want_label is None else want_label
+        if want_label and src.label is None:
+            raise ValueError("the cache was built without labels")
+        tr = bool(want_transpose)
+        if tr and src.rowT_ptr is None:
+            raise ValueError("the cache was built without the transposed pattern")
+        if n_rows is None:
+            ok = (idx >= 0) & (idx < len(self))
+            n_rows = int((self.lens.index_select(0, idx.clamp(0, len(self) - 1)).clamp(max=T) * ok).sum().item())
+        n_rows = max(int(n_rows), 1)
+        nnz_cap = max(3 * n_rows, 1)
+        dev = src.device
+        i32 = dict(dtype=torch.int32, device=dev)
+        cu = torch.empty((B + 1,), **i32)
+        row_ptr = torch.empty((n_rows + 1,), **i32)
+        col_idx = torch.empty((nnz_cap,), **i32)
+        label = torch.empty((nnz_cap,), **i32) if want_label else None
+        rowT_ptr = torch.empty((n_rows + 1,), **i32) if tr else None
+        colT_idx = torch.empty((nnz_cap,), **i32) if tr else None
+        ell = torch.zeros((n_rows * 8,), **i32)
+        ellT = torch.zeros((n_rows * 8,), **i32) if tr else None
+        pool_mask = torch.ones((n_rows, 1), dtype=torch.bool, device=dev)
+        row_sent = torch.zeros((n_rows,), **i32)
+        status = torch.empty((2,), **i32)
+        sent_status = torch.empty((B + 1,), **i32)
+        pm_padded = torch.empty((B, T, 1), dtype=torch.bool, device=dev) if want_padded_mask else None
+        P = _lib.ptr
+        tail = pack.c_args() if pack is not None else (0, None, None, None, 0, None, None)
+        _lib.check(_lib.lib().gcnpt_gather_trees_packed(
+            _lib.stream(), P(src.row_ptr), P(src.col_idx), P(src.label), P(src.rowT_ptr), P(src.colT_idx), P(src.ell), P(src.ellT),
+            P(src.pool_mask), P(src.status), P(self.lens), src.B, src.T, src.cap, P(idx), B, T,
+            P(cu), P(row_ptr), P(col_idx), P(label), P(rowT_ptr), P(colT_idx), P(ell), P(ellT), P(pool_mask), P(row_sent),
+            n_rows, nnz_cap, P(status), P(sent_status), P(pm_padded), *tail))
+        if pack is not None:
+            pack.launched = True
+        return PackedTrees(_PaddedInfo(B, T, pm_padded, sent_status), n_rows, nnz_cap, cu, row_ptr, col_idx, label, rowT_ptr, colT_idx,
+                           ell, ellT, pool_mask, row_sent, status)
+
     @staticmethod
     def _gather(src, lens, idx, T, want_label, pack=None):
         B = int(idx.numel())

@@ -287,6 +287,15 @@ int gcnpt_prune_to_csr_packed(void* stream, const int64_t* head, const int64_t* 
                               uint8_t* pool_mask, int32_t* row_sent, int n_rows, int nnz_cap, int32_t* status, int32_t* sent_status,
                               uint8_t* pool_mask_padded, uint64_t* sync_ws, int n_layers, const float* const* W, const int* H, const int* Din,
                               int dtype, void* const* w_fwd, void* const* w_bwd);
+/* gcnpt_gather_trees (N4: a batch from a dataset pruned once) writing the packed layout itself, likewise: what gcnpt_pack_trees makes of
+ * gcnpt_gather_trees' arrays (cap = 3 T), bit for bit, in one launch; the offsets come from the cache's own lengths and row offsets. */
+int gcnpt_gather_trees_packed(void* stream, const int32_t* src_row_ptr, const int32_t* src_col_idx, const int32_t* src_label,
+                              const int32_t* src_rowT_ptr, const int32_t* src_colT_idx, const int32_t* src_ell, const int32_t* src_ellT,
+                              const uint8_t* src_pool_mask, const int32_t* src_status, const int32_t* src_len, int S, int Ts, int cap_s,
+                              const int64_t* idx, int B, int T, int32_t* cu_seqlens, int32_t* row_ptr, int32_t* col_idx, int32_t* label,
+                              int32_t* rowT_ptr, int32_t* colT_idx, int32_t* ell, int32_t* ellT, uint8_t* pool_mask, int32_t* row_sent,
+                              int n_rows, int nnz_cap, int32_t* status, int32_t* sent_status, uint8_t* pool_mask_padded, int n_layers,
+                              const float* const* W, const int* H, const int* Din, int dtype, void* const* w_fwd, void* const* w_bwd);
 int gcnpt_pack_rows(void* stream, const void* src, int dtype, const int32_t* cu_seqlens, int B, int T, int W, void* dst);
 int gcnpt_unpack_rows(void* stream, const void* src, int dtype, const int32_t* cu_seqlens, int B, int T, int W, void* dst);
 

@@ -141,6 +141,45 @@ def test_prune_to_csr_packed_equals_pack_of_prune(api, dev, shape):
     _same_packed(again, one, (shape, "after capacity"))
 
 
+@pytest.mark.parametrize("shape", ["golden", "errors", "long"])
+def test_cache_batch_packed_equals_pack_of_batch(api, dev, shape):
+    """VERDICT r3 item 2, the cache's half: TreeCache.batch_packed (gcnpt_gather_trees_packed) gives exactly batch(idx, T).pack(lens[idx])
+    -- every array, bit for bit -- for batches with repeats, a width narrower than the cache's (sentences too long for it fail as
+    they do in the padded form), failed sentences, sentence numbers out of range, with/without labels and the transposed pattern."""
+    gcn, tree = api
+    if shape == "long":
+        tb = synthetic.random_tree_batch(23, 64, 280, "tacred", overlap_frac=0.1)
+        head, subj, obj, dep, lens = tb["head"], tb["subj_pos"], tb["obj_pos"], tb["deprel"], tb["lens"].astype(np.int64)
+    else:
+        g = load_golden("trees_random.npz" if shape == "golden" else "trees_edge_cases.npz")
+        head, subj, obj, dep, lens = g["head"], g["subj_pos"], g["obj_pos"], g["deprel"], g["lens"].astype(np.int64)
+    S, Ts = head.shape
+    cache = tree.TreeCache.build(*(_t(a, dev) for a in (head, subj, obj, dep)), 1, lens=_t(lens.astype(np.int32), dev), want_label=True)
+    rng = np.random.RandomState(5)
+    for trial in range(4):
+        B = int(rng.randint(1, 2 * S))
+        idx = rng.randint(0, S, size=B)
+        if trial == 3:
+            idx[rng.randint(0, B)] = S + 3                                # not a sentence of the cache
+        T = int(max(lens[np.minimum(idx, S - 1)].max(), 1)) if trial != 2 else max(int(np.median(lens)), 1)   # trial 2: too narrow for some
+        idx_t = _t(idx.astype(np.int64), dev)
+        bl = [int(min(lens[i], T)) if i < S else 0 for i in idx]
+        for want_label, want_T in ((True, True), (False, True), (False, False)):
+            padded = cache.batch(idx_t, T, want_label=want_label)
+            if not want_T:
+                padded = tree.PrunedTrees(padded.B, padded.T, padded.cap, padded.row_ptr, padded.col_idx, padded.label, None, None, padded.ell, None,
+                                          padded.pool_mask, padded.status)
+            two = padded.pack(bl)
+            one = cache.batch_packed(idx_t, T, want_label=want_label, want_transpose=want_T, n_rows=(None if trial & 1 else max(sum(bl), 1)))
+            torch.cuda.synchronize()
+            _same_packed(one, two, (shape, trial, want_label, want_T))
+            assert torch.equal(one.padded.status, padded.status), (shape, trial)
+            assert torch.equal(one.padded.pool_mask, padded.pool_mask), (shape, trial)
+    small = cache.batch_packed(idx_t, T, n_rows=max(sum(bl) - 2, 1))
+    torch.cuda.synchronize()
+    assert int(small.status[0]) == -8                                   # GCNPT_E_CAPACITY: reported, not overrun
+
+
 @pytest.mark.parametrize("width,dtype", [(360, torch.float32), (300, torch.bfloat16), (200, torch.bfloat16), (7, torch.float32)])
 def test_pack_unpack_rows_roundtrip(api, dev, width, dtype):
     gcn, tree = api

@@ -7,13 +7,13 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 200 --warmup 20 --launch native --no-cpu-baseline --no-kernel-breakdown --no-pooled-only --no-secondary --no-secondary-shapes"
+ARGS="--steps 200 --warmup 20 --launch native --no-cpu-baseline --no-kernel-breakdown --no-pooled-only --no-secondary --no-secondary-shapes --repeats 1"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $ARGS > $OUT/trace.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_graph -- python3 $R/bench.py --steps 200 --warmup 20 --launch graph --no-cpu-baseline --no-kernel-breakdown --no-pooled-only --no-secondary --no-secondary-shapes > $OUT/trace_graph.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_graph -- python3 $R/bench.py --steps 200 --warmup 20 --launch graph --no-cpu-baseline --no-kernel-breakdown --no-pooled-only --no-secondary --no-secondary-shapes --repeats 1 > $OUT/trace_graph.log 2>&1 || exit 1
 C5="--batch 128 --seq 300 --din 600 --hidden 300 --prune-k 2"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_c5 -- python3 $R/bench.py $C5 --steps 100 --warmup 10 --launch native --no-cpu-baseline --no-kernel-breakdown --no-pooled-only --no-secondary --no-secondary-shapes > $OUT/trace_c5.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_c5_packed -- python3 $R/bench.py $C5 --lengths tacred --layout packed --steps 100 --warmup 10 --launch native --no-cpu-baseline --no-kernel-breakdown --no-pooled-only --no-secondary-shapes > $OUT/trace_c5_packed.log 2>&1 || exit 1
-PMC="--steps 30 --warmup 5 --launch native --no-cpu-baseline --no-kernel-breakdown --no-pooled-only --no-secondary --no-secondary-shapes"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_c5 -- python3 $R/bench.py $C5 --steps 100 --warmup 10 --launch native --no-cpu-baseline --no-kernel-breakdown --no-pooled-only --no-secondary --no-secondary-shapes --repeats 1 > $OUT/trace_c5.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_c5_packed -- python3 $R/bench.py $C5 --lengths tacred --layout packed --steps 100 --warmup 10 --launch native --no-cpu-baseline --no-kernel-breakdown --no-pooled-only --no-secondary-shapes --repeats 1 > $OUT/trace_c5_packed.log 2>&1 || exit 1
+PMC="--steps 30 --warmup 5 --launch native --no-cpu-baseline --no-kernel-breakdown --no-pooled-only --no-secondary --no-secondary-shapes --repeats 1"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $R/bench.py $PMC > $OUT/fetch.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 $R/bench.py $PMC > $OUT/write.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $OUT/sq -- python3 $R/bench.py $PMC > $OUT/sq.log 2>&1 || exit 1

@@ -1,7 +1,7 @@
 // The row-tile layer kernel for SMALL batches of WIDE layers: every 32-row tile is given to `col_split` workgroups that gather the same rows
 // and each produce `tiles_pp` of the layer's output column tiles.
 //
-// Why: the one-tile-per-workgroup kernel of rowtile_body.h pulls ALL weight fragments of the layer through its CU's
+// Why (EXPERIMENTS.md): the one-tile-per-workgroup kernel of rowtile_body.h pulls ALL weight fragments of the layer through its CU's
 // L1 path (~20 B per clock and CU) -- 360 KB at the C5 input layer, next to 50 KB of rows -- and when a batch has a few dozen row tiles
 // (BASELINE configs[4] on 8 GPUs: 16 sentences per GPU, token-packed: 25 tiles) nine CUs in ten have no tile at all while the others
 // wait for their weights.  Split 3 ... 8 ways by output COLUMNS a workgroup takes in 45 ... 120 KB of weights; the rows are gathered

@@ -260,9 +260,9 @@ __global__ __launch_bounds__(NWV * WAVE, 2) void rowtile_kernel(const RowTilePar
 // earlier launches have left (dZ_{l+1}, S_{l+1}), and a batch of <= ~6 k rows leaves a third of the CUs without a row tile.  Workgroups [0, n_tiles) are row tiles, workgroups
 // [wg_first, gridDim.x) (wg_first = n_tiles rounded up to 8, so that the weight gradient's block -> XCD map holds) contract one slice of
 // one output block each.  The last launch of the sweep is then the bottom layer's weight gradient alone: 7.5 us instead of 13.0 us for
-// both layers.
+// both layers (EXPERIMENTS.md).
 // The weight gradient that rides: ONE layer's, planned for the CUs without a row tile (weight_grad_body of wgrad_common.h, (4 x 3)-tile
-// blocks, XCD-aware slice map).  Measured in round 3 and NOT adopted (profiles/r03_riders_*): both layers' gradients in
+// blocks, XCD-aware slice map).  Measured in round 3 and NOT adopted (EXPERIMENTS.md, profiles/r03_riders_*): both layers' gradients in
 // the bottom layer's launch (the dZ image of the layer below written by the hand-over epilogue) -- 22 us for that launch with (4 x 3)
 // blocks, 19 with (4 x 6), 20.5 with every CU sharing the units, 29 with an LDS-staged rows-form kernel -- against 10.5 + 7.5 us for this
 // launch plus the bottom layer's own: a CU retires ~1 float atomic per clock and a workgroup's fragment stream ~25 B per clock, so a

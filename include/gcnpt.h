@@ -345,7 +345,7 @@ int gcnpt_layers_bwd_dz(void* stream, int n_layers, const void* dz_top, const vo
  * rows) the gradient rides in the same launch, on the CUs that have no row tile (one launch boundary less on the step's critical path: the
  * last launch of a backward sweep is then the bottom layer's weight gradient alone); otherwise it is launched right after.
  * gcnpt_layers_bwd / _bwd_dz do this for every layer but the top one.  (Round 3 measured putting BOTH gradients of a two-layer sweep into
- * the bottom layer's launch, four ways: slower every time) */
+ * the bottom layer's launch, four ways: slower every time, EXPERIMENTS.md.) */
 int gcnpt_layer_bwd_data_wgrad(void* stream, const void* dY, const void* Y, int g_dtype, const void* w_bwd, const int32_t* ell,
                                const int32_t* rowT_ptr, const int32_t* colT_idx, const int32_t* ellT, int B, int T, int Din, int H,
                                void* dh, int dh_dtype, int compute_dtype, float scale, void* z_frag, float* zero_dW, float* zero_db,

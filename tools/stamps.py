@@ -64,7 +64,7 @@ def main():
         stack.step_native()
     torch.cuda.synchronize()
     # the tree build (slots: 0 entry, 1 parse staged, 2 entity chains, 3 LCA, 4 distances, 5 degrees + scans, 6 row info, 8 -> 7 rows emitted)
-    if args.layout != "packed":                     # (the token-packed layout's trees come from pack_trees, not from the tree build)
+    if True:                                        # (padded: gcnpt_prune_to_csr; packed: gcnpt_prune_to_csr_packed)
         for _ in range(3):
             stack.prune()
         torch.cuda.synchronize()

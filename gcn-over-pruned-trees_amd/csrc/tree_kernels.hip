@@ -296,8 +296,8 @@ __device__ void prune_sentence(const int64_t* __restrict__ head, const int64_t* 
             const int he = (i < len && (pw[i] & (F_HASEDGE << PW_SHIFT))) ? 1 : 0;
             deg[i] += he; degT[i] += he;                             // the 84 on the diagonal
             rank[i] = he;
-            if (po.cu) { if (po.pool_mask_padded) po.pool_mask_padded[base + i] = (deg[i] + degT[i]) == 0; }
-            else if (pool_mask) pool_mask[base + i] = (deg[i] + degT[i]) == 0;   // gcn.py:262
+            uint8_t* pm = po.cu ? po.pool_mask_padded : pool_mask;
+            if (pm) pm[base + i] = (deg[i] + degT[i]) == 0;                      // gcn.py:262
         }
         phase_sync();
         if (!ALLW || threadIdx.x < WAVE) {                           // the three scans: one wave (lane l owns a contiguous segment)
@@ -312,80 +312,48 @@ __device__ void prune_sentence(const int64_t* __restrict__ head, const int64_t* 
     GCNPT_STAMP(stamps, 5);
 
     // ---- where this sentence's rows and entries go.  Padded layout: slots of its own (rows b*T.., entries b*cap..).  Packed: behind
-    //      the sentences before it (see PackedOut)
-    size_t rbase = base;                    // first row
-    int ebase = b * cap, eTbase = b * cap;   // first entry of the two patterns
-    int cshift = 0, nrw = T;                // added to every column; rows this sentence writes
-    bool fits = true;
+    //      the sentences before it (see PackedOut): the counts are published HERE, the offsets are taken as late as possible -- in
+    //      emit_rows(), after the rows have been sorted in registers --, so that waiting for a slower sentence costs nothing
+    const size_t rbase = base;              // first row
+    const int ebase = b * cap, eTbase = b * cap;   // first entry of the two patterns
     if (po.cu) {
         const int my_nnz = err ? 0 : deg[T], my_nnzT = err ? 0 : degT[T];
-        if (threadIdx.x == 0)
+        if (threadIdx.x == 0) {
             __hip_atomic_store(po.sync + b, PK_VALID | ((unsigned long long)len << 40) | ((unsigned long long)my_nnz << 20) | (unsigned long long)my_nnzT,
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int a0 = 0, a1 = 0, a2 = 0;
-        for (int j = t0; j < b; j += NT) {
-            unsigned long long v = __hip_atomic_load(po.sync + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            while (!(v & PK_VALID)) {
-                __builtin_amdgcn_s_sleep(2);
-                v = __hip_atomic_load(po.sync + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            a0 += (int)((v >> 40) & 0xffff); a1 += (int)((v >> 20) & 0xfffff); a2 += (int)(v & 0xfffff);
+            s_out[0] = len; s_out[1] = my_nnz; s_out[2] = my_nnzT;
+            status[b] = err; *s_status = err; *s_nrows = err ? 0 : n_edge_rows;
         }
-        a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
-        if constexpr (ALLW) {                                          // (the workgroup-wide sums of the earlier phases are consumed: s_red is free)
-            __syncthreads();
-            if (threadIdx.x == 0) { s_red[0] = 0; s_red[1] = 0; s_red[2] = 0; }
-            __syncthreads();
-            if (lane == 0) { atomicAdd(&s_red[0], a0); atomicAdd(&s_red[1], a1); atomicAdd(&s_red[2], a2); }
-            __syncthreads();
-            a0 = s_red[0]; a1 = s_red[1]; a2 = s_red[2];
-        }
-        // every sentence has been polled by this workgroup: the last one to get here leaves the workspace zeroed for the next launch
-        int done = 0;
-        if (threadIdx.x == 0) done = (int)atomicAdd(po.sync + B + 1, 1ull);
-        done = __builtin_amdgcn_readfirstlane(done);
-        if constexpr (ALLW) { if (threadIdx.x == 0) s_red[3] = done; __syncthreads(); done = s_red[3]; }
-        if (done == B - 1)
-            for (int j = t0; j < B + 2; j += NT) po.sync[j] = 0ull;
-        rbase = (size_t)a0; ebase = a1; eTbase = a2; cshift = a0; nrw = len;
-        fits = a0 + len <= po.n_rows && a1 + my_nnz <= po.nnz_cap && a2 + my_nnzT <= po.nnz_cap;
-        if (threadIdx.x == 0) {
-            po.cu[b] = a0;
-            if (b == B - 1) {                                          // the totals: the one writer of the batch-level results
-                po.cu[B] = a0 + len;
-                po.pk_status[0] = fits ? 0 : GCNPT_E_CAPACITY;         // (offsets grow with b: the last sentence fits iff all do)
-                po.pk_status[1] = a0 + len;
-                if (fits) {
-                    row_ptr[a0 + len] = a1 + my_nnz;
-                    if (rowT_ptr) rowT_ptr[a0 + len] = a2 + my_nnzT;
-                }
-            }
-        }
-        if (!fits) {                                                   // nothing of this sentence is written (gcnpt_pack_trees' rule)
-            if (threadIdx.x == 0) { status[b] = err; *s_status = GCNPT_E_CAPACITY; }
+        if (err) {
+            if (po.pool_mask_padded)
+                for (int i = t0; i < T; i += NT) po.pool_mask_padded[base + i] = 1;
             return;
         }
-        for (int i = t0; i < len; i += NT) {
-            po.row_sent[a0 + i] = b;
-            if (pool_mask) pool_mask[a0 + i] = err ? 1 : ((deg[i + 1] - deg[i]) + (degT[i + 1] - degT[i])) == 0;
+        for (int i = t0; i < len; i += NT) {                         // the compacted edge rows (see below); every global write waits
+            const int w = pw[i];
+            if (w & (F_HASEDGE << PW_SHIFT)) {
+                const int f = w >> PW_SHIFT;
+                einfo[rank[i]] = i | ((w & PW_MASK) << 12) | ((cnt[i] & K_CHILD) ? 1 << 24 : 0) |
+                                 ((f & F_FWD_NZ) ? 1 << 25 : 0) | ((f & F_REV_NZ) ? 1 << 26 : 0);
+            }
         }
-        if (err && po.pool_mask_padded)
-            for (int i = t0; i < T; i += NT) po.pool_mask_padded[base + i] = 1;
+        if constexpr (!ALLW) wave_lds_fence();
+        GCNPT_STAMP(stamps, 6);
+        return;
     }
     // row_ptr index of this sentence's row 0 (the padded layout keeps T + 1 offsets per sentence)
-    const size_t rp0 = po.cu ? rbase : (size_t)b * (T + 1);
-    const int n_off = po.cu ? nrw : T + 1;                             // offsets it writes (packed: the next sentence writes the closing one)
-    if (threadIdx.x == 0) { s_out[0] = (int)rbase; s_out[1] = ebase; s_out[2] = eTbase; s_out[3] = cshift; }
+    const size_t rp0 = (size_t)b * (T + 1);
+    const int n_off = T + 1;
+    if (threadIdx.x == 0) { s_out[0] = (int)rbase; s_out[1] = ebase; s_out[2] = eTbase; s_out[3] = 0; }
 
     if (err) {   // the sentence contributes no edges; every row is empty and masked
         for (int i = t0; i < n_off; i += NT) {
             row_ptr[rp0 + i] = ebase;
             if (rowT_ptr) rowT_ptr[rp0 + i] = eTbase;
         }
-        if (!po.cu)
-            for (int i = t0; i < T; i += NT)
-                if (pool_mask) pool_mask[base + i] = 1;
-        for (int i = t0; i < nrw * 8; i += NT) {
+        for (int i = t0; i < T; i += NT)
+            if (pool_mask) pool_mask[base + i] = 1;
+        for (int i = t0; i < T * 8; i += NT) {
             ell[rbase * 8 + i] = 0;
             if (ellT) ellT[rbase * 8 + i] = 0;
         }
@@ -406,7 +374,7 @@ __device__ void prune_sentence(const int64_t* __restrict__ head, const int64_t* 
             const int f = w >> PW_SHIFT;
             einfo[rank[i]] = i | ((w & PW_MASK) << 12) | ((cnt[i] & K_CHILD) ? 1 << 24 : 0) |
                              ((f & F_FWD_NZ) ? 1 << 25 : 0) | ((f & F_REV_NZ) ? 1 << 26 : 0);
-        } else if (i < nrw) {                                        // no entries: an all-zero ELL head
+        } else {                                                     // no entries: an all-zero ELL head
             int4* e = reinterpret_cast<int4*>(ell + (rbase + i) * 8);
             e[0] = make_int4(0, 0, 0, 0); e[1] = make_int4(0, 0, 0, 0);
             if (ellT) {
@@ -472,10 +440,19 @@ __device__ __forceinline__ void emit_row_scan(size_t base, int ebase, int eTbase
 // Otherwise: one row at a time per wave, one candidate column per lane (emit_row_scan) -- O(rows^2 / 64) wave iterations, which at
 // T = 300, K = 2 was 11-25 k cycles of the sentence's 29-43 k.
 constexpr int EMIT_SORT_MAX = 12;
-__device__ void emit_rows(const int* s_out, int T, int* smem, int err, int n_edge_rows, int lane, int wave, bool staged,
+// What emit_rows() needs beyond the entry arrays when the output is token-packed: the sentence's offsets are resolved INSIDE it.
+struct PackedEmit {
+    PackedOut po;
+    int b, B;
+    int32_t *row_ptr, *rowT_ptr, *status;
+    uint8_t* pool_mask;
+    int *s_red, *s_status;
+};
+__device__ void emit_rows(int* s_out, int T, int* smem, int err, int n_edge_rows, int lane, int wave, bool staged,
                           int32_t* __restrict__ col_idx, int32_t* __restrict__ label, int32_t* __restrict__ colT_idx,
-                          int32_t* __restrict__ ell, int32_t* __restrict__ ellT, unsigned long long* stamps) {
-    if (err) return;
+                          int32_t* __restrict__ ell, int32_t* __restrict__ ellT, unsigned long long* stamps, const PackedEmit& pe) {
+    const bool packed = pe.po.cu != nullptr;
+    if (err && !packed) return;
     GCNPT_STAMP(stamps, 8);
     int* cnt = smem + T;               // free after the pruning phases: fill counter of the forward rows
     int* deg = smem + 2 * T;
@@ -483,9 +460,79 @@ __device__ void emit_rows(const int* s_out, int T, int* smem, int err, int n_edg
     int* rank = degT + T + 1;          // free as well: fill counter of the transposed rows
     int* lab = rank + T + 1;
     int* einfo = lab + T;
-    const size_t base = (size_t)s_out[0];                  // first row, first entries of the two patterns, column shift (prune_sentence)
-    const int ebase = s_out[1], eTbase = s_out[2], cshift = s_out[3];
-    if (staged && n_edge_rows > WAVE) {          // (up to 64 edge rows the scan form is as fast: 4.7 k against 5.3 k cycles at T = 100, K = 1)
+    size_t base = (size_t)s_out[0];                        // first row, first entries of the two patterns, column shift (prune_sentence)
+    int ebase = s_out[1], eTbase = s_out[2], cshift = s_out[3];
+    int done = -1;                                         // (thread 0, packed) how many workgroups had resolved before this one
+
+    // Token-packed output: the look-back of PackedOut.  Sums the words of the sentences before this one (spinning on their valid bits),
+    // then writes everything of the sentence that is not an entry of an edge row: cu, row offsets, empty ELL heads, masks, sentence ids.
+    // All threads; false = the sentence does not fit the caller's arrays (nothing of it is written: gcnpt_pack_trees' rule).
+    auto resolve = [&]() -> bool {
+        const PackedOut& po = pe.po;
+        const int b = pe.b, B = pe.B;
+        const int len = s_out[0], my_nnz = s_out[1], my_nnzT = s_out[2];
+        int a0 = 0, a1 = 0, a2 = 0;
+        for (int j = threadIdx.x; j < b; j += PRUNE_THREADS) {
+            unsigned long long v = __hip_atomic_load(po.sync + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (!(v & PK_VALID)) {
+                __builtin_amdgcn_s_sleep(2);
+                v = __hip_atomic_load(po.sync + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            a0 += (int)((v >> 40) & 0xffff); a1 += (int)((v >> 20) & 0xfffff); a2 += (int)(v & 0xfffff);
+        }
+        a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+        __syncthreads();                                               // (s_out and the sums of the pruning phases are consumed)
+        if (threadIdx.x == 0) { pe.s_red[0] = 0; pe.s_red[1] = 0; pe.s_red[2] = 0; }
+        __syncthreads();
+        if (lane == 0 && (a0 | a1 | a2)) { atomicAdd(&pe.s_red[0], a0); atomicAdd(&pe.s_red[1], a1); atomicAdd(&pe.s_red[2], a2); }
+        __syncthreads();
+        a0 = pe.s_red[0]; a1 = pe.s_red[1]; a2 = pe.s_red[2];
+        // this workgroup has polled every sentence before it: the last one to get here leaves the workspace zeroed (finish(), below; the
+        // counter's old value is only looked at there, so its round trip is off the sentence's critical path)
+        if (threadIdx.x == 0) done = (int)atomicAdd(po.sync + B + 1, 1ull);
+        base = (size_t)a0; ebase = a1; eTbase = a2; cshift = a0;
+        const bool fits = a0 + len <= po.n_rows && a1 + my_nnz <= po.nnz_cap && a2 + my_nnzT <= po.nnz_cap;
+        if (threadIdx.x == 0) {
+            po.cu[b] = a0;
+            if (b == B - 1) {                                          // the totals: the one writer of the batch-level results
+                po.cu[B] = a0 + len;
+                po.pk_status[0] = fits ? 0 : GCNPT_E_CAPACITY;         // (offsets grow with b: the last sentence fits iff all do)
+                po.pk_status[1] = a0 + len;
+                if (fits) {
+                    pe.row_ptr[a0 + len] = a1 + my_nnz;
+                    if (pe.rowT_ptr) pe.rowT_ptr[a0 + len] = a2 + my_nnzT;
+                }
+            }
+            if (!fits) *pe.s_status = GCNPT_E_CAPACITY;
+        }
+        if (!fits) return false;
+        for (int i = threadIdx.x; i < len; i += PRUNE_THREADS) {
+            po.row_sent[a0 + i] = b;
+            pe.row_ptr[a0 + i] = a1 + (err ? 0 : deg[i]);
+            if (pe.rowT_ptr) pe.rowT_ptr[a0 + i] = a2 + (err ? 0 : degT[i]);
+            if (pe.pool_mask) pe.pool_mask[a0 + i] = err ? 1 : ((deg[i + 1] - deg[i]) + (degT[i + 1] - degT[i])) == 0;
+            if (err || !(smem[i] & (F_HASEDGE << PW_SHIFT))) {         // no entries: an all-zero ELL head
+                int4* e = reinterpret_cast<int4*>(ell + (size_t)(a0 + i) * 8);
+                e[0] = make_int4(0, 0, 0, 0); e[1] = make_int4(0, 0, 0, 0);
+                if (ellT) {
+                    int4* eT = reinterpret_cast<int4*>(ellT + (size_t)(a0 + i) * 8);
+                    eT[0] = make_int4(0, 0, 0, 0); eT[1] = make_int4(0, 0, 0, 0);
+                }
+            }
+        }
+        return true;
+    };
+    auto finish = [&]() {
+        if (packed && threadIdx.x == 0 && done == pe.B - 1)
+            for (int j = 0; j < pe.B + 2; ++j) pe.po.sync[j] = 0ull;
+    };
+    if (err) {                                                         // (packed) an empty sentence still has its rows
+        resolve();
+        finish();
+        return;
+    }
+
+    if (staged && (n_edge_rows > WAVE || packed)) {          // (up to 64 edge rows the scan form is as fast: 4.7 k against 5.3 k cycles at T = 100, K = 1)
         int* entF = einfo + T;         // [nnz]  forward entries: column (the label follows from the pair, see below)
         int* entT = entF + 3 * T;      // [nnzT] transposed entries: column
         int* longrows = entT + 3 * T;  // [<= T / EMIT_SORT_MAX + 1] edge rows left to the scan form; [T-1] (end of the region) = their count
@@ -510,46 +557,65 @@ __device__ void emit_rows(const int* s_out, int T, int* smem, int err, int n_edg
             }
         }
         __syncthreads();
-        for (int q = threadIdx.x; q < n_edge_rows; q += PRUNE_THREADS) {
-            const int r = einfo[q] & 0xfff;
-            const int o = deg[r], n = deg[r + 1] - o, oT = degT[r], nT = degT[r + 1] - oT;
-            if (n > EMIT_SORT_MAX || nT > EMIT_SORT_MAX) { longrows[atomicAdd(n_long, 1)] = q; continue; }
-            int v[EMIT_SORT_MAX], vT[EMIT_SORT_MAX];
+        // a thread's edge row: its entries sorted by column in registers (sort_row), then written with its ELL head (write_row).  Packed
+        // output, one row per thread at most: the offsets are resolved BETWEEN the two, so a sentence that has to wait for a slower one
+        // before it waits with its rows sorted
+        struct Row { int r, o, n, oT, nT; int v[EMIT_SORT_MAX], vT[EMIT_SORT_MAX]; };
+        auto sort_row = [&](int q, Row& w) -> bool {
+            w.r = einfo[q] & 0xfff;
+            w.o = deg[w.r]; w.n = deg[w.r + 1] - w.o; w.oT = degT[w.r]; w.nT = degT[w.r + 1] - w.oT;
+            if (w.n > EMIT_SORT_MAX || w.nT > EMIT_SORT_MAX) { longrows[atomicAdd(n_long, 1)] = q; return false; }
 #pragma unroll
             for (int k = 0; k < EMIT_SORT_MAX; ++k) {
-                v[k] = k < n ? entF[o + k] : 0x7fffffff;
-                vT[k] = k < nT ? entT[oT + k] : 0x7fffffff;
+                w.v[k] = k < w.n ? entF[w.o + k] : 0x7fffffff;
+                w.vT[k] = k < w.nT ? entT[w.oT + k] : 0x7fffffff;
             }
             // (a fixed odd-even transposition network keeps the arrays in registers; unused slots hold INT_MAX and stay behind)
 #pragma unroll
             for (int pass = 0; pass < EMIT_SORT_MAX; ++pass)
 #pragma unroll
                 for (int k = pass & 1; k + 1 < EMIT_SORT_MAX; k += 2) {
-                    const bool sw = v[k] > v[k + 1];
-                    const int lo = sw ? v[k + 1] : v[k], hi = sw ? v[k] : v[k + 1];
-                    v[k] = lo; v[k + 1] = hi;
-                    const bool swT = vT[k] > vT[k + 1];
-                    const int loT = swT ? vT[k + 1] : vT[k], hiT = swT ? vT[k] : vT[k + 1];
-                    vT[k] = loT; vT[k + 1] = hiT;
+                    const bool sw = w.v[k] > w.v[k + 1];
+                    const int lo = sw ? w.v[k + 1] : w.v[k], hi = sw ? w.v[k] : w.v[k + 1];
+                    w.v[k] = lo; w.v[k + 1] = hi;
+                    const bool swT = w.vT[k] > w.vT[k + 1];
+                    const int loT = swT ? w.vT[k + 1] : w.vT[k], hiT = swT ? w.vT[k] : w.vT[k + 1];
+                    w.vT[k] = loT; w.vT[k + 1] = hiT;
                 }
+            return true;
+        };
+        auto write_row = [&](const Row& w) {
+            const int r = w.r, o = w.o, n = w.n, oT = w.oT, nT = w.nT;
             int hd[8], hdT[8];
             hd[0] = n; hdT[0] = nT;
 #pragma unroll
             for (int k = 0; k < EMIT_SORT_MAX; ++k) {
                 if (k < n) {
-                    const int j = v[k];
+                    const int j = w.v[k];
                     col_idx[ebase + o + k] = j + cshift;
                     // the value tree_to_adj wrote there (tree.py:184-192): 84 on the diagonal, deprel[j] for a child j, deprel[r] + 42 for the parent
                     if (label) label[ebase + o + k] = j == r ? SELF_LOOP_ID : (pw_par(smem[j]) == r ? lab[j] : lab[r] + FWD_BOUND);
                 }
-                if (k < nT && colT_idx) colT_idx[eTbase + oT + k] = vT[k] + cshift;
-                if (k < 7) { hd[1 + k] = k < n ? v[k] + cshift : 0; hdT[1 + k] = k < nT ? vT[k] + cshift : 0; }
+                if (k < nT && colT_idx) colT_idx[eTbase + oT + k] = w.vT[k] + cshift;
+                if (k < 7) { hd[1 + k] = k < n ? w.v[k] + cshift : 0; hdT[1 + k] = k < nT ? w.vT[k] + cshift : 0; }
             }
             int4* e = reinterpret_cast<int4*>(ell + (base + r) * 8);
             e[0] = make_int4(hd[0], hd[1], hd[2], hd[3]); e[1] = make_int4(hd[4], hd[5], hd[6], hd[7]);
             if (ellT) {
                 int4* eT = reinterpret_cast<int4*>(ellT + (base + r) * 8);
                 eT[0] = make_int4(hdT[0], hdT[1], hdT[2], hdT[3]); eT[1] = make_int4(hdT[4], hdT[5], hdT[6], hdT[7]);
+            }
+        };
+        if (packed && n_edge_rows <= PRUNE_THREADS) {
+            Row w;
+            const bool mine = (int)threadIdx.x < n_edge_rows && sort_row(threadIdx.x, w);
+            if (!resolve()) { finish(); return; }
+            if (mine) write_row(w);
+        } else {
+            if (packed && !resolve()) { finish(); return; }
+            for (int q = threadIdx.x; q < n_edge_rows; q += PRUNE_THREADS) {
+                Row w;
+                if (sort_row(q, w)) write_row(w);
             }
         }
         __syncthreads();
@@ -560,8 +626,10 @@ __device__ void emit_rows(const int* s_out, int T, int* smem, int err, int n_edg
             emit_row_scan(base, ebase, eTbase, cshift, lab, einfo, n_edge_rows, lane, me, lab[r], deg[r], degT[r], col_idx, label, colT_idx, ell, ellT);
         }
         GCNPT_STAMP(stamps, 7);
+        finish();
         return;
     }
+    if (packed && !resolve()) { finish(); return; }
     for (int q0 = 0; q0 < n_edge_rows; q0 += WAVE) {                  // rows, a chunk of 64 at a time (registers)
         const int rw = q0 + lane < n_edge_rows ? einfo[q0 + lane] : 0;
         const int rdeg = deg[rw & 0xfff], rdegT = degT[rw & 0xfff], rlab = lab[rw & 0xfff];
@@ -572,6 +640,7 @@ __device__ void emit_rows(const int* s_out, int T, int* smem, int err, int n_edg
         }
     }
     GCNPT_STAMP(stamps, 7);
+    finish();
 }
 
 __global__ __launch_bounds__(PRUNE_THREADS) void prune_to_csr_kernel(
@@ -628,7 +697,9 @@ __global__ __launch_bounds__(PRUNE_THREADS) void prune_to_csr_kernel(
                                               &s_nrows, s_red, row_ptr, rowT_ptr, ell, ellT, pool_mask, status, stamps, po, s_out);
     __syncthreads();
     if (b == 0 && threadIdx.x == 0 && (long long)B * T <= PRUNE_SCAN_MAX && first_idle < PRUNE_THREADS / WAVE) status[B] = s_maxlen;
-    emit_rows(s_out, T, smem, s_status, s_nrows, lane, wave, staged != 0, col_idx, label, colT_idx, ell, ellT, stamps);
+    const PackedEmit pe{po, b, B, row_ptr, rowT_ptr, status, pool_mask, s_red, &s_status};
+    emit_rows(s_out, T, smem, s_status, s_nrows, lane, wave, staged != 0, col_idx, label, colT_idx, ell, ellT, stamps, pe);
+    // (packed output that did not fit: the per-sentence code stays what the pruning found; the batch-level status says E_CAPACITY)
 }
 
 // ---- dense float adjacency -> CSR of (adj != 0) and of its transpose (gcn.py:260-262) -----------------

@@ -141,6 +141,46 @@ def test_prune_to_csr_packed_equals_pack_of_prune(api, dev, shape):
     _same_packed(again, one, (shape, "after capacity"))
 
 
+def test_prune_to_csr_packed_random_shapes(api, dev):
+    """The look-back of the packed pruner under many grid shapes: 40 random (B, T, K, length profile) batches -- one sentence to more
+    sentences than the chip holds workgroups, widths on both sides of the wave-0 / all-waves switch, zero-length sentences, corrupted
+    parses (a failing sentence still owns its rows) -- every array equal to the two-step form, the workspace reused throughout."""
+    gcn, tree = api
+    rng = np.random.RandomState(99)
+    for case in range(40):
+        B = int(rng.choice([1, 2, 3, 7, 16, 50, 129, 300, 513]))
+        T = int(rng.choice([1, 2, 5, 33, 64, 65, 100, 128, 257, 400]))
+        if B * T > 60000:
+            B = max(60000 // T, 1)
+        K = int(rng.randint(0, 4))
+        profile = rng.choice(["full", "tacred", "ragged"])
+        if profile == "ragged":
+            lens = rng.randint(0, T + 1, size=B).astype(np.int32)
+            lens[0] = T
+            tb = synthetic.random_tree_batch(1000 + case, B, T, np.maximum(lens, 1)[np.argsort(-np.maximum(lens, 1), kind="stable")])
+            lens = tb["lens"].astype(np.int64)
+            short = rng.rand(B) < 0.1                                     # some sentences are empty: no row, no entry
+            short[0] = False
+            lens = np.where(short, 0, lens)
+        else:
+            tb = synthetic.random_tree_batch(1000 + case, B, T, str(profile), overlap_frac=0.2)
+            lens = tb["lens"].astype(np.int64)
+        head = tb["head"].copy()
+        bad = np.flatnonzero(rng.rand(B) < 0.1)
+        for b_ in bad:                                                    # a head past the sentence / a cycle: the sentence fails
+            if lens[b_] >= 2:
+                head[b_, 0], head[b_, 1] = (2, 1) if rng.rand() < 0.5 else (lens[b_] + 5, head[b_, 1])
+        args = [_t(a, dev) for a in (head, tb["subj_pos"], tb["obj_pos"], tb["deprel"])]
+        lens_dev = _t(lens.astype(np.int32), dev)
+        want_label, want_T = bool(case & 1), bool(case & 2)
+        two = tree.prune_to_csr(*args, K, lens=lens_dev, want_label=want_label, want_transpose=want_T).pack(lens.tolist())
+        one = tree.prune_to_csr_packed(*args, K, lens.tolist(), want_label=want_label, want_transpose=want_T)
+        torch.cuda.synchronize()
+        _same_packed(one, two, (case, B, T, K, str(profile)))
+        assert torch.equal(one.padded.status, two.padded.status), (case, B, T, K)
+        assert torch.equal(one.padded.pool_mask, two.padded.pool_mask), (case, B, T, K)
+
+
 @pytest.mark.parametrize("shape", ["golden", "errors", "long"])
 def test_cache_batch_packed_equals_pack_of_batch(api, dev, shape):
     """VERDICT r3 item 2, the cache's half: TreeCache.batch_packed (gcnpt_gather_trees_packed) gives exactly batch(idx, T).pack(lens[idx])

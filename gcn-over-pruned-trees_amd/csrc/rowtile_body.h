@@ -13,6 +13,9 @@ static_assert(RT_THREADS == 16 * ROWS, "the row store loop gives every row 16 th
 #ifndef GCNPT_A_AHEAD
 #define GCNPT_A_AHEAD 2              // k-steps the tile's MFMA operand is read ahead of its use (measured 1..4 at the C2 shape: 51.7 / 51.1 / 51.3 / 51.7 us per step)
 #endif
+#ifndef GCNPT_W_STAGGER
+#define GCNPT_W_STAGGER 3            // n > 0: the fragments behind the early quarter are requested in n pieces (<= 5) between the gather's phases
+#endif
 #ifndef GCNPT_W_EARLY_NUM
 #define GCNPT_W_EARLY_NUM 1          // quarters of a wave's weight fragments requested before the adjacency is known (0..4 measured: 1 is best)
 #endif
@@ -131,7 +134,14 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
 
     GItem g0;
     G.issue(n_g, tid, g0);
-    load_w(0, 0, KS_EARLY, KSMAX);                              // 156 KB per workgroup at Din=360, H=200
+    // a wave that requests faster than the CU's L2 -> L1 path delivers (~30 B per clock) stalls AT the request: with everything asked
+    // for here, the phases below only start when the last request has left
+    constexpr int NP = GCNPT_W_STAGGER ? GCNPT_W_STAGGER : 1;   // pieces the rest is requested in, one per site below
+    auto load_piece = [&](auto site) {
+        constexpr int i = decltype(site)::value;
+        if constexpr (i < NP) load_w(0, 0, KS_EARLY + (KSMAX - KS_EARLY) * i / NP, KS_EARLY + (KSMAX - KS_EARLY) * (i + 1) / NP);
+    };
+    load_piece(std::integral_constant<int, 0>{});               // 156 KB per workgroup at Din=360, H=200
     GCNPT_STAMP(p.stamps, 3);
 
     // (2b)
@@ -141,9 +151,11 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
         for (int u = 0; u < ITEMS; ++u) G.template copy_item<BWD>((batch * ITEMS + u) * RTT + tid, self[u], selfy[u], Z);
     };
     copy_batch(0);
+    load_piece(std::integral_constant<int, 1>{});
     GCNPT_STAMP(p.stamps, 4);
     // (2a) -- only the waves that own an item: the sums cost a wave ~120 VALU instructions whether its lanes are live or not
     if (wave * WAVE < n_g) G.finish(n_g, tid, g0);
+    load_piece(std::integral_constant<int, 2>{});
     for (int base = RTT; base < n_g; base += RTT) {      // tiles with more than 512 / (K/8) aggregating rows
         GItem g;
         G.issue(n_g, base + tid, g);
@@ -155,11 +167,13 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
     }
     GCNPT_STAMP(p.stamps, 5);
     __syncthreads();
+    load_piece(std::integral_constant<int, 3>{});
     GCNPT_STAMP(p.stamps, 6);
 
     // side outputs: the tile in MFMA fragment order for the weight gradient (rows are its contraction index),
     // and cleared accumulators for the kernel that follows
     if (p.frag_out) emit_tile_image(static_cast<uint4*>(p.frag_out), BWD ? Z : S, stride, wave, RTW, ceil_div(p.K, 16), lane, (size_t)n_blocks, tile_id, BWD);
+    load_piece(std::integral_constant<int, 4>{});
     if constexpr (BWD) {
         if (p.frag_out) __syncthreads();                         // every wave has read its share of Z: the region becomes O
     }

@@ -9,10 +9,10 @@
 // (156 KB of weights) the split buys nothing and costs the backward launch its passenger (the weight gradient that rides on idle CUs):
 // the dispatcher takes this form only from 170 KB of weight fragments on and for at most 128 row tiles.
 //
-// Structure: the one-shot kernel's, with two differences.  (1) A wave requests the fragments of its own column tiles FIRST, before the
-// ELL heads -- they are few now and land while the heads make their round trip -- and a wave whose slot lies past the workgroup's share
-// requests nothing and skips the matrix phase (the condition sits in front of every other load, so no later wait is counted across it).
-// (2) All k-steps of a wave's tiles are resident (six register-budgeted configurations, no spills), the fragment image of S / dZ is dealt over the
+// Structure: the one-shot kernel's, with two differences.  (1) A wave whose slot lies past the workgroup's share of the column tiles
+// requests no fragments and skips the matrix phase: the kernel body exists in two straight-line copies, chosen per wave at the top, so that
+// neither copy has a load behind a condition (round 3 had one copy and the owning waves' fragments in front of everything else: their ELL
+// heads then landed behind 19 ... 24 KB of weights).  (2) All k-steps of a wave's tiles are resident (six register-budgeted configurations, no spills), the fragment image of S / dZ is dealt over the
 // workgroups that share the tile.  Every barrier is `s_waitcnt lgkmcnt(0)` + `s_barrier`.
 //
 // Values: bit-identical to rowtile_body.h's (same gather order, same k order on the matrix cores, same epilogue) -- the tests compare
@@ -81,113 +81,129 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_colsplit_kernel(const R
     if (!BWD && p.seed_dev) seed_off = *p.seed_dev;
     static_assert(VEC == 8 || VEC == 4, "rows are read in 16- or 8-byte pieces");
 
-    // ---- (0) this wave's weight fragments, FIRST: with the columns split they are few (19 ... 60 KB per workgroup) and land while the heads
-    //      make their round trip.  Wave w owns column tiles cpass * tiles_pp + w, + 8, ...; a wave whose slot lies past the workgroup's share
-    //      requests nothing (the condition sits in front of every other load of the kernel, so no later wait is counted across it).
+    // Two roles, two copies of the code (a wave-uniform branch at the top; both copies run the same barriers): a wave that owns column
+    // tiles requests their fragments in pieces BETWEEN the gather's phases, like the one-shot kernel (a wave that requests faster than the
+    // CU's L2 -> L1 path delivers stalls at the request, rowtile_body.h) -- heads and own rows first in the queue, a third of the fragments
+    // behind them, a third behind the neighbour requests, the rest behind the parked rows; a wave whose slot lies past the workgroup's
+    // share requests none and skips the matrix phase.  Straight-line code in each copy: every wait counts exactly what was requested.
     bool has_tile[NTW];
     bool any_tile = false;
-    uint4 wreg[KS][NTW];
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
-        const int tloc = j * RTW + wave, tl = cpass * p.tiles_pp + tloc;
-        has_tile[j] = tloc < p.tiles_pp && tl < n_ctiles;
+        const int tloc = j * RTW + wave;
+        has_tile[j] = tloc < p.tiles_pp && cpass * p.tiles_pp + tloc < n_ctiles;
         any_tile = any_tile || has_tile[j];
-        if (has_tile[j]) {
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) wreg[ks][j] = wfrag[((size_t)tl * ksteps + min(ks, ksteps - 1)) * 64 + lane];
-        } else {
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) wreg[ks][j] = make_uint4(0, 0, 0, 0);
-        }
     }
     GCNPT_STAMP_REAL(p.stamps);
     GCNPT_STAMP(p.stamps, 0);
-
-    // ---- (1) the tile's adjacency (ELL heads, degrees) -> LDS; (2) its rows and its aggregating rows' neighbours -> S: the phases of
-    //      the one-shot kernel (rowtile_phases.h), PI chunks of the tile's own rows per thread in the first batch
-    const TileHeads heads = load_tile_heads(p, r0, lane);
-    float bias_v = 0.0f;
-    if constexpr (!BWD) bias_v = p.bias[min(cpass * ncols_pass + min(tid, ncols_pass - 1), p.NOUT - 1)];
-    park_tile_heads<BWD>(p, m, heads, r0, lane, true);
-    if constexpr (!BWD) { if (tid < ncols_pass) sbias[tid] = bias_v; }
-    wave_lds_fence();
-    GCNPT_STAMP(p.stamps, 1);
-    const TileGather<CT, IT, MASKED, VEC, NBU> G{p, m, Sw, stride, r0};
-    const int n_items = ROWS * (p.Kpad / 8), n_g = *m.gcount * (p.Kpad / 8);
-    raw8<IT> self[PI], selfy[PI];
-#pragma unroll
-    for (int u = 0; u < PI; ++u) G.issue_self(u * RTT + tid, self[u], selfy[u]);
-    GatherItem<IT, NBU> g0;
-    G.issue(n_g, tid, g0);
-    GCNPT_STAMP(p.stamps, 2);
-#pragma unroll
-    for (int u = 0; u < PI; ++u) G.template copy_item<BWD>(u * RTT + tid, self[u], selfy[u], Zw);
-    if (wave * WAVE < n_g) G.finish(n_g, tid, g0);
-    for (int base = RTT; base < n_g; base += RTT) {                  // more than 512 (aggregating row, chunk) items: further rounds
-        GatherItem<IT, NBU> g;
-        G.issue(n_g, base + tid, g);
-        G.finish(n_g, base + tid, g);
-    }
-    for (int first = PI * RTT; first < n_items; first += RTT) {       // K wider than PI covers: further batches
-        raw8<IT> s, sy;
-        G.issue_self(first + tid, s, sy);
-        G.template copy_item<BWD>(first + tid, s, sy, Zw);
-    }
-    GCNPT_STAMP(p.stamps, 3);
-    lds_barrier();                                                      // S (and Z) complete
-    GCNPT_STAMP(p.stamps, 4);
-
     const int arow = lane & 15, kgrp = lane >> 4;
     const int c_lo = cpass * ncols_pass, c_hi = min(p.NOUT, c_lo + ncols_pass);
 
-    // side output: the tile in MFMA fragment order for the weight gradient; the column tiles of the image are dealt over the workgroups
-    // that share this row tile
-    if (p.frag_out) emit_tile_image(static_cast<uint4*>(p.frag_out), BWD ? Zw : Sw, stride, wave + RTW * cpass, RTW * C, ceil_div(p.K, 16), lane,
-                                    (size_t)n_rt, tile_id, BWD);
-
-    // (3) the tile meets the resident weights
-    f32x4_t acc[2][NTW];
+    auto body = [&](auto role) {
+        constexpr bool HASW = decltype(role)::value;
+        uint4 wreg[KS][NTW];
+        auto load_w = [&](int ks_lo, int ks_hi) {                       // (an absent second slot of an owning wave: a duplicate of the last tile, not used)
+            if constexpr (HASW) {
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) { acc[0][j] = (f32x4_t){0, 0, 0, 0}; acc[1][j] = (f32x4_t){0, 0, 0, 0}; }
-    if (any_tile) {                                                 // (a wave without a column tile reads no operand either: LDS bandwidth)
-        constexpr int AH = GCNPT_A_AHEAD;
-        uint4 a_st[AH + 1][2];                                       // [0] = the k-step on the matrix cores, [d] = d k-steps ahead
-        auto read_a = [&](int kk, uint4 (&dst)[2]) {
-            dst[0] = *reinterpret_cast<const uint4*>(Sw + (size_t)arow * stride + kk * KSTEP + kgrp * 8);
-            dst[1] = *reinterpret_cast<const uint4*>(Sw + (size_t)(arow + 16) * stride + kk * KSTEP + kgrp * 8);
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) {
+                        if (ks < ks_lo || ks >= ks_hi) continue;            // compile-time after unrolling
+                        const int tl = min(cpass * p.tiles_pp + j * RTW + wave, n_ctiles - 1);
+                        wreg[ks][j] = wfrag[((size_t)tl * ksteps + min(ks, ksteps - 1)) * 64 + lane];
+                    }
+            }
         };
+        // ---- (1) the tile's adjacency (ELL heads, degrees) -> LDS; (2) its rows and its aggregating rows' neighbours -> S: the phases of
+        //      the one-shot kernel (rowtile_phases.h), PI chunks of the tile's own rows per thread in the first batch
+        const TileHeads heads = load_tile_heads(p, r0, lane);
+        float bias_v = 0.0f;
+        if constexpr (!BWD) bias_v = p.bias[min(cpass * ncols_pass + min(tid, ncols_pass - 1), p.NOUT - 1)];
+        const TileGather<CT, IT, MASKED, VEC, NBU> G{p, m, Sw, stride, r0};
+        const int n_items = ROWS * (p.Kpad / 8);
+        raw8<IT> self[PI], selfy[PI];
 #pragma unroll
-        for (int d = 0; d < AH; ++d) read_a(min(d, ksteps - 1), a_st[d]);
+        for (int u = 0; u < PI; ++u) G.issue_self(u * RTT + tid, self[u], selfy[u]);
+        constexpr int KS_A = KS / 3, KS_B = 2 * KS / 3;
+        load_w(0, KS_A);
+        park_tile_heads<BWD>(p, m, heads, r0, lane, true);
+        if constexpr (!BWD) { if (tid < ncols_pass) sbias[tid] = bias_v; }
+        wave_lds_fence();
+        GCNPT_STAMP(p.stamps, 1);
+        const int n_g = *m.gcount * (p.Kpad / 8);
+        GatherItem<IT, NBU> g0;
+        G.issue(n_g, tid, g0);
+        load_w(KS_A, KS_B);
+        GCNPT_STAMP(p.stamps, 2);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if (ks < ksteps) {                                       // wave-uniform, no global load inside
-                read_a(min(ks + AH, ksteps - 1), a_st[AH]);
+        for (int u = 0; u < PI; ++u) G.template copy_item<BWD>(u * RTT + tid, self[u], selfy[u], Zw);
+        load_w(KS_B, KS);
+        if (wave * WAVE < n_g) G.finish(n_g, tid, g0);
+        for (int base = RTT; base < n_g; base += RTT) {                  // more than 512 (aggregating row, chunk) items: further rounds
+            GatherItem<IT, NBU> g;
+            G.issue(n_g, base + tid, g);
+            G.finish(n_g, base + tid, g);
+        }
+        for (int first = PI * RTT; first < n_items; first += RTT) {       // K wider than PI covers: further batches
+            raw8<IT> s, sy;
+            G.issue_self(first + tid, s, sy);
+            G.template copy_item<BWD>(first + tid, s, sy, Zw);
+        }
+        GCNPT_STAMP(p.stamps, 3);
+        lds_barrier();                                                      // S (and Z) complete
+        GCNPT_STAMP(p.stamps, 4);
+
+        // side output: the tile in MFMA fragment order for the weight gradient; the column tiles of the image are dealt over the workgroups
+        // that share this row tile
+        if (p.frag_out) emit_tile_image(static_cast<uint4*>(p.frag_out), BWD ? Zw : Sw, stride, wave + RTW * cpass, RTW * C, ceil_div(p.K, 16), lane,
+                                        (size_t)n_rt, tile_id, BWD);
+
+        // (3) the tile meets the resident weights (a wave without a column tile reads no operand either: LDS bandwidth)
+        f32x4_t acc[2][NTW];
 #pragma unroll
-                for (int j = 0; j < NTW; ++j) {
-                    const bf16x8_t bq = __builtin_bit_cast(bf16x8_t, wreg[ks][j]);
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq, __builtin_bit_cast(bf16x8_t, a_st[0][0]), acc[0][j], 0, 0, 0);
-                    acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq, __builtin_bit_cast(bf16x8_t, a_st[0][1]), acc[1][j], 0, 0, 0);
+        for (int j = 0; j < NTW; ++j) { acc[0][j] = (f32x4_t){0, 0, 0, 0}; acc[1][j] = (f32x4_t){0, 0, 0, 0}; }
+        if constexpr (HASW) {
+            constexpr int AH = GCNPT_A_AHEAD;
+            uint4 a_st[AH + 1][2];                                       // [0] = the k-step on the matrix cores, [d] = d k-steps ahead
+            auto read_a = [&](int kk, uint4 (&dst)[2]) {
+                dst[0] = *reinterpret_cast<const uint4*>(Sw + (size_t)arow * stride + kk * KSTEP + kgrp * 8);
+                dst[1] = *reinterpret_cast<const uint4*>(Sw + (size_t)(arow + 16) * stride + kk * KSTEP + kgrp * 8);
+            };
+#pragma unroll
+            for (int d = 0; d < AH; ++d) read_a(min(d, ksteps - 1), a_st[d]);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks < ksteps) {                                       // wave-uniform, no global load inside
+                    read_a(min(ks + AH, ksteps - 1), a_st[AH]);
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) {
+                        const bf16x8_t bq = __builtin_bit_cast(bf16x8_t, wreg[ks][j]);
+                        acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq, __builtin_bit_cast(bf16x8_t, a_st[0][0]), acc[0][j], 0, 0, 0);
+                        acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq, __builtin_bit_cast(bf16x8_t, a_st[0][1]), acc[1][j], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int d = 0; d < AH; ++d) { a_st[d][0] = a_st[d + 1][0]; a_st[d][1] = a_st[d + 1][1]; }
                 }
-#pragma unroll
-                for (int d = 0; d < AH; ++d) { a_st[d][0] = a_st[d + 1][0]; a_st[d][1] = a_st[d + 1][1]; }
             }
         }
-    }
-    GCNPT_STAMP(p.stamps, 5);
+        GCNPT_STAMP(p.stamps, 5);
 
-    // (4) epilogue on the accumulators -> O, then whole rows leave in 16-byte pieces (rowtile_phases.h)
-    {
-        float den[2], inv[2];
+        // (4) epilogue on the accumulators -> O, then whole rows leave in 16-byte pieces (rowtile_phases.h)
+        if constexpr (HASW) {
+            float den[2], inv[2];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) { den[mt] = m.rden[mt * 16 + (lane & 15)]; inv[mt] = m.rinv[mt * 16 + (lane & 15)]; }
+            for (int mt = 0; mt < 2; ++mt) { den[mt] = m.rden[mt * 16 + (lane & 15)]; inv[mt] = m.rinv[mt * 16 + (lane & 15)]; }
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) {
-            if (!has_tile[j]) continue;
-            const int col0 = (cpass * p.tiles_pp + j * RTW + wave) * 16 + (lane >> 4) * 4;
-            const f32x4_t aj[2] = {acc[0][j], acc[1][j]};
-            epilogue_tile<OT, BWD>(p, aj, col0, col0 - c_lo, r0, den, inv, sbias, O, ostride, seed_off, lane);
+            for (int j = 0; j < NTW; ++j) {
+                if (!has_tile[j]) continue;
+                const int col0 = (cpass * p.tiles_pp + j * RTW + wave) * 16 + (lane >> 4) * 4;
+                const f32x4_t aj[2] = {acc[0][j], acc[1][j]};
+                epilogue_tile<OT, BWD>(p, aj, col0, col0 - c_lo, r0, den, inv, sbias, O, ostride, seed_off, lane);
+            }
         }
-    }
+    };
+    if (any_tile) body(std::true_type{});
+    else body(std::false_type{});
     GCNPT_STAMP(p.stamps, 6);
     lds_barrier();                                                      // O complete
     GCNPT_STAMP(p.stamps, 7);

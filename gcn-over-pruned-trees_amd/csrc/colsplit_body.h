@@ -137,8 +137,11 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_colsplit_kernel(const R
         GCNPT_STAMP(p.stamps, 2);
 #pragma unroll
         for (int u = 0; u < PI; ++u) G.template copy_item<BWD>(u * RTT + tid, self[u], selfy[u], Zw);
+        GCNPT_STAMP(p.stamps, 9);
         load_w(KS_B, KS);
+        GCNPT_STAMP(p.stamps, 10);
         if (wave * WAVE < n_g) G.finish(n_g, tid, g0);
+        GCNPT_STAMP(p.stamps, 11);
         for (int base = RTT; base < n_g; base += RTT) {                  // more than 512 (aggregating row, chunk) items: further rounds
             GatherItem<IT, NBU> g;
             G.issue(n_g, base + tid, g);

@@ -101,6 +101,7 @@ __device__ __forceinline__ void rowtile_body(const RowTileParams& p, const int b
                 const int kk = min(kc0 + ks, ksteps - 1);
 #ifdef GCNPT_STAMPS
                 if (p.knob & 1) { wreg[ks][j] = wfrag[lane]; continue; }          // experiment: no weight traffic
+                if ((p.knob & 32) && ks >= (KSMAX * 2 + 4) / 5) { wreg[ks][j] = wfrag[lane]; continue; }   // experiment: 40 % of the weight traffic (a 64-row x 1/3-column tiling's share)
 #endif
                 wreg[ks][j] = wfrag[((size_t)tl * ksteps + kk) * 64 + lane];
 #ifdef GCNPT_STAMPS

@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("GCNPT_LIB") or os.path.join(_HERE, "csrc", "libgcnpt.
 
 F32, BF16 = 0, 1
 ABI_VERSION = 7            # GCNPT_ABI_VERSION of the include/gcnpt.h this binding was written against
-OPT_DETERMINISTIC, OPT_FOUR_WAVES, OPT_SIDE_TILES, OPT_COL_SPLIT, OPT_FOREST = 0, 1, 2, 3, 4      # gcnpt_set_option keys (include/gcnpt.h)
+OPT_DETERMINISTIC, OPT_FOUR_WAVES, OPT_SIDE_TILES, OPT_COL_SPLIT = 0, 1, 2, 3      # gcnpt_set_option keys (include/gcnpt.h)
 OK, E_INVALID, E_PRUNE_NEGATIVE, E_NO_SUBJECT, E_NO_LCA, E_CYCLE, E_BAD_HEAD, E_ASSERT, E_CAPACITY, E_HIP, E_UNSUPPORTED, E_LENGTH = \
     0, -1, -2, -3, -4, -5, -6, -7, -8, -9, -10, -11
 

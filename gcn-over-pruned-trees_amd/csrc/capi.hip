@@ -26,8 +26,8 @@ int fail(int code, const char* fmt, ...) {
 // at the top of a call; the environment is consulted exactly once, when the library is loaded, for the defaults.
 static std::atomic<int> g_options[GCNPT_OPT_COUNT];
 static const bool g_options_init = [] {
-    const int defaults[GCNPT_OPT_COUNT] = {0, -1, 192, -1, 1};
-    const char* names[GCNPT_OPT_COUNT] = {"GCNPT_DETERMINISTIC", "GCNPT_WAVES4", "GCNPT_SIDE_TILES", "GCNPT_COL_SPLIT", "GCNPT_FOREST"};
+    const int defaults[GCNPT_OPT_COUNT] = {0, -1, 192, -1};
+    const char* names[GCNPT_OPT_COUNT] = {"GCNPT_DETERMINISTIC", "GCNPT_WAVES4", "GCNPT_SIDE_TILES", "GCNPT_COL_SPLIT"};
     for (int i = 0; i < GCNPT_OPT_COUNT; ++i) {
         const char* e = getenv(names[i]);
         g_options[i].store((e && e[0]) ? atoi(e) : defaults[i], std::memory_order_relaxed);
@@ -75,7 +75,6 @@ extern "C" int gcnpt_set_option(int option, int value) {
     if (option == GCNPT_OPT_FOUR_WAVES && (value < -1 || value > 1)) return gcnpt::fail(GCNPT_E_INVALID, "set_option: four_waves is -1 (auto), 0 or 1");
     if (option == GCNPT_OPT_SIDE_TILES && value < 0) return gcnpt::fail(GCNPT_E_INVALID, "set_option: side_tiles must be >= 0");
     if (option == GCNPT_OPT_COL_SPLIT && (value < -1 || value > 8)) return gcnpt::fail(GCNPT_E_INVALID, "set_option: col_split is -1 (auto), 0 or 1..8 workgroups per row tile");
-    if (option == GCNPT_OPT_FOREST && value != 0 && value != 1) return gcnpt::fail(GCNPT_E_INVALID, "set_option: forest is 0 or 1");
     gcnpt::g_options[option].store(value, std::memory_order_relaxed);
     return GCNPT_OK;
 }

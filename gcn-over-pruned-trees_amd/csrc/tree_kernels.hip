@@ -702,259 +702,6 @@ __global__ __launch_bounds__(PRUNE_THREADS) void prune_to_csr_kernel(
     // (packed output that did not fit: the per-sentence code stays what the pruning found; the batch-level status says E_CAPACITY)
 }
 
-// ---- A SMALL token-packed batch pruned by ONE workgroup, as a forest (gcnpt_prune_to_csr_packed for up to FOREST_MAX_ROWS token
-// rows: BASELINE configs[4]'s per-GPU share is 16 sentences, ~800 tokens).  The batch IS one block-diagonal problem over its packed
-// rows: every phase of prune_sentence() is elementwise over tokens, so one workgroup runs each phase once over ALL the batch's
-// tokens (positions are packed row numbers, parents likewise; the per-sentence scalars -- entity counts, lca, error bits -- are LDS
-// arrays), and the scans over the packed rows give the packed layout's contiguous offsets directly.  No hand-off between
-// workgroups: the look-back of the per-sentence form costs two device-scope round trips (~4 us), this form none.  Same arrays,
-// bit for bit (tests/test_gpu_packed.py).  LDS: the per-sentence form's layout with T := M (rows allocated), so emit_rows() is
-// shared; behind it sid[M] and the per-sentence arrays.
-constexpr int FOREST_MAX_ROWS = 1536, FOREST_MAX_SENT = 512;
-__global__ __launch_bounds__(PRUNE_THREADS) void prune_forest_kernel(
-    const int64_t* __restrict__ head, const int64_t* __restrict__ subj_pos, const int64_t* __restrict__ obj_pos,
-    const int64_t* __restrict__ deprel, const uint8_t* __restrict__ pad_mask, const int32_t* __restrict__ len_in,
-    int B, int T, int prune_k, int32_t* __restrict__ row_ptr, int32_t* __restrict__ col_idx,
-    int32_t* __restrict__ label, int32_t* __restrict__ rowT_ptr, int32_t* __restrict__ colT_idx,
-    int32_t* __restrict__ ell, int32_t* __restrict__ ellT, uint8_t* __restrict__ pool_mask,
-    int32_t* __restrict__ status, unsigned long long* stamps, const PackParams pk, int pk_dtype, const PackedOut po) {
-    extern __shared__ int smem[];
-    if (blockIdx.x >= 1) {             // side job: the weights' fragment images
-        pack_side_job(pk, pk_dtype, 1);
-        return;
-    }
-    constexpr int NT = PRUNE_THREADS;
-    const int M = po.n_rows;           // rows allocated = capacity of the token arrays
-    int* pw = smem;                    // the layout emit_rows() expects for a "sentence" of M tokens
-    int* cnt = pw + M;
-    int* deg = cnt + M;
-    int* degT = deg + M + 1;
-    int* rank = degT + M + 1;
-    int* lab = rank + M + 1;
-    int* einfo = lab + M;
-    int* sid = smem + 15 * M + 4;      // behind emit_rows' entry lists: sentence of a packed row
-    int* cu = sid + M;                 // [B+1] first packed row of a sentence
-    int* lens = cu + B + 1;            // [B]
-    int* nsubj = lens + B;             // [B]
-    int* nent = nsubj + B;             // [B]
-    int* lca = nent + B;               // [B]
-    int* errb = lca + B;               // [B] ERR_* bits
-    int* serr = errb + B;              // [B] the sentence's status code so far
-    __shared__ int s_maxlen, s_tot[3], s_out[4], s_red[4], s_status;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    GCNPT_STAMP_REAL(stamps);
-    GCNPT_STAMP(stamps, 0);
-    if (t == 0) s_maxlen = 0;
-    __syncthreads();
-
-    // ---- lengths (gcn.py:96: non-pad slots), first rows
-    if (pad_mask) {
-        for (int b = wave; b < B; b += NT / WAVE) {
-            int n = 0;
-            for (int i0 = 0; i0 < T; i0 += WAVE) {
-                const int i = i0 + lane;
-                n += __popcll(__ballot(i < T && pad_mask[(size_t)b * T + min(i, T - 1)] == 0));
-            }
-            if (lane == 0) lens[b] = n;
-        }
-    } else {
-        for (int b = t; b < B; b += NT) lens[b] = min(max(len_in[b], 0), T);
-    }
-    __syncthreads();
-    for (int b = t; b < B; b += NT) {
-        const int n = lens[b];
-        cu[b] = n; nsubj[b] = 0; nent[b] = 0; lca[b] = 0x7fffffff; errb[b] = 0; serr[b] = 0;
-        if (n) atomicMax(&s_maxlen, n);
-    }
-    __syncthreads();
-    if (t < WAVE) {
-        const int tot = wave_exclusive_scan(cu, B, lane);
-        if (lane == 0) cu[B] = tot;
-    }
-    __syncthreads();
-    const int Nall = cu[B];
-    const bool rows_fit = Nall <= M;
-    const int N = rows_fit ? Nall : 0;            // (a batch that does not fit its arrays: only cu, the status words and the masks are written)
-    auto sent_of = [&](int p) {                   // the sentence that owns packed row p
-        int lo = 0, hi = B;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (cu[mid] <= p) lo = mid; else hi = mid;
-        }
-        return lo;
-    };
-
-    // ---- stage the parses (tree.py:60-63, 82-83): one token per thread and round, every load of the round issued before the first use
-    for (int p0 = 0; p0 < N; p0 += NT) {
-        const int p = p0 + t;
-        const int pc = min(p, N - 1);
-        const int b = sent_of(pc), i = pc - cu[b];
-        const size_t j = (size_t)b * T + i;
-        const int64_t h = head[j], sp = subj_pos[j], op = obj_pos[j], d = deprel[j];
-        if (p < N) {
-            const int n = lens[b];
-            int f = 0;
-            if (sp == 0) f |= F_SUBJ;
-            if (op == 0) f |= F_OBJ;
-            if (d != 0) f |= F_FWD_NZ;
-            if (d + FWD_BOUND != 0) f |= F_REV_NZ;
-            const int par = h > 0 ? (h - 1 < n ? cu[b] + (int)(h - 1) : -2) : -1;
-            pw[p] = (par + 2) | (f << PW_SHIFT);
-            lab[p] = (int)d; cnt[p] = 0; deg[p] = 0; degT[p] = 0; sid[p] = b;
-            if (f & F_SUBJ) atomicAdd(&nsubj[b], 1);
-            if (f & (F_SUBJ | F_OBJ)) atomicAdd(&nent[b], ((f & F_SUBJ) ? 1 : 0) + ((f & F_OBJ) ? 1 : 0));
-        }
-    }
-    __syncthreads();
-    GCNPT_STAMP(stamps, 1);
-
-    // ---- every entity token walks to the root, counting visits (tree.py:86-109)
-    for (int p = t; p < N; p += NT) {
-        const int f = pw[p] >> PW_SHIFT;
-        const int w = ((f & F_SUBJ) ? 1 : 0) + ((f & F_OBJ) ? 1 : 0);
-        if (!w) continue;
-        const int b = sid[p], n = lens[b];
-        int a = p, steps = 0;
-        while (a >= 0) {
-            atomicAdd(&cnt[a], w);
-            a = pw_par(pw[a]);
-            if (++steps > n) { atomicOr(&errb[b], ERR_CHAIN_CYCLE); a = -1; }
-        }
-        if (a == -2) atomicOr(&errb[b], ERR_CHAIN_BADHEAD);
-    }
-    __syncthreads();
-    for (int b = t; b < B; b += NT) {
-        const int e = errb[b];
-        serr[b] = (e & ERR_CHAIN_BADHEAD) ? GCNPT_E_BAD_HEAD : (e & ERR_CHAIN_CYCLE) ? GCNPT_E_CYCLE : (nsubj[b] == 0 ? GCNPT_E_NO_SUBJECT : 0);
-    }
-    __syncthreads();
-    GCNPT_STAMP(stamps, 2);
-
-    // ---- common ancestors and the lowest of them (tree.py:112-124)
-    for (int p = t; p < N; p += NT) {
-        const int b = sid[p];
-        if (!serr[b] && cnt[p] == nent[b]) pw[p] |= F_CA << PW_SHIFT;
-    }
-    __syncthreads();
-    for (int p = t; p < N; p += NT) {
-        const int w = pw[p], par = pw_par(w);
-        if ((w & (F_CA << PW_SHIFT)) && par >= 0 && (pw[par] & (F_CA << PW_SHIFT))) atomicOr(&pw[par], F_CA_HASCHILD << PW_SHIFT);
-    }
-    __syncthreads();
-    for (int p = t; p < N; p += NT)
-        if (((pw[p] >> PW_SHIFT) & (F_CA | F_CA_HASCHILD)) == F_CA) atomicMin(&lca[sid[p]], p);
-    __syncthreads();
-    for (int b = t; b < B; b += NT)
-        if (!serr[b] && lca[b] == 0x7fffffff) serr[b] = GCNPT_E_NO_LCA;
-    __syncthreads();
-    GCNPT_STAMP(stamps, 3);
-
-    // ---- path nodes, distance to the path, kept tokens (tree.py:126-147)
-    for (int p = t; p < N; p += NT) {
-        const int b = sid[p];
-        if (!serr[b] && ((cnt[p] > 0 && !(pw[p] & (F_CA << PW_SHIFT))) || p == lca[b])) pw[p] |= F_PATH << PW_SHIFT;
-    }
-    __syncthreads();
-    for (int p = t; p < N; p += NT) {
-        const int b = sid[p];
-        if (serr[b]) { cnt[p] = 0; continue; }
-        const int n = lens[b];
-        int a = p, d = 0, w = pw[p];
-        while (a >= 0 && !(w & (F_PATH << PW_SHIFT))) {
-            a = pw_par(w);
-            if (a >= 0) w = pw[a];
-            if (++d > n) { atomicOr(&errb[b], ERR_CYCLE); a = -1; }
-        }
-        if (a == -2) atomicOr(&errb[b], ERR_BADHEAD);
-        const bool keep = a >= 0 && d <= prune_k;
-        const bool child = keep && p != lca[b] && pw_par(pw[p]) >= 0;
-        cnt[p] = (keep ? K_KEEP : 0) | (child ? K_CHILD : 0);
-    }
-    __syncthreads();
-    for (int b = t; b < B; b += NT)
-        if (!serr[b]) { const int e = errb[b]; if (e & ERR_BADHEAD) serr[b] = GCNPT_E_BAD_HEAD; else if (e & ERR_CYCLE) serr[b] = GCNPT_E_CYCLE; }
-    __syncthreads();
-    GCNPT_STAMP(stamps, 4);
-
-    // ---- degrees of the labelled adjacency tree_to_adj would write (tree.py:182-192)
-    for (int p = t; p < N; p += NT) {
-        if (!(cnt[p] & K_CHILD) || serr[sid[p]]) continue;
-        const int w = pw[p], par = pw_par(w), f = w >> PW_SHIFT;
-        if (!(cnt[par] & K_KEEP)) atomicOr(&errb[sid[p]], ERR_ASSERT);    // tree.py:159
-        if (f & F_FWD_NZ) { atomicAdd(&deg[par], 1); atomicAdd(&degT[p], 1); }
-        if (f & F_REV_NZ) { atomicAdd(&deg[p], 1); atomicAdd(&degT[par], 1); }
-        atomicOr(&pw[par], F_HASEDGE << PW_SHIFT);
-        atomicOr(&pw[p], F_HASEDGE << PW_SHIFT);
-    }
-    __syncthreads();
-    for (int b = t; b < B; b += NT)
-        if (!serr[b] && (errb[b] & ERR_ASSERT)) serr[b] = GCNPT_E_ASSERT;
-    __syncthreads();
-    for (int p = t; p < N; p += NT) {
-        const bool ok = serr[sid[p]] == 0;
-        const int he = (ok && (pw[p] & (F_HASEDGE << PW_SHIFT))) ? 1 : 0;
-        if (!ok) pw[p] &= ~(F_HASEDGE << PW_SHIFT);                       // a failed sentence has rows, no entries
-        deg[p] = ok ? deg[p] + he : 0;                                    // (+ the 84 on the diagonal)
-        degT[p] = ok ? degT[p] + he : 0;
-        rank[p] = he;
-    }
-    __syncthreads();
-    if (po.pool_mask_padded)                                             // gcn.py:262 in the padded layout (what GCN.forward returns)
-        for (int j = t; j < B * T; j += NT) {
-            const int b = j / T, i = j - b * T;
-            const bool in = rows_fit && i < lens[b] && serr[b] == 0;
-            po.pool_mask_padded[j] = in ? (deg[cu[b] + i] + degT[cu[b] + i]) == 0 : (uint8_t)1;
-        }
-    if (t < WAVE) {
-        int tot, totT, ner;
-        wave_exclusive_scan3(deg, degT, rank, N, lane, tot, totT, ner);
-        if (lane == 0) { deg[N] = tot; degT[N] = totT; rank[N] = ner; s_tot[0] = tot; s_tot[1] = totT; s_tot[2] = ner; }
-    }
-    __syncthreads();
-    const int nnz = s_tot[0], nnzT = s_tot[1], n_edge_rows = s_tot[2];
-    const bool fits = rows_fit && nnz <= po.nnz_cap && nnzT <= po.nnz_cap;
-    GCNPT_STAMP(stamps, 5);
-
-    // ---- everything that is not an entry of an edge row
-    for (int b = t; b <= B; b += NT) {
-        po.cu[b] = cu[b];
-        if (b < B) status[b] = rows_fit ? serr[b] : GCNPT_E_CAPACITY;
-    }
-    if (t == 0) {
-        status[B] = s_maxlen;
-        po.pk_status[0] = fits ? 0 : GCNPT_E_CAPACITY;
-        po.pk_status[1] = Nall;
-        if (fits) { row_ptr[N] = nnz; if (rowT_ptr) rowT_ptr[N] = nnzT; }
-        s_out[0] = 0; s_out[1] = 0; s_out[2] = 0; s_out[3] = 0;          // emit_rows: first row, first entries, column shift
-        s_status = 0;
-    }
-    if (!fits) return;
-    for (int p = t; p < N; p += NT) {
-        const int w = pw[p];
-        row_ptr[p] = deg[p];
-        if (rowT_ptr) rowT_ptr[p] = degT[p];
-        po.row_sent[p] = sid[p];
-        if (pool_mask) pool_mask[p] = serr[sid[p]] ? 1 : ((deg[p + 1] - deg[p]) + (degT[p + 1] - degT[p])) == 0;
-        if (w & (F_HASEDGE << PW_SHIFT)) {
-            const int f = w >> PW_SHIFT;
-            einfo[rank[p]] = p | ((w & PW_MASK) << 12) | ((cnt[p] & K_CHILD) ? 1 << 24 : 0) |
-                             ((f & F_FWD_NZ) ? 1 << 25 : 0) | ((f & F_REV_NZ) ? 1 << 26 : 0);
-        } else {                                                         // no entries: an all-zero ELL head
-            int4* e = reinterpret_cast<int4*>(ell + (size_t)p * 8);
-            e[0] = make_int4(0, 0, 0, 0); e[1] = make_int4(0, 0, 0, 0);
-            if (ellT) {
-                int4* eT = reinterpret_cast<int4*>(ellT + (size_t)p * 8);
-                eT[0] = make_int4(0, 0, 0, 0); eT[1] = make_int4(0, 0, 0, 0);
-            }
-        }
-    }
-    __syncthreads();
-    GCNPT_STAMP(stamps, 6);
-    // the edge rows' entries and ELL heads: the per-sentence form's emission over the whole forest (rows are packed rows already: no shift)
-    const PackedEmit pe{PackedOut{}, 0, 1, row_ptr, rowT_ptr, status, pool_mask, s_red, &s_status};
-    emit_rows(s_out, M, smem, 0, n_edge_rows, lane, wave, true, col_idx, label, colT_idx, ell, ellT, stamps, pe);
-}
-
 // ---- dense float adjacency -> CSR of (adj != 0) and of its transpose (gcn.py:260-262) -----------------
 __global__ __launch_bounds__(ADJ_THREADS) void adj_to_csr_kernel(
     const float* __restrict__ adj, int B, int T, int cap, int32_t* __restrict__ row_ptr, int32_t* __restrict__ col_idx,
@@ -1392,24 +1139,6 @@ extern "C" int gcnpt_prune_to_csr_packed(void* stream, const int64_t* head, cons
         blocks = pack_side_blocks(pk, PRUNE_THREADS);
     }
     PackedOut po{cu_seqlens, row_sent, pool_mask_padded, reinterpret_cast<unsigned long long*>(sync_ws), status, n_rows, nnz_cap};
-    // a small batch: one workgroup prunes it as a forest (no hand-off between workgroups: prune_forest_kernel)
-    if (n_rows <= FOREST_MAX_ROWS && B <= FOREST_MAX_SENT && (long long)B * T <= PRUNE_SCAN_MAX && option(GCNPT_OPT_FOREST) != 0) {
-        GCNPT_REQUIRE(head && subj_pos && obj_pos && deprel && (pad_mask || len), "prune_to_csr_packed: null input pointer");
-        GCNPT_REQUIRE(row_ptr && col_idx && ell, "prune_to_csr_packed: null output pointer");
-        GCNPT_REQUIRE((rowT_ptr == nullptr) == (ellT == nullptr) && (rowT_ptr == nullptr) == (colT_idx == nullptr),
-                      "prune_to_csr_packed: rowT_ptr, colT_idx and ellT go together");
-        GCNPT_REQUIRE(B > 0 && T > 0, "prune_to_csr_packed: B and T must be positive");
-        if (prune_k < 0)
-            return fail(GCNPT_E_PRUNE_NEGATIVE, "prune_k=%d: the reference fork only works with prune_k >= 0 "
-                        "(model/tree.py:194 reads Tree.head, which the unpruned branch never sets)", prune_k);
-        const size_t lds = sizeof(int) * ((size_t)16 * n_rows + 4 + (size_t)8 * B + 1);
-        GCNPT_LDS_ATTR_ONCE(prune_forest_kernel, 160 * 1024 - 256);
-        hipLaunchKernelGGL(prune_forest_kernel, dim3(1 + blocks), dim3(PRUNE_THREADS), lds, (hipStream_t)stream, head, subj_pos, obj_pos, deprel,
-                           pad_mask, len, B, T, prune_k, row_ptr, col_idx, label, rowT_ptr, colT_idx, ell, ellT, pool_mask, sent_status,
-                           static_cast<unsigned long long*>(g_debug_stamps), pk, dtype, po);
-        GCNPT_HIP_CHECK(hipGetLastError());
-        return GCNPT_OK;
-    }
     return prune_impl(stream, head, subj_pos, obj_pos, deprel, pad_mask, len, B, T, prune_k, 3 * T, row_ptr, col_idx, label, rowT_ptr, colT_idx,
                       ell, ellT, pool_mask, sent_status, pk, dtype, blocks, po);
 }

@@ -78,16 +78,12 @@ const char* gcnpt_last_error(void);
  *   GCNPT_OPT_COL_SPLIT     (env GCNPT_COL_SPLIT, default -1 = by shape)  the column-split form of the layer kernel (bf16 MFMA operands): every
  *       32-row tile is given to 2 ... 8 workgroups that gather the same rows and each produce a share of the output columns, so that a
  *       small batch of a wide layer spreads the layer's weight fragments over the CUs that have no tile.  By itself: <= 128 row tiles and
- *       >= 170 KB of weight fragments.  0: never;  n >= 1: always, with at least n workgroups per tile (tests).  Same values bit for bit
- *   GCNPT_OPT_FOREST        (env GCNPT_FOREST, default 1)  gcnpt_prune_to_csr_packed prunes a batch of up to 1 536 token rows and 512 sentences
- *       in ONE workgroup, as a forest over its packed rows (no hand-off between workgroups); 0: always one workgroup per sentence with the
- *       in-launch look-back (tests, A/B).  Same arrays bit for bit */
+ *       >= 170 KB of weight fragments.  0: never;  n >= 1: always, with at least n workgroups per tile (tests).  Same values bit for bit */
 #define GCNPT_OPT_DETERMINISTIC 0
 #define GCNPT_OPT_FOUR_WAVES 1
 #define GCNPT_OPT_SIDE_TILES 2
 #define GCNPT_OPT_COL_SPLIT 3
-#define GCNPT_OPT_FOREST 4
-#define GCNPT_OPT_COUNT 5
+#define GCNPT_OPT_COUNT 4
 int gcnpt_set_option(int option, int value);
 int gcnpt_get_option(int option);
 

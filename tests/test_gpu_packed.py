@@ -99,17 +99,8 @@ def _same_packed(a, b, what):
         assert torch.equal(a.rowT_ptr[:N + 1], b.rowT_ptr[:N + 1]) and torch.equal(a.ellT, b.ellT) and torch.equal(a.colT_idx[:nnzT], b.colT_idx[:nnzT]), what
 
 
-@pytest.fixture(params=[1, 0], ids=["forest_form_allowed", "per_sentence_form"])
-def forest(request):
-    """Both forms of gcnpt_prune_to_csr_packed: small batches as a forest in one workgroup (default) / always a workgroup per sentence."""
-    from gcn_over_pruned_trees_amd import _lib
-    old = _lib.set_option(_lib.OPT_FOREST, request.param)
-    yield request.param
-    _lib.set_option(_lib.OPT_FOREST, old)
-
-
-@pytest.mark.parametrize("shape", ["golden_wave0", "long_allwaves", "many_sentences", "errors", "small_forest"])
-def test_prune_to_csr_packed_equals_pack_of_prune(api, dev, shape, forest):
+@pytest.mark.parametrize("shape", ["golden_wave0", "long_allwaves", "many_sentences", "errors"])
+def test_prune_to_csr_packed_equals_pack_of_prune(api, dev, shape):
     """the pruner writing the packed layout itself (gcnpt_prune_to_csr_packed: offsets by a look-back over the
     sentences before, inside the launch) gives exactly gcnpt_pack_trees(gcnpt_prune_to_csr(...)) -- every array, bit for bit -- for the
     wave-0 form (T <= 64), the all-waves form, more sentences than the chip holds workgroups (ticket order), sentences that fail,
@@ -124,7 +115,7 @@ def test_prune_to_csr_packed_equals_pack_of_prune(api, dev, shape, forest):
         head, subj, obj, dep, lens = g["head"], g["subj_pos"], g["obj_pos"], g["deprel"], g["lens"].astype(np.int64)
         Ks = (1,)
     else:
-        B, T = {"long_allwaves": (24, 300), "many_sentences": (700, 40), "small_forest": (16, 300)}[shape]   # small_forest: configs[4]'s per-GPU share
+        B, T = (24, 300) if shape == "long_allwaves" else (700, 40)
         tb = synthetic.random_tree_batch(17, B, T, "tacred", overlap_frac=0.1)
         head, subj, obj, dep, lens = tb["head"], tb["subj_pos"], tb["obj_pos"], tb["deprel"], tb["lens"].astype(np.int64)
         Ks = (1, 2)
@@ -150,7 +141,7 @@ def test_prune_to_csr_packed_equals_pack_of_prune(api, dev, shape, forest):
     _same_packed(again, one, (shape, "after capacity"))
 
 
-def test_prune_to_csr_packed_random_shapes(api, dev, forest):
+def test_prune_to_csr_packed_random_shapes(api, dev):
     """The look-back of the packed pruner under many grid shapes: 40 random (B, T, K, length profile) batches -- one sentence to more
     sentences than the chip holds workgroups, widths on both sides of the wave-0 / all-waves switch, zero-length sentences, corrupted
     parses (a failing sentence still owns its rows) -- every array equal to the two-step form, the workspace reused throughout."""

@@ -99,7 +99,7 @@ def _same_packed(a, b, what):
         assert torch.equal(a.rowT_ptr[:N + 1], b.rowT_ptr[:N + 1]) and torch.equal(a.ellT, b.ellT) and torch.equal(a.colT_idx[:nnzT], b.colT_idx[:nnzT]), what
 
 
-@pytest.mark.parametrize("shape", ["golden_wave0", "long_allwaves", "many_sentences", "errors"])
+@pytest.mark.parametrize("shape", ["golden_wave0", "long_allwaves", "many_sentences", "errors", "shard16"])
 def test_prune_to_csr_packed_equals_pack_of_prune(api, dev, shape):
     """the pruner writing the packed layout itself (gcnpt_prune_to_csr_packed: offsets by a look-back over the
     sentences before, inside the launch) gives exactly gcnpt_pack_trees(gcnpt_prune_to_csr(...)) -- every array, bit for bit -- for the
@@ -115,7 +115,7 @@ def test_prune_to_csr_packed_equals_pack_of_prune(api, dev, shape):
         head, subj, obj, dep, lens = g["head"], g["subj_pos"], g["obj_pos"], g["deprel"], g["lens"].astype(np.int64)
         Ks = (1,)
     else:
-        B, T = (24, 300) if shape == "long_allwaves" else (700, 40)
+        B, T = {"long_allwaves": (24, 300), "many_sentences": (700, 40), "shard16": (16, 300)}[shape]      # shard16: configs[4]'s per-GPU share
         tb = synthetic.random_tree_batch(17, B, T, "tacred", overlap_frac=0.1)
         head, subj, obj, dep, lens = tb["head"], tb["subj_pos"], tb["obj_pos"], tb["deprel"], tb["lens"].astype(np.int64)
         Ks = (1, 2)

@@ -80,6 +80,7 @@ def parse():
                          "async: the round-2 ring of buckets whose all-reduce nobody consumes -- an upper bound, not data-parallel SGD")
     ap.add_argument("--repeats", type=int, default=20, help="N = 1: repeats of the timed K-step region behind the contract's one, for ms_per_step_median")
     ap.add_argument("--no-clip", action="store_true", help="N > 1, A/B: plain W -= lr*g instead of the reference's clip_grad_norm_ + SGD update")
+    ap.add_argument("--torch-update", action="store_true", help="N > 1, A/B: clip + SGD update through torch's element-wise kernels instead of gcnpt_sgd_clip_update")
     ap.add_argument("--two-step-pack", action="store_true", help="A/B, packed layout with the tree build: gcnpt_prune_to_csr + gcnpt_pack_trees "
                                                                    "instead of the pruner writing the packed layout itself")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
@@ -132,6 +133,7 @@ class Stack(object):
         # parameters as views of ONE flat fp32 tensor laid out like the gradient bucket [W0, b0, W1, b1]: the N > 1 update is one add_
         self.n_grad = H * Din + H + H * H + H
         self.wflat = torch.empty((self.n_grad,), dtype=torch.float32, device=dev)
+        self.sgd_scratch = torch.empty((65,), dtype=torch.float32, device=dev)      # gcnpt_sgd_clip_update's partial sums + coefficient
         o = [0, H * Din, H * Din + H, H * Din + H + H * H, self.n_grad]
         self.W = [self.wflat[o[0]:o[1]].view(H, Din), self.wflat[o[2]:o[3]].view(H, H)]
         self.b = [self.wflat[o[1]:o[2]], self.wflat[o[3]:o[4]]]
@@ -414,7 +416,9 @@ def capture(fn, use_graph):
         fn()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: with a process group alive its watchdog thread polls events while this thread captures; under the default (global)
+        # capture mode that poll is an illegal call, the watchdog throws and the process aborts (seen once in ~4 single-rank RCCL runs)
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             fn()
         torch.cuda.synchronize()
         return g.replay, True
@@ -746,12 +750,14 @@ def main():
             replays[0][0]()
             g = stack.buckets[0]
             dist.all_reduce(g)                                       # SUM: supported by every backend; the 1/world goes into the step size
-            if args.no_clip:
-                stack.wflat.add_(g, alpha=-SGD_LR / world)
-            else:
-                # the reference's update: clip_grad_norm_(max_grad_norm = 5) then SGD (train.py:224-227), on the device, no host sync
+            if args.torch_update:                                    # A/B: the same update through six element-wise library kernels
                 coef = (MAX_GRAD_NORM / (torch.linalg.vector_norm(g) / world + 1e-6)).clamp_(max=1.0)
                 stack.wflat.addcmul_(g, coef, value=-SGD_LR / world)
+                return
+            # the reference's update: clip_grad_norm_(max_grad_norm = 5) then SGD (train.py:224-227) on the flat parameter tensor, one
+            # native call (gcnpt_sgd_clip_update: two launches, no host sync); --no-clip: the plain update
+            stack._lib.check(stack.L.gcnpt_sgd_clip_update(stack._lib.stream(), stack._lib.ptr(stack.wflat), stack._lib.ptr(g), g.numel(), 1.0 / world,
+                                                           0.0 if args.no_clip else MAX_GRAD_NORM, SGD_LR, stack._lib.ptr(stack.sgd_scratch), None))
 
         def run_async(i):
             k = i % N_BUCKETS
@@ -865,7 +871,7 @@ def main():
                        "launch": "hipGraph replay" if graphed else "eager launches from 1 native call per step (gcnpt_layers_step)",
                        "kernels_per_step": ", ".join(names),
                        "launch_trial_us_per_step": {m: round(t * 1e6, 2) for m, t in trial.items()} or None, "nnz_per_batch": stack.nnz,
-                       "dp_mode": ("synchronous SGD: step -> all_reduce(SUM) of the flat fp32 bucket (%d B) over %s -> clip to max_grad_norm %g + W -= lr*g/world on the device -> "
+                       "dp_mode": ("synchronous SGD: step -> all_reduce(SUM) of the flat fp32 bucket (%d B) over %s -> clip to max_grad_norm %g + W -= lr*g/world on the device (gcnpt_sgd_clip_update: 2 launches) -> "
                                    "the next step's weight pack reads W" % (4 * stack.n_grad, args.dist_backend, MAX_GRAD_NORM)) if (multi and exchange == "sync")
                                   else ("ASYNC RING (not synchronous SGD; --exchange async)" if multi else "none (1 GPU)"),
                        "weight_abs_drift_after_timed_steps": weight_drift if multi else None},

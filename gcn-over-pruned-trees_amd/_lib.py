@@ -56,6 +56,7 @@ SIGNATURES = {
     "gcnpt_layers_bwd": (_i, [_p, _i] + [_p] * 8 + [_i, _i] + [_p] * 4 + [_i] + [_p] * 5),
     "gcnpt_prune_to_csr_packed": (_i, [_p] * 7 + [_i, _i, _i] + [_p] * 10 + [_i, _i] + [_p] * 4 + [_i, _p, _p, _p, _i, _p, _p]),
     "gcnpt_gather_trees_packed": (_i, [_p] * 11 + [_i, _i, _i, _p, _i, _i] + [_p] * 10 + [_i, _i] + [_p] * 3 + [_i, _p, _p, _p, _i, _p, _p]),
+    "gcnpt_sgd_clip_update": (_i, [_p, _p, _p, ctypes.c_longlong, _f, _f, _f, _p, _p]),
     "gcnpt_pack_trees": (_i, [_p] * 10 + [_i, _i, _i] + [_p] * 10 + [_i, _i, _p]),
     "gcnpt_pack_rows": (_i, [_p, _p, _i, _p, _i, _i, _i, _p]),
     "gcnpt_unpack_rows": (_i, [_p, _p, _i, _p, _i, _i, _i, _p]),

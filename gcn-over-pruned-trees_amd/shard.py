@@ -77,6 +77,24 @@ class FlatGradBucket(object):
             o += p.numel()
         self.attach()
 
+    def flatten_parameters(self):
+        """Re-home the parameters' storage into ONE flat fp32 buffer, in the bucket's order (every p.data becomes a view of it; values
+        kept).  With it the whole update -- global-norm clip + SGD on all dense parameters -- is one native call on two flat buffers
+        (gcnpt_sgd_clip_update, used by sync_sgd_step when the tensors are on a GPU).  Returns the flat parameter tensor."""
+        if getattr(self, "flat_params", None) is None:
+            flat = torch.empty_like(self.flat)
+            o = 0
+            with torch.no_grad():
+                for p in self.params:
+                    if p.dtype != torch.float32:
+                        raise TypeError("flatten_parameters: fp32 parameters only")
+                    v = flat[o:o + p.numel()].view_as(p)
+                    v.copy_(p.data)
+                    p.data = v
+                    o += p.numel()
+            self.flat_params = flat
+        return self.flat_params
+
     def attach(self):
         """(Re-)point every p.grad at its slice of the flat buffer."""
         for p, v in zip(self.params, self.views):
@@ -270,16 +288,31 @@ def sync_sgd_step(dist, bucket, lr, sparse=(), weight=None, max_grad_norm=None, 
             ids, rows = ex.exchange(torch.cat([a for a, _ in rows_acc[j]]), torch.cat([b for _, b in rows_acc[j]]))
             exchanged.append((p, ids, rows))
         coef = None
-        if max_grad_norm is not None:
-            sq = acc.double().pow(2).sum()
-            for _, _, rows in exchanged:
-                sq = sq + rows.double().pow(2).sum()
-            coef = (float(max_grad_norm) / (sq.sqrt() + 1e-6)).clamp(max=1.0).to(acc.dtype)     # clip_grad_norm_'s coefficient, no host sync
-        flat = acc if coef is None else acc * coef
-        o = 0
-        for p in bucket.params:
-            p.add_(flat[o:o + p.numel()].view_as(p), alpha=-lr)
-            o += p.numel()
+        flat_w = getattr(bucket, "flat_params", None)
+        if acc.is_cuda and flat_w is not None:
+            # the dense parameters' whole update in one native call (two launches): sum of squares, clip coefficient, w -= lr * coef * g
+            from . import _lib
+            scratch = state.get("partials")
+            if scratch is None:
+                scratch = state["partials"] = torch.empty((65,), dtype=torch.float32, device=acc.device)
+            extra = None
+            if max_grad_norm is not None and exchanged:
+                extra = sum(rows.float().pow(2).sum() for _, _, rows in exchanged).reshape(1).contiguous()
+            _lib.check(_lib.lib().gcnpt_sgd_clip_update(_lib.stream(), _lib.ptr(flat_w), _lib.ptr(acc), acc.numel(), 1.0,
+                                                        float(max_grad_norm) if max_grad_norm is not None else 0.0, float(lr),
+                                                        _lib.ptr(scratch), _lib.ptr(extra) if extra is not None else None))
+            coef = scratch[64] if max_grad_norm is not None else None
+        else:
+            if max_grad_norm is not None:
+                sq = acc.double().pow(2).sum()
+                for _, _, rows in exchanged:
+                    sq = sq + rows.double().pow(2).sum()
+                coef = (float(max_grad_norm) / (sq.sqrt() + 1e-6)).clamp(max=1.0).to(acc.dtype)     # clip_grad_norm_'s coefficient, no host sync
+            flat = acc if coef is None else acc * coef
+            o = 0
+            for p in bucket.params:
+                p.add_(flat[o:o + p.numel()].view_as(p), alpha=-lr)
+                o += p.numel()
         for p, ids, rows in exchanged:
             p.index_add_(0, ids, (rows if coef is None else rows * coef).to(p.dtype), alpha=-lr)
         acc.zero_()

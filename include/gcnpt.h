@@ -87,6 +87,16 @@ const char* gcnpt_last_error(void);
 int gcnpt_set_option(int option, int value);
 int gcnpt_get_option(int option);
 
+/* ---- the data-parallel update (SURVEY.md 8 row e; reference train.py:224-227: clip_grad_norm_(max_grad_norm) then SGD) ---------------------
+ * On the flat fp32 buffers the all-reduced gradient bucket and the parameters live in (shard.FlatGradBucket):
+ *     g_eff = g * g_scale   (g_scale = 1 / world after a SUM all-reduce)
+ *     coef  = max_norm > 0 ? min(1, max_norm / (sqrt(sum(g_eff^2) + *extra_sq) + 1e-6)) : 1      (torch.nn.utils.clip_grad_norm_'s coefficient)
+ *     w    -= lr * coef * g_eff
+ * Two launches, no host sync.  partials: [dev] float[65] scratch, no initialisation needed; partials[64] = coef afterwards (for the caller's
+ * row-sparse parameters, whose squared norm -- already scaled -- comes in through extra_sq [dev] float[1] or NULL).  w, g 16-byte aligned. */
+int gcnpt_sgd_clip_update(void* stream, float* w, const float* g, long long n, float g_scale, float max_norm, float lr, float* partials,
+                          const float* extra_sq);
+
 /* ---- measurement aids (no reference counterpart) --------------------------------------------------------------
  * gcnpt_last_launch: grid, workgroup size, dynamic LDS bytes and kernel-argument bytes of the calling thread's most recent launch of
  * the layer path (pack, layer forward / backward-data, weight gradient).  gcnpt_launch_empty: enqueues a kernel of that shape whose

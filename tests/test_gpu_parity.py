@@ -1674,6 +1674,81 @@ def test_eval_forward_sees_p_data_updates(api, dev, grad_mode):
         assert not torch.allclose(after, before) and torch.equal(after.detach(), want)
 
 
+class _OneRank(object):
+    """torch.distributed's interface for a world of one (the update rule needs no second rank to be checked)."""
+    class ReduceOp(object):
+        SUM = "sum"
+
+    @staticmethod
+    def get_world_size():
+        return 1
+
+    @staticmethod
+    def all_reduce(t, op=None, async_op=False):
+        return None
+
+    @staticmethod
+    def all_gather(out, t):
+        out[0].copy_(t)
+
+
+@pytest.mark.parametrize("n", [112360, 4099, 3])
+def test_sgd_clip_update_kernel_matches_clip_grad_norm(api, dev, n):
+    """gcnpt_sgd_clip_update == torch.nn.utils.clip_grad_norm_ + SGD (reference train.py:224-227) on flat buffers: a norm above and below
+    max_norm, the gradient scale of a SUM all-reduce, the row-sparse parameters' share of the norm, odd lengths; the coefficient it leaves
+    for the caller; fp32 throughout (tolerance: rounding of one multiply-add per element)."""
+    from gcn_over_pruned_trees_amd import _lib
+    gen = torch.Generator(device="cpu").manual_seed(n)
+    w0 = torch.randn((n,), generator=gen).to(dev)
+    g = torch.randn((n,), generator=gen).to(dev) * 3.0
+    scratch = torch.empty((65,), dtype=torch.float32, device=dev)
+    for g_scale, max_norm, extra in ((0.125, 5.0, None), (1.0, 1e9, None), (0.5, 0.7, 2.5), (1.0, 0.0, None)):
+        w = w0.clone()
+        ex = torch.tensor([extra], dtype=torch.float32, device=dev) if extra is not None else None
+        _lib.check(_lib.lib().gcnpt_sgd_clip_update(_lib.stream(), _lib.ptr(w), _lib.ptr(g), n, g_scale, max_norm, 0.3, _lib.ptr(scratch),
+                                                    _lib.ptr(ex) if ex is not None else None))
+        torch.cuda.synchronize()
+        ge = g.double() * g_scale
+        norm = torch.sqrt((ge * ge).sum() + (extra or 0.0))
+        coef = min(1.0, max_norm / (float(norm) + 1e-6)) if max_norm > 0 else 1.0
+        want = w0.double() - 0.3 * coef * ge
+        assert abs(float(scratch[64]) - coef) <= 1e-6 * coef
+        assert float((w.double() - want).abs().max()) <= 2e-6 * float(want.abs().max())
+        if max_norm == 5.0 and n > 1000:
+            assert coef < 1.0                                                            # (the clip bites in the first case)
+
+
+def test_sync_sgd_step_fused_path_equals_library_path(api, dev):
+    """shard.sync_sgd_step on a GPU with flattened parameters (one native call) leaves the weights its element-wise library path leaves:
+    clipping that bites, two accumulated micro-batches, a row-sparse parameter in the norm and in the update."""
+    from gcn_over_pruned_trees_amd import shard
+    torch.manual_seed(3)
+
+    def run(flatten):
+        torch.manual_seed(11)
+        lin = [torch.nn.Linear(40, 24).to(dev), torch.nn.Linear(24, 24).to(dev)]
+        emb = torch.nn.Parameter(torch.randn(50, 8, device=dev))
+        params = [q for l in lin for q in l.parameters()]
+        bucket = shard.FlatGradBucket(params)
+        if flatten:
+            bucket.flatten_parameters()
+        ex = shard.SparseRowExchange(_OneRank)
+        state = {}
+        for micro in range(4):                                          # two updates of two micro-batches each
+            x = torch.randn(9, 40, device=dev) * (5.0 + micro)
+            idx = torch.randint(0, 50, (9,), device=dev)
+            rows = emb[idx].detach().requires_grad_()
+            y = lin[1](torch.relu(lin[0](x))).sum() * 3.0 + (rows * rows).sum()
+            y.backward()
+            done = shard.sync_sgd_step(_OneRank, bucket, 0.05, sparse=[(emb, idx, rows.grad, ex)], max_grad_norm=5.0, accumulate=2, state=state)
+            assert done == (micro % 2 == 1)
+        return [q.detach().clone() for q in params] + [emb.detach().clone()]
+
+    a, b = run(True), run(False)
+    for u, v in zip(a, b):
+        assert float((u - v).abs().max()) <= 2e-6 * float(v.abs().max())
+
+
 def test_sparse_embedding_gradient_equals_dense(api, dev):
     """opt['gcn_sparse_emb_grad']: the word table's gradient as a row-sparse tensor (what shard.SparseRowExchange exchanges between
     ranks instead of the dense [V, E] all-reduce) holds exactly the dense gradient, topn (gcn.py:84-88) and the padding row included."""

@@ -705,12 +705,13 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (the host driver only supports dmabuf IPC: RCCL across processes needs it)
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         if os.environ.get("GCNPT_BENCH_ONE_DEVICE"):          # rehearsal of the N > 1 code path on a 1-GPU box (with --dist-backend gloo)
             local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group(args.dist_backend)
+        dist.init_process_group(args.dist_backend, device_id=torch.device("cuda", local) if args.dist_backend == "nccl" else None)
         barrier = dist.barrier
     else:
         dist = None

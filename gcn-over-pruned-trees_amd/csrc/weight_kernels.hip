@@ -114,8 +114,14 @@ static int launch_weight_grad_cfg(hipStream_t s, const WeightGradMulti& mp) {
 
 // waves per workgroup / workgroups the launch may have: small batches are one latency chain per CU (8 waves when layers share the
 // CUs); from 512 k-steps (16 k rows) on the fragment stream through the CUs' L1 paths is what counts: 4-wave workgroups, 2 per CU
-static int wg_waves(int n_layers, int nks) { return (n_layers > 1 && nks < 512) ? 8 : 4; }
-static int wg_budget(int nks) { return nks < 512 ? 256 : 512; }
+#ifndef GCNPT_WG_SINGLE_WAVES
+#define GCNPT_WG_SINGLE_WAVES 4      // waves per workgroup when a launch holds ONE layer's gradient of a small batch (A/B: 4 / 8)
+#endif
+#ifndef GCNPT_WG_SMALL_BUDGET
+#define GCNPT_WG_SMALL_BUDGET 256    // workgroups a small batch's launch may have (A/B: 128 / 256 / 512)
+#endif
+static int wg_waves(int n_layers, int nks) { return nks < 512 ? (n_layers > 1 ? 8 : GCNPT_WG_SINGLE_WAVES) : 4; }
+static int wg_budget(int nks) { return nks < 512 ? GCNPT_WG_SMALL_BUDGET : 512; }
 // (4 x 3)-tile blocks of all layers of a launch: the budget is shared in proportion to them, so every workgroup gets the same k-steps
 static int wg_nt(int nks) { return nks < 512 ? WG_NT : 6; }       // output tiles per block row: wide blocks for big batches (see the kernel)
 static int wg_blocks(int n_layers, const int* Din, const int* H, int nt) {

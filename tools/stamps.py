@@ -3,7 +3,8 @@
 Developer diagnostic: per-phase cycle stamps of the hot kernels (needs `make -C gcn-over-pruned-trees_amd/csrc stamps`).
 Runs the bench workload with libgcnpt_stamps.so and prints, for every launch of the step, per stamp interval the median /
 max cycles over workgroups, the dispatch skew (100 MHz real time) and the first-start -> last-end span.  Row-tile workgroups stamp
-slots 0-10, a weight-gradient unit slots 11-14 (the LAST unit a workgroup ran), a passenger workgroup 0 (entry) and 10 (exit).
+slots 0-10 (the column-split form 0-8 and 9-11 inside its gather), a weight-gradient unit slots 11-14 (the LAST unit a workgroup ran), a
+passenger workgroup 0 (entry) and 10 (exit).
 Not part of the product; timings of this build are NOT quoted anywhere (the stamps forbid overlaps).
 """
 import ctypes
@@ -64,16 +65,16 @@ def main():
         stack.step_native()
     torch.cuda.synchronize()
     # the tree build (slots: 0 entry, 1 parse staged, 2 entity chains, 3 LCA, 4 distances, 5 degrees + scans, 6 row info, 8 -> 7 rows emitted)
-    if True:                                        # (padded: gcnpt_prune_to_csr; packed: gcnpt_prune_to_csr_packed)
-        for _ in range(3):
-            stack.prune()
-        torch.cuda.synchronize()
-        buf.zero_()
-        L.gcnpt_debug_set_stamps(buf.data_ptr())
+    # (padded layout: gcnpt_prune_to_csr; token-packed: gcnpt_prune_to_csr_packed)
+    for _ in range(3):
         stack.prune()
-        torch.cuda.synchronize()
-        L.gcnpt_debug_set_stamps(None)
-        report("prune", buf.cpu().numpy().reshape(-1, 16).astype(np.int64))
+    torch.cuda.synchronize()
+    buf.zero_()
+    L.gcnpt_debug_set_stamps(buf.data_ptr())
+    stack.prune()
+    torch.cuda.synchronize()
+    L.gcnpt_debug_set_stamps(None)
+    report("prune", buf.cpu().numpy().reshape(-1, 16).astype(np.int64))
     if os.environ.get("GCNPT_STAMPS_PRUNE_ONLY"):
         return
     for k in range(2, len(names) + 1):              # (the pack kernel has no stamps)

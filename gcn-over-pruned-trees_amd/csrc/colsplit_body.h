@@ -39,7 +39,10 @@ __global__ __launch_bounds__(RT_THREADS, 2) void rowtile_colsplit_kernel(const R
     constexpr bool MASKED = BWD && !DZIN;
     constexpr int KSTEP = 32;
     constexpr bool WIDE = MASKED && sizeof(IT) == 4;
-    constexpr int NBU = WIDE ? 2 : 4;
+#ifndef GCNPT_CS_NBU
+#define GCNPT_CS_NBU 4               // neighbour rows an item requests together when the rows are ready-made (A/B: 4 / 7 = the whole ELL head)
+#endif
+    constexpr int NBU = MASKED ? (WIDE ? 2 : 4) : GCNPT_CS_NBU;
     const int stride = lds_stride_dw(p.Kpad * (int)sizeof(CT) / 4) * 4 / (int)sizeof(CT);
     const int ncols_pass = p.tiles_pp * 16;
     const int ostride = out_stride_dw(min(round_up(p.NOUT, 16), ncols_pass) * (int)sizeof(OT) / 4) * 4 / (int)sizeof(OT);

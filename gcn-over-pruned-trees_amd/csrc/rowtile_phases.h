@@ -141,16 +141,26 @@ struct TileGather {
     __device__ __forceinline__ void issue(int n_g, int gi, GatherItem<IT, NBU>& g) const {
         int row, k0, n;
         decode(n_g, gi, row, k0, n);
-        const size_t r = (size_t)min(r0 + row, p.N - 1);
+        size_t r = (size_t)min(r0 + row, p.N - 1);
         const int sbase = m.rsb[row];                                  // first row of this row's sentence
-        const int k0c = min(k0, kmax8());
+        int k0c = min(k0, kmax8());
+#ifdef GCNPT_STAMPS
+        const bool in_lds = (p.knob & 64) != 0;                       // experiment (timing only, wrong values): what an in-tile neighbour and the
+        if (in_lds) { r = (size_t)r0; k0c = 0; }                      // item's own piece would cost if they came from the parked rows in LDS
+#endif
         ld8(src(), r, k0c, g.s);
         if (MASKED) ld8(yref(), r, k0c, g.sy);
+#ifdef GCNPT_STAMPS
+        k0c = min(k0, kmax8());
+#endif
 #pragma unroll
         for (int e = 0; e < NBU; ++e) {
             // no e-th neighbour: the first 16 bytes of the tile's first row, one cache line for all such lanes.  (NOT the
             // item's own row: hipcc would then reuse the load above, wait for it, and branch around the others.)
-            const bool on = e < min(n, NB_INLINE);
+            bool on = e < min(n, NB_INLINE);
+#ifdef GCNPT_STAMPS
+            if (in_lds && on) { const int cc = sbase + m.rell[row * 8 + 1 + e]; if (cc >= r0 && cc < r0 + ROWS) on = false; }
+#endif
             const size_t c = on ? (size_t)(sbase + m.rell[row * 8 + 1 + e]) : (size_t)r0;
             const int kc = on ? k0c : 0;
             ld8(src(), c, kc, g.nb[e]);

@@ -377,3 +377,11 @@ def test_classifier_packed_matches_golden_logits(api, dev, fixture):
         outs[packed] = (logits.cpu().numpy(), pooled.cpu().numpy())
     assert max_rel(outs[True][0], e["logits"]) <= 1e-4
     assert max_rel(outs[True][0], outs[False][0]) <= 1e-5 and max_rel(outs[True][1], outs[False][1]) <= 1e-5
+    # the same batch with its packed trees assembled from a dataset pruned once (TreeCache.batch_packed): the model takes them as `trees=`
+    head, subj, obj, dep, masks = (_t(e[k], dev) for k in ("head", "subj_pos", "obj_pos", "deprel", "masks"))
+    lens = (~masks.bool()).sum(1).to(torch.int32)
+    cache = tree.TreeCache.build(head, subj, obj, dep, opt["prune_k"], lens=lens, want_label=False)
+    ids = torch.arange(head.shape[0], device=dev)
+    with torch.no_grad():
+        logits_c, pooled_c = model(inputs, trees=cache.batch_packed(ids, head.shape[1], n_rows=int(lens.sum())))
+    assert np.array_equal(logits_c.cpu().numpy(), outs[True][0]) and np.array_equal(pooled_c.cpu().numpy(), outs[True][1])
